@@ -1,0 +1,187 @@
+"""ctypes binding of the TEST oracle (oracle/liboracle_reorder.so).
+
+TEST INFRASTRUCTURE: importable only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (spring_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "unmatched", "search_calls", "probes", "keyok", "cands", "hits", "updates",
+        "iterations", "rounds", "lost")]
+
+    def asdict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class OrcOut(C.Structure):
+    _fields_ = [
+        ("order", C.c_void_p), ("rc", C.c_void_p), ("flag", C.c_void_p), ("pos", C.c_void_p),
+        ("rlen", C.c_void_p), ("order_s", C.c_void_p), ("tid_off", C.c_void_p),
+        ("tid_off_s", C.c_void_p), ("n_matched", C.c_uint64), ("n_single", C.c_uint64)]
+
+
+def build():
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle_reorder.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_limbs.restype = C.c_int
+        L.orc_load_dna.restype = C.c_int64
+        L.orc_load_dna.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_reorder_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                         C.POINTER(OrcOut), C.POINTER(OrcStats)]
+        L.orc_reorder_rounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
+                                         C.POINTER(OrcOut), C.POINTER(OrcStats)]
+        L.orc_write_dna_stream.restype = C.c_size_t
+        L.orc_write_dna_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_uint64, C.c_void_p]
+        L.orc_build_dict.restype = C.c_uint32
+        L.orc_build_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_bin_remove.restype = C.c_int64
+        L.orc_bin_remove.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
+        L.orc_bin_live.restype = C.c_int64
+        L.orc_bin_live.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_hamming_range.restype = C.c_int
+        L.orc_hamming_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_updaterefcount.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_dict_windows.argtypes = [C.c_int, C.POINTER(C.c_int * 2), C.POINTER(C.c_int * 2)]
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """The real reference bitset_util build (oracle/_ref), or None if absent."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libref_bitset.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_build_dict.restype = C.c_int
+        R.ref_build_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        R.ref_bin_remove.restype = C.c_int64
+        R.ref_bin_remove.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64]
+        R.ref_bin_live.restype = C.c_int64
+        R.ref_bin_live.argtypes = [C.c_void_p, C.c_uint32]
+        R.ref_mask_hamming.restype = C.c_int
+        R.ref_mask_hamming.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _REF = R
+    return _REF
+
+
+def limbs(L):
+    return (2 * L - 1) // 64 + 1
+
+
+def dict_windows(L):
+    s = (C.c_int * 2)()
+    e = (C.c_int * 2)()
+    lib().orc_dict_windows(L, C.byref(s), C.byref(e))
+    return list(s), list(e)
+
+
+def load_dna(dna: bytes, n: int, L: int):
+    """readDnaFile: -> (read limbs [n,W] u64, lengths [n] u16)."""
+    W = limbs(L)
+    read = np.zeros((max(n, 1), W), dtype=np.uint64)
+    ln = np.zeros(max(n, 1), dtype=np.uint16)
+    buf = np.frombuffer(dna, dtype=np.uint8)
+    used = lib().orc_load_dna(buf.ctypes.data if len(buf) else None, len(buf), n, L,
+                              read.ctypes.data, ln.ctypes.data)
+    if used < 0:
+        raise ValueError("malformed .dna stream")
+    return read[:n], ln[:n]
+
+
+def _alloc_out(n, num_thr):
+    m = max(n, 1)
+    arrs = dict(order=np.zeros(m, np.uint32), rc=np.zeros(m, np.uint8), flag=np.zeros(m, np.uint8),
+                pos=np.zeros(m, np.int64), rlen=np.zeros(m, np.uint16), order_s=np.zeros(m, np.uint32),
+                tid_off=np.zeros(num_thr + 1, np.uint64), tid_off_s=np.zeros(num_thr + 1, np.uint64))
+    o = OrcOut()
+    for k, a in arrs.items():
+        setattr(o, k, a.ctypes.data)
+    return o, arrs
+
+
+def _finish(o, arrs, st):
+    nm, ns = int(o.n_matched), int(o.n_single)
+    return dict(order=arrs["order"][:nm].copy(), rc=arrs["rc"][:nm].copy(), flag=arrs["flag"][:nm].copy(),
+                pos=arrs["pos"][:nm].copy(), rlen=arrs["rlen"][:nm].copy(),
+                order_s=arrs["order_s"][:ns].copy(), tid_off=arrs["tid_off"].copy(),
+                tid_off_s=arrs["tid_off_s"].copy(), stats=st.asdict())
+
+
+def reorder_serial(read, ln, L):
+    """Literal `-t 1` restatement of reorder_main<N>()."""
+    n = len(ln)
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    o, arrs = _alloc_out(n, 1)
+    st = OrcStats()
+    rc = lib().orc_reorder_serial(read.ctypes.data, ln.ctypes.data, n, L, C.byref(o), C.byref(st))
+    assert rc == 0
+    return _finish(o, arrs, st)
+
+
+def reorder_rounds(read, ln, L, num_chains, num_thr=1):
+    """Deterministic K-chain lock-step schedule (the spec the GPU path follows)."""
+    n = len(ln)
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    o, arrs = _alloc_out(n, num_thr)
+    st = OrcStats()
+    rc = lib().orc_reorder_rounds(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr,
+                                  C.byref(o), C.byref(st))
+    assert rc == 0
+    return _finish(o, arrs, st)
+
+
+def write_dna_stream(read, ln, L, order, rc=None):
+    """writetofile(): bytes of temp.dna.<tid> (rc given) or temp.dna.singleton (rc None)."""
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    cnt = len(order)
+    dst = np.zeros(cnt * (2 + (L + 3) // 4) + 8, dtype=np.uint8)
+    rcp = None
+    if rc is not None:
+        rc = np.ascontiguousarray(rc, dtype=np.uint8)
+        rcp = rc.ctypes.data
+    nb = lib().orc_write_dna_stream(read.ctypes.data, ln.ctypes.data, L, order.ctypes.data, rcp, cnt,
+                                    dst.ctypes.data)
+    return dst[:nb].tobytes()
+
+
+def build_dict(read, ln, L, which):
+    n = len(ln)
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    keys = np.zeros(max(n, 1), np.uint64)
+    sp = np.zeros(n + 2, np.uint32)
+    ids = np.zeros(max(n, 1), np.uint32)
+    dn = C.c_uint32()
+    nk = lib().orc_build_dict(read.ctypes.data, ln.ctypes.data, n, L, which, keys.ctypes.data,
+                              sp.ctypes.data, ids.ctypes.data, C.byref(dn))
+    return keys[:nk].copy(), sp[:nk + 1].copy(), ids[:dn.value].copy()

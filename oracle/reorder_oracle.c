@@ -1,0 +1,950 @@
+/*
+ * oracle/reorder_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of SPRING's reorder stage.  Every function cites the
+ * reference lines it follows (paths relative to /root/reference/src).
+ * See reorder_oracle.h for who may call this and oracle/README.md for the
+ * pinning status.
+ */
+#include "reorder_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define MAX_SEARCH_REORDER 1000           /* params.h:26 */
+#define THRESH_REORDER 4                  /* params.h:27 */
+#define MAX_NUM_READS 4294967290u         /* params.h:24 */
+#define STOP_CRITERIA_REORDER 0.5f        /* params.h:30 */
+
+/* ------------------------------------------------------------------ limbs */
+
+int orc_limbs(int L) { return (2 * L - 1) / 64 + 1; } /* call_template_functions.cpp:10 */
+
+/* bits [bitpos, bitpos+nbits) of a W-limb little-endian bitset, nbits<=64 */
+static inline uint64_t window64(const uint64_t *b, int W, int bitpos, int nbits) {
+  int li = bitpos >> 6, off = bitpos & 63;
+  uint64_t v = li < W ? b[li] >> off : 0;
+  if (off && li + 1 < W) v |= b[li + 1] << (64 - off);
+  if (nbits < 64) v &= ((1ULL << nbits) - 1);
+  return v;
+}
+
+/* std::bitset<W*64> operator>>=(2) / operator<<=(2) (reorder.h:556-557) */
+static inline void shr2(uint64_t *b, int W) {
+  for (int i = 0; i < W; i++) b[i] = (b[i] >> 2) | (i + 1 < W ? b[i + 1] << 62 : 0);
+}
+static inline void shl2(uint64_t *b, int W) {
+  for (int i = W - 1; i >= 0; i--) b[i] = (b[i] << 2) | (i ? b[i - 1] >> 62 : 0);
+}
+
+/* ((a ^ b) & mask[lo][L-hi]).count() where the mask covers bases [lo,hi)
+ * (generatemasks, bitset_util.h:223-236; use at reorder.h:291-301) */
+static inline int hamming_range(const uint64_t *a, const uint64_t *b, int W, int lo, int hi) {
+  if (hi <= lo) return 0;
+  int blo = 2 * lo, bhi = 2 * hi, c = 0;
+  for (int i = blo >> 6; i < W && i * 64 < bhi; i++) {
+    uint64_t x = a[i] ^ b[i];
+    int s = i * 64;
+    if (blo > s) x &= ~0ULL << (blo - s);
+    if (bhi < s + 64) x &= (1ULL << (bhi - s)) - 1;
+    c += __builtin_popcountll(x);
+  }
+  return c;
+}
+
+/* ----------------------------------------------------- chars <-> 2 bits */
+
+/* bitsettostring (reorder.h:76-92): code 0..3 -> A,G,C,T */
+static void bits_to_string(const uint64_t *b, int W, char *s, int readlen) {
+  static const char revinttochar[4] = {'A', 'G', 'C', 'T'};
+  for (int j = 0; j < readlen; j++) s[j] = revinttochar[window64(b, W, 2 * j, 2)];
+  s[readlen] = '\0';
+}
+
+/* chartobitset (bitset_util.h:238-244) with basemask of reorder.h:94-108:
+ * A=00, G: bit 2i, C: bit 2i+1, T: both */
+static void string_to_bits(const char *s, int readlen, uint64_t *b, int W) {
+  memset(b, 0, sizeof(uint64_t) * W);
+  for (int i = 0; i < readlen; i++) {
+    uint64_t v;
+    switch (s[i]) {
+      case 'A': v = 0; break;
+      case 'G': v = 1; break;
+      case 'C': v = 2; break;
+      default: v = 3; break; /* 'T' */
+    }
+    b[(2 * i) >> 6] |= v << ((2 * i) & 63);
+  }
+}
+
+/* reverse_complement (util.cpp:376-381, table util.h:23-29) */
+static void reverse_complement(const char *s, char *s1, int readlen) {
+  for (int j = 0; j < readlen; j++) {
+    char c = s[readlen - j - 1];
+    s1[j] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+  }
+  s1[readlen] = '\0';
+}
+
+size_t orc_pack_read(const char *s, int len, uint8_t *dst) { /* util.cpp:269-294 */
+  uint16_t readlen = (uint16_t)len;
+  memcpy(dst, &readlen, 2);
+  int nb = (len + 3) / 4;
+  for (int i = 0; i < nb; i++) dst[2 + i] = 0;
+  for (int i = 0; i < len; i++) {
+    uint8_t v = s[i] == 'A' ? 0 : s[i] == 'C' ? 2 : s[i] == 'G' ? 1 : 3;
+    dst[2 + i / 4] |= (uint8_t)(v << (2 * (i % 4)));
+  }
+  return 2 + (size_t)nb;
+}
+
+int64_t orc_load_dna(const uint8_t *dna, size_t nbytes, uint32_t n, int L, uint64_t *read,
+                     uint16_t *len) { /* reorder.h:222-244 */
+  int W = orc_limbs(L);
+  size_t p = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (p + 2 > nbytes) return -1;
+    uint16_t l;
+    memcpy(&l, dna + p, 2);
+    p += 2;
+    size_t nb = ((uint32_t)l + 3) / 4;
+    if (p + nb > nbytes || (int)l > L) return -1;
+    memcpy((uint8_t *)(read + (size_t)i * W), dna + p, nb); /* raw copy into bitset memory */
+    len[i] = l;
+    p += nb;
+  }
+  return (int64_t)p;
+}
+
+void orc_dict_windows(int L, int start[2], int end[2]) { /* reorder.h:751-759 */
+  start[0] = L > 100 ? L / 2 - 32 : L / 2 - L * 32 / 100;
+  end[0] = L / 2 - 1;
+  start[1] = L / 2;
+  end[1] = L > 100 ? L / 2 - 1 + 32 : L / 2 - 1 + L * 32 / 100;
+}
+
+/* ------------------------------------------------------------ dictionary */
+
+typedef struct {
+  int start, end;
+  uint32_t numkeys, dict_numreads;
+  uint64_t *keys;     /* sorted unique (stand-in for the MPHF domain)        */
+  uint32_t *startpos; /* numkeys+1 */
+  uint32_t *read_id;  /* dict_numreads */
+  uint8_t *empty_bin; /* numkeys */
+  uint32_t *htab;     /* exact key -> bin index+1 (replaces boomphf lookup,  */
+  uint64_t hmask;     /*  BooPHF.h:851; any exact map gives the same output) */
+} dict_t;
+
+static inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+static int cmp_u64(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : x > y;
+}
+
+/* returns bin index or -1 (the reference gets >= numkeys or a false positive
+ * that fails the key check at reorder.h:282-285) */
+static inline int64_t dict_lookup(const dict_t *d, uint64_t key) {
+  if (d->numkeys == 0) return -1;
+  uint64_t h = mix64(key) & d->hmask;
+  for (;;) {
+    uint32_t v = d->htab[h];
+    if (!v) return -1;
+    if (d->keys[v - 1] == key) return (int64_t)v - 1;
+    h = (h + 1) & d->hmask;
+  }
+}
+
+static inline uint64_t read_key(const uint64_t *r, int W, const dict_t *d) {
+  /* (read & mask1) >> 2*start  (bitset_util.h:64-72,:94-95) */
+  return window64(r, W, 2 * d->start, 2 * (d->end - d->start + 1));
+}
+
+/* constructdictionary (bitset_util.h:74-221) */
+static void dict_build(dict_t *d, const uint64_t *read, const uint16_t *len, uint32_t n, int W) {
+  uint64_t *ull = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+  d->dict_numreads = 0;
+  for (uint32_t i = 0; i < n; i++) /* :83-105 */
+    if ((int)len[i] > d->end) ull[d->dict_numreads++] = read_key(read + (size_t)i * W, W, d);
+  uint64_t *allkeys = (uint64_t *)malloc(sizeof(uint64_t) * (d->dict_numreads ? d->dict_numreads : 1));
+  memcpy(allkeys, ull, sizeof(uint64_t) * d->dict_numreads);
+  qsort(ull, d->dict_numreads, sizeof(uint64_t), cmp_u64); /* :123 */
+  uint32_t k = 0;
+  if (d->dict_numreads) {
+    for (uint32_t i = 1; i < d->dict_numreads; i++)
+      if (ull[i] != ull[k]) ull[++k] = ull[i];
+    d->numkeys = k + 1;
+  } else {
+    d->numkeys = 0;
+  }
+  d->keys = ull;
+  uint64_t cap = 2;
+  while (cap < 2ull * d->numkeys) cap <<= 1;
+  d->hmask = cap - 1;
+  d->htab = (uint32_t *)calloc(cap, sizeof(uint32_t));
+  for (uint32_t i = 0; i < d->numkeys; i++) {
+    uint64_t h = mix64(d->keys[i]) & d->hmask;
+    while (d->htab[h]) h = (h + 1) & d->hmask;
+    d->htab[h] = i + 1;
+  }
+  /* counting sort into CSR bins, ascending read id inside a bin (:172-215) */
+  d->startpos = (uint32_t *)calloc((size_t)d->numkeys + 1, sizeof(uint32_t));
+  d->empty_bin = (uint8_t *)calloc(d->numkeys ? d->numkeys : 1, 1);
+  d->read_id = (uint32_t *)malloc(sizeof(uint32_t) * (d->dict_numreads ? d->dict_numreads : 1));
+  for (uint32_t j = 0; j < d->dict_numreads; j++) d->startpos[dict_lookup(d, allkeys[j]) + 1]++;
+  for (uint32_t i = 1; i < d->numkeys; i++) d->startpos[i] += d->startpos[i - 1];
+  uint32_t i = 0;
+  for (uint32_t j = 0; j < d->dict_numreads; j++) {
+    while ((int)len[i] <= d->end) i++;
+    d->read_id[d->startpos[dict_lookup(d, allkeys[j])]++] = i;
+    i++;
+  }
+  for (int64_t keynum = d->numkeys; keynum >= 1; keynum--) d->startpos[keynum] = d->startpos[keynum - 1];
+  if (d->numkeys) d->startpos[0] = 0;
+  free(allkeys);
+}
+
+static void dict_free(dict_t *d) {
+  free(d->keys); free(d->startpos); free(d->read_id); free(d->empty_bin); free(d->htab);
+}
+
+/* bbhashdict::findpos (bitset_util.cpp:20-35) */
+static inline void findpos(const dict_t *d, int64_t *dictidx, uint64_t startposidx) {
+  dictidx[0] = d->startpos[startposidx];
+  uint32_t endidx = d->startpos[startposidx + 1];
+  if (d->read_id[endidx - 1] == MAX_NUM_READS)
+    dictidx[1] = endidx - 1;
+  else if (d->read_id[endidx - 1] == MAX_NUM_READS + 1)
+    dictidx[1] = dictidx[0] + d->read_id[endidx - 2];
+  else
+    dictidx[1] = endidx;
+}
+
+/* bbhashdict::remove (bitset_util.cpp:37-63) */
+static inline void bin_remove(dict_t *d, int64_t *dictidx, uint64_t startposidx, int64_t current) {
+  int64_t size = dictidx[1] - dictidx[0];
+  if (size == 1) {
+    d->empty_bin[startposidx] = 1;
+    return;
+  }
+  /* std::lower_bound(read_id+dictidx[0], read_id+dictidx[1], current) */
+  int64_t lo = dictidx[0], hi = dictidx[1];
+  while (lo < hi) {
+    int64_t mid = lo + (hi - lo) / 2;
+    if ((int64_t)d->read_id[mid] < current) lo = mid + 1; else hi = mid;
+  }
+  for (int64_t i = lo; i < dictidx[1] - 1; i++) d->read_id[i] = d->read_id[i + 1];
+  uint32_t endidx = d->startpos[startposidx + 1];
+  if (dictidx[1] == endidx)
+    d->read_id[endidx - 1] = MAX_NUM_READS;
+  else if (d->read_id[endidx - 1] == MAX_NUM_READS) {
+    d->read_id[endidx - 1] = MAX_NUM_READS + 1;
+    d->read_id[endidx - 2] = (uint32_t)(size - 1);
+  } else
+    d->read_id[endidx - 2]--;
+}
+
+uint32_t orc_build_dict(const uint64_t *read, const uint16_t *len, uint32_t n, int L, int which,
+                        uint64_t *keys_out, uint32_t *startpos_out, uint32_t *read_id_out,
+                        uint32_t *dict_numreads) {
+  int s[2], e[2];
+  orc_dict_windows(L, s, e);
+  dict_t d;
+  memset(&d, 0, sizeof(d));
+  d.start = s[which];
+  d.end = e[which];
+  dict_build(&d, read, len, n, orc_limbs(L));
+  memcpy(keys_out, d.keys, sizeof(uint64_t) * d.numkeys);
+  memcpy(startpos_out, d.startpos, sizeof(uint32_t) * ((size_t)d.numkeys + 1));
+  memcpy(read_id_out, d.read_id, sizeof(uint32_t) * d.dict_numreads);
+  *dict_numreads = d.dict_numreads;
+  uint32_t nk = d.numkeys;
+  dict_free(&d);
+  return nk;
+}
+
+int64_t orc_bin_live(const uint32_t *read_id, uint32_t cap) {
+  dict_t d;
+  uint32_t sp[2] = {0, cap};
+  d.startpos = sp;
+  d.read_id = (uint32_t *)read_id;
+  int64_t di[2];
+  findpos(&d, di, 0);
+  return di[1] - di[0];
+}
+
+int64_t orc_bin_remove(uint32_t *read_id, uint32_t cap, uint8_t *empty_bin, int64_t current) {
+  dict_t d;
+  uint32_t sp[2] = {0, cap};
+  d.startpos = sp;
+  d.read_id = read_id;
+  d.empty_bin = empty_bin;
+  int64_t di[2];
+  findpos(&d, di, 0);
+  bin_remove(&d, di, 0, current);
+  findpos(&d, di, 0);
+  return di[1] - di[0];
+}
+
+/* -------------------------------------------------------- updaterefcount */
+
+typedef struct {
+  int32_t cnt[4][ORC_MAX_READ_LEN + 1];
+  uint64_t ref[ORC_WMAX], revref[ORC_WMAX];
+  int ref_len;
+} cons_t;
+
+static inline int chartoint(char a) { return (a & 0x06) >> 1; } /* reorder.h:121-123: A0 C1 T2 G3 */
+
+/* updaterefcount (reorder.h:110-220), loops kept literal (order-sensitive,
+ * including the in-place aliasing of the first reverse case). */
+static void updaterefcount(const uint64_t *cur, cons_t *c, int resetcount, int rev, int shift,
+                           int cur_readlen, int max_readlen, int W, orc_stats *st) {
+  static const char inttochar[4] = {'A', 'C', 'T', 'G'};
+  char s[ORC_MAX_READ_LEN + 1], s1[ORC_MAX_READ_LEN + 1], *current;
+  int32_t(*count)[ORC_MAX_READ_LEN + 1] = c->cnt;
+  int ref_len = c->ref_len;
+  st->updates++;
+  bits_to_string(cur, W, s, cur_readlen);
+  if (!rev)
+    current = s;
+  else {
+    reverse_complement(s, s1, cur_readlen);
+    current = s1;
+  }
+  if (resetcount) { /* :133-142 */
+    for (int j = 0; j < 4; j++) memset(count[j], 0, sizeof(int32_t) * max_readlen);
+    for (int i = 0; i < cur_readlen; i++) count[chartoint(current[i])][i] = 1;
+    ref_len = cur_readlen;
+  } else {
+    if (!rev) { /* :144-156 */
+      for (int i = 0; i < ref_len - shift; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = count[j][i + shift];
+        if (i < cur_readlen) count[chartoint(current[i])][i] += 1;
+      }
+      for (int i = ref_len - shift; i < cur_readlen; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = 0;
+        count[chartoint(current[i])][i] = 1;
+      }
+      ref_len = ref_len - shift > cur_readlen ? ref_len - shift : cur_readlen;
+    } else { /* :157-200 */
+      if (cur_readlen - shift >= ref_len) {
+        for (int i = cur_readlen - shift - ref_len; i < cur_readlen - shift; i++) {
+          for (int j = 0; j < 4; j++) count[j][i] = count[j][i - (cur_readlen - shift - ref_len)];
+          count[chartoint(current[i])][i] += 1;
+        }
+        for (int i = 0; i < cur_readlen - shift - ref_len; i++) {
+          for (int j = 0; j < 4; j++) count[j][i] = 0;
+          count[chartoint(current[i])][i] = 1;
+        }
+        for (int i = cur_readlen - shift; i < cur_readlen; i++) {
+          for (int j = 0; j < 4; j++) count[j][i] = 0;
+          count[chartoint(current[i])][i] = 1;
+        }
+        ref_len = cur_readlen;
+      } else if (ref_len + shift <= max_readlen) {
+        for (int i = ref_len - cur_readlen + shift; i < ref_len; i++)
+          count[chartoint(current[i - (ref_len - cur_readlen + shift)])][i] += 1;
+        for (int i = ref_len; i < ref_len + shift; i++) {
+          for (int j = 0; j < 4; j++) count[j][i] = 0;
+          count[chartoint(current[i - (ref_len - cur_readlen + shift)])][i] = 1;
+        }
+        ref_len = ref_len + shift;
+      } else {
+        for (int i = 0; i < max_readlen - shift; i++)
+          for (int j = 0; j < 4; j++) count[j][i] = count[j][i + (ref_len + shift - max_readlen)];
+        for (int i = max_readlen - cur_readlen; i < max_readlen - shift; i++)
+          count[chartoint(current[i - (max_readlen - cur_readlen)])][i] += 1;
+        for (int i = max_readlen - shift; i < max_readlen; i++) {
+          for (int j = 0; j < 4; j++) count[j][i] = 0;
+          count[chartoint(current[i - (max_readlen - cur_readlen)])][i] = 1;
+        }
+        ref_len = max_readlen;
+      }
+    }
+    for (int i = 0; i < ref_len; i++) { /* :204-212 */
+      int max = 0, indmax = 0;
+      for (int j = 0; j < 4; j++)
+        if (count[j][i] > max) {
+          max = count[j][i];
+          indmax = j;
+        }
+      current[i] = inttochar[indmax];
+    }
+  }
+  string_to_bits(current, ref_len, c->ref, W); /* :214-217 */
+  char revcurrent[ORC_MAX_READ_LEN + 1];
+  reverse_complement(current, revcurrent, ref_len);
+  string_to_bits(revcurrent, ref_len, c->revref, W);
+  c->ref_len = ref_len;
+}
+
+/* -------------------------------------------------------- output helpers */
+
+typedef struct {
+  uint32_t *order; char *rc; char *flag; int64_t *pos; uint16_t *rlen;
+  uint64_t n, cap;
+  uint32_t *order_s; uint64_t ns, caps;
+} outbuf_t;
+
+static void ob_push(outbuf_t *o, uint32_t order, char rc, char flag, int64_t pos, uint16_t rlen) {
+  if (o->n == o->cap) {
+    o->cap = o->cap ? o->cap * 2 : 64;
+    o->order = (uint32_t *)realloc(o->order, o->cap * sizeof(uint32_t));
+    o->rc = (char *)realloc(o->rc, o->cap);
+    o->flag = (char *)realloc(o->flag, o->cap);
+    o->pos = (int64_t *)realloc(o->pos, o->cap * sizeof(int64_t));
+    o->rlen = (uint16_t *)realloc(o->rlen, o->cap * sizeof(uint16_t));
+  }
+  o->order[o->n] = order; o->rc[o->n] = rc; o->flag[o->n] = flag; o->pos[o->n] = pos; o->rlen[o->n] = rlen;
+  o->n++;
+}
+static void ob_push_s(outbuf_t *o, uint32_t order) {
+  if (o->ns == o->caps) {
+    o->caps = o->caps ? o->caps * 2 : 64;
+    o->order_s = (uint32_t *)realloc(o->order_s, o->caps * sizeof(uint32_t));
+  }
+  o->order_s[o->ns++] = order;
+}
+static void ob_free(outbuf_t *o) {
+  free(o->order); free(o->rc); free(o->flag); free(o->pos); free(o->rlen); free(o->order_s);
+}
+
+/* ----------------------------------------------------------- serial path */
+
+typedef struct {
+  const uint64_t *read;
+  const uint16_t *len;
+  uint32_t n;
+  int L, W, maxshift;
+  dict_t dict[2];
+  uint8_t *remainingreads;
+  orc_stats *st;
+} ctx_t;
+
+/* search_match (reorder.h:246-318), single-thread (locks always succeed).
+ * `ref` is the already shifted bitset (ref >> 2*shift or revref << 2*shift). */
+static int search_match(ctx_t *x, const uint64_t *ref, uint32_t *k, int rev, int shift, int ref_len) {
+  int flag = 0;
+  int64_t dictidx[2];
+  x->st->search_calls++;
+  for (int l = 0; l < 2; l++) {
+    dict_t *d = &x->dict[l];
+    if (!rev) {
+      if (d->end + shift >= ref_len) continue;
+    } else {
+      if (d->end >= ref_len + shift || d->start <= shift) continue;
+    }
+    uint64_t ull = read_key(ref, x->W, d); /* :269-270 */
+    x->st->probes++;
+    int64_t startposidx = dict_lookup(d, ull); /* :271-273 */
+    if (startposidx < 0) continue;
+    findpos(d, dictidx, (uint64_t)startposidx);
+    if (d->empty_bin[startposidx]) continue; /* :277-281 */
+    uint64_t ull1 = read_key(x->read + (size_t)d->read_id[dictidx[0]] * x->W, x->W, d);
+    if (ull == ull1) { /* :285 */
+      x->st->keyok++;
+      for (int64_t i = dictidx[1] - 1; i >= dictidx[0] && i >= dictidx[1] - MAX_SEARCH_REORDER; i--) {
+        uint32_t rid = d->read_id[i];
+        x->st->cands++;
+        int hamming;
+        if (!rev) {
+          int m = ref_len - shift < (int)x->len[rid] ? ref_len - shift : (int)x->len[rid];
+          hamming = hamming_range(ref, x->read + (size_t)rid * x->W, x->W, 0, m);
+        } else {
+          int m = ref_len + shift < (int)x->len[rid] ? ref_len + shift : (int)x->len[rid];
+          hamming = hamming_range(ref, x->read + (size_t)rid * x->W, x->W, shift, m);
+        }
+        if (hamming <= THRESH_REORDER) {
+          x->st->hits++;
+          if (x->remainingreads[rid]) {
+            x->remainingreads[rid] = 0;
+            *k = rid;
+            flag = 1;
+          }
+          if (flag == 1) break;
+        }
+      }
+    }
+    if (flag == 1) break;
+  }
+  return flag;
+}
+
+int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, int L, orc_out *out,
+                       orc_stats *st) {
+  ctx_t x;
+  memset(&x, 0, sizeof(x));
+  memset(st, 0, sizeof(*st));
+  x.read = read; x.len = len; x.n = n; x.L = L; x.W = orc_limbs(L);
+  x.maxshift = L / 2; /* reorder.h:750 */
+  x.st = st;
+  int s[2], e[2];
+  orc_dict_windows(L, s, e);
+  for (int l = 0; l < 2; l++) { x.dict[l].start = s[l]; x.dict[l].end = e[l]; }
+  if (n > 0) /* reorder.h:772 */
+    for (int l = 0; l < 2; l++) dict_build(&x.dict[l], read, len, n, x.W);
+  x.remainingreads = (uint8_t *)malloc(n ? n : 1);
+  memset(x.remainingreads, 1, n);
+  const int W = x.W;
+
+  outbuf_t ob;
+  memset(&ob, 0, sizeof(ob));
+  cons_t *c = (cons_t *)calloc(1, sizeof(cons_t));
+  uint64_t ref[ORC_WMAX], revref[ORC_WMAX];
+
+  /* reorder() thread body (reorder.h:351-627) with one thread */
+  uint32_t firstread = 0, unmatched = 0;
+  int stop_searching = 0;
+  uint32_t num_reads_thr = 0, num_unmatched_past_1M_thr = 0;
+  int flag = 0, done = 0, prev_unmatched = 0, left_search_start = 0, left_search = 0;
+  int64_t current = 0, prev = 0, first_rid = 0;
+  int64_t ref_pos = 0, cur_read_pos = 0;
+  int64_t remainingpos = (int64_t)n - 1;
+  int64_t dictidx[2];
+  current = firstread;
+  if (n == 0)
+    done = 1;
+  else if (x.remainingreads[current] == 0)
+    done = 1;
+  else {
+    x.remainingreads[current] = 0;
+    unmatched++;
+  }
+  if (!done) {
+    updaterefcount(read + (size_t)current * W, c, 1, 0, 0, len[current], L, W, st);
+    cur_read_pos = 0; ref_pos = 0; first_rid = current; prev_unmatched = 1; prev = current;
+  }
+  while (!done) {
+    st->iterations++;
+    if (num_reads_thr % 1000000 == 0) { /* :433-438 */
+      if ((float)num_unmatched_past_1M_thr > STOP_CRITERIA_REORDER * 1000000) stop_searching = 1;
+      num_unmatched_past_1M_thr = 0;
+    }
+    num_reads_thr++;
+    if (!left_search_start) { /* :458-475 */
+      for (int l = 0; l < 2; l++) {
+        dict_t *d = &x.dict[l];
+        if ((int)len[current] <= d->end) continue;
+        uint64_t ull = read_key(read + (size_t)current * W, W, d);
+        int64_t startposidx = dict_lookup(d, ull);
+        findpos(d, dictidx, (uint64_t)startposidx);
+        bin_remove(d, dictidx, (uint64_t)startposidx, current);
+      }
+    } else
+      left_search_start = 0;
+    flag = 0;
+    uint32_t k = 0;
+    if (!stop_searching) {
+      memcpy(ref, c->ref, sizeof(uint64_t) * W);
+      memcpy(revref, c->revref, sizeof(uint64_t) * W);
+      for (int shift = 0; shift < x.maxshift; shift++) { /* :479-558 */
+        flag = search_match(&x, ref, &k, 0, shift, c->ref_len);
+        if (flag == 1) {
+          current = k;
+          int ref_len_old = c->ref_len;
+          updaterefcount(read + (size_t)current * W, c, 0, 0, shift, len[current], L, W, st);
+          if (!left_search) {
+            cur_read_pos = ref_pos + shift;
+            ref_pos = cur_read_pos;
+          } else {
+            cur_read_pos = ref_pos + ref_len_old - shift - len[current];
+            ref_pos = ref_pos + ref_len_old - shift - c->ref_len;
+          }
+          if (prev_unmatched) ob_push(&ob, (uint32_t)prev, 'd', '0', 0, len[prev]);
+          ob_push(&ob, (uint32_t)current, left_search ? 'r' : 'd', '1', cur_read_pos, len[current]);
+          prev_unmatched = 0;
+          break;
+        }
+        flag = search_match(&x, revref, &k, 1, shift, c->ref_len);
+        if (flag == 1) {
+          current = k;
+          int ref_len_old = c->ref_len;
+          updaterefcount(read + (size_t)current * W, c, 0, 1, shift, len[current], L, W, st);
+          if (!left_search) {
+            cur_read_pos = ref_pos + ref_len_old + shift - len[current];
+            ref_pos = ref_pos + ref_len_old + shift - c->ref_len;
+          } else {
+            cur_read_pos = ref_pos - shift;
+            ref_pos = cur_read_pos;
+          }
+          if (prev_unmatched) ob_push(&ob, (uint32_t)prev, 'd', '0', 0, len[prev]);
+          ob_push(&ob, (uint32_t)current, left_search ? 'd' : 'r', '1', cur_read_pos, len[current]);
+          prev_unmatched = 0;
+          break;
+        }
+        shl2(revref, W); /* :556 */
+        shr2(ref, W);    /* :557 */
+      }
+    }
+    if (flag == 0) { /* :559-615 */
+      num_unmatched_past_1M_thr++;
+      if (!left_search) {
+        left_search = 1;
+        left_search_start = 1;
+        updaterefcount(read + (size_t)first_rid * W, c, 1, 1, 0, len[first_rid], L, W, st);
+        ref_pos = 0;
+        cur_read_pos = 0;
+      } else {
+        left_search = 0;
+        for (int64_t j = remainingpos; j >= 0; j--) {
+          if (x.remainingreads[j] == 1) {
+            current = j;
+            remainingpos = j - 1;
+            x.remainingreads[j] = 0;
+            flag = 1;
+            unmatched++;
+            break;
+          }
+        }
+        if (flag == 0) {
+          if (prev_unmatched) ob_push_s(&ob, (uint32_t)prev);
+          done = 1;
+        } else {
+          updaterefcount(read + (size_t)current * W, c, 1, 0, 0, len[current], L, W, st);
+          ref_pos = 0;
+          cur_read_pos = 0;
+          if (prev_unmatched) ob_push_s(&ob, (uint32_t)prev);
+          prev_unmatched = 1;
+          first_rid = current;
+          prev = current;
+        }
+      }
+    }
+  }
+  st->unmatched = unmatched;
+  memcpy(out->order, ob.order, ob.n * sizeof(uint32_t));
+  memcpy(out->rc, ob.rc, ob.n);
+  memcpy(out->flag, ob.flag, ob.n);
+  memcpy(out->pos, ob.pos, ob.n * sizeof(int64_t));
+  memcpy(out->rlen, ob.rlen, ob.n * sizeof(uint16_t));
+  memcpy(out->order_s, ob.order_s, ob.ns * sizeof(uint32_t));
+  out->n_matched = ob.n;
+  out->n_single = ob.ns;
+  if (out->tid_off) { out->tid_off[0] = 0; out->tid_off[1] = ob.n; }
+  if (out->tid_off_s) { out->tid_off_s[0] = 0; out->tid_off_s[1] = ob.ns; }
+  ob_free(&ob);
+  free(c);
+  free(x.remainingreads);
+  if (n > 0) for (int l = 0; l < 2; l++) dict_free(&x.dict[l]);
+  return 0;
+}
+
+/* -------------------------------------------------- K-chain rounds schedule
+ *
+ * The schedule the GPU path implements (DESIGN.md "Chain schedule"):
+ *   - K chains; chain i starts at seed i*floor(N/K) (reorder.h:405-421, with
+ *     the critical section entered in chain-id order).
+ *   - bins are immutable; a read is live in a bin iff !taken[rid].  In the
+ *     single-thread reference a claimed read is always removed from its bins
+ *     before the next search (reorder.h:458-472), so "live" == "remaining".
+ *   - each round has two phases.  Phase A: every chain, looking at taken[] as
+ *     it was at the start of the round, either searches (reorder.h:479-558
+ *     order: shift, fwd before rev, dict 0 before 1, bin tail first, at most
+ *     1000 live entries) or, if it needs a new contig seed, proposes the
+ *     (r+1)-th highest untaken read at or below the global cursor, r being
+ *     its rank among seed-needing chains (reorder.h:576-592; one cursor is
+ *     equivalent to per-thread remainingpos because every read above any
+ *     thread's remainingpos is already claimed).  Proposals do
+ *     resv[rid] = min(resv[rid], chain).  Phase B: a chain whose proposal
+ *     holds resv wins and applies it; a loser retries the same iteration in
+ *     the next round (in the reference a thread that loses the read_lock race
+ *     keeps scanning, reorder.h:303-311; both are legal `-t K` interleavings).
+ *   K = 1 degenerates to the reference's `-t 1` order exactly.
+ */
+
+enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
+enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2 };
+
+typedef struct {
+  cons_t c;
+  int64_t current, prev, first_rid, ref_pos, cur_read_pos;
+  int done, prev_unmatched, left_search, stop_searching, mode, retrying;
+  uint32_t num_reads_thr, num_unmatched_past_1M_thr, unmatched;
+  int prop_kind, prop_shift, prop_rev;
+  uint32_t prop_rid;
+  outbuf_t ob;
+} chain_t;
+
+typedef struct {
+  const uint64_t *read;
+  const uint16_t *len;
+  uint32_t n;
+  int L, W, maxshift;
+  dict_t dict[2];
+  uint8_t *taken;
+  orc_stats *st;
+} rctx_t;
+
+/* one full search of a chain against the round-start taken[] */
+static int rounds_search(rctx_t *x, const cons_t *c, uint32_t *k, int *oshift, int *orev) {
+  uint64_t ref[ORC_WMAX], revref[ORC_WMAX];
+  const int W = x->W;
+  memcpy(ref, c->ref, sizeof(uint64_t) * W);
+  memcpy(revref, c->revref, sizeof(uint64_t) * W);
+  for (int shift = 0; shift < x->maxshift; shift++) {
+    for (int rev = 0; rev < 2; rev++) {
+      const uint64_t *r = rev ? revref : ref;
+      x->st->search_calls++;
+      for (int l = 0; l < 2; l++) {
+        dict_t *d = &x->dict[l];
+        if (!rev) {
+          if (d->end + shift >= c->ref_len) continue;
+        } else {
+          if (d->end >= c->ref_len + shift || d->start <= shift) continue;
+        }
+        uint64_t key = read_key(r, W, d);
+        x->st->probes++;
+        int64_t b = dict_lookup(d, key);
+        if (b < 0) continue;
+        int live = 0;
+        for (int64_t i = (int64_t)d->startpos[b + 1] - 1;
+             i >= (int64_t)d->startpos[b] && live < MAX_SEARCH_REORDER; i--) {
+          uint32_t rid = d->read_id[i];
+          if (x->taken[rid]) continue;
+          if (!live) x->st->keyok++;
+          live++;
+          x->st->cands++;
+          int lo = rev ? shift : 0;
+          int m = rev ? c->ref_len + shift : c->ref_len - shift;
+          if ((int)x->len[rid] < m) m = x->len[rid];
+          if (hamming_range(r, x->read + (size_t)rid * W, W, lo, m) <= THRESH_REORDER) {
+            x->st->hits++;
+            *k = rid; *oshift = shift; *orev = rev;
+            return 1;
+          }
+        }
+      }
+    }
+    shl2(revref, W);
+    shr2(ref, W);
+  }
+  return 0;
+}
+
+int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
+                       int num_thr, orc_out *out, orc_stats *st) {
+  if (K == 0 || num_thr <= 0) return -1;
+  rctx_t x;
+  memset(&x, 0, sizeof(x));
+  memset(st, 0, sizeof(*st));
+  x.read = read; x.len = len; x.n = n; x.L = L; x.W = orc_limbs(L); x.maxshift = L / 2; x.st = st;
+  const int W = x.W;
+  int s[2], e[2];
+  orc_dict_windows(L, s, e);
+  for (int l = 0; l < 2; l++) { x.dict[l].start = s[l]; x.dict[l].end = e[l]; }
+  if (n > 0) for (int l = 0; l < 2; l++) dict_build(&x.dict[l], read, len, n, W);
+  x.taken = (uint8_t *)calloc(n ? n : 1, 1);
+  uint32_t *resv = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+  memset(resv, 0xff, sizeof(uint32_t) * (n ? n : 1));
+  chain_t *ch = (chain_t *)calloc(K, sizeof(chain_t));
+  uint32_t *seedlist = (uint32_t *)malloc(sizeof(uint32_t) * K);
+  int64_t cursor = (int64_t)n - 1;
+  uint32_t alive = 0;
+
+  uint32_t firstread = 0;
+  for (uint32_t i = 0; i < K; i++) { /* reorder.h:405-431 */
+    chain_t *c = &ch[i];
+    c->current = firstread;
+    if (n == 0 || x.taken[firstread])
+      c->done = 1;
+    else {
+      x.taken[firstread] = 1;
+      c->unmatched++;
+      updaterefcount(read + (size_t)c->current * W, &c->c, 1, 0, 0, len[c->current], L, W, st);
+      c->first_rid = c->prev = c->current;
+      c->prev_unmatched = 1;
+      alive++;
+    }
+    firstread += n / K;
+  }
+
+  while (alive) {
+    st->rounds++;
+    /* ---- phase A: proposals from the round-start state */
+    uint32_t nneed = 0;
+    for (uint32_t i = 0; i < K; i++)
+      if (!ch[i].done && ch[i].mode == MODE_NEED_SEED) nneed++;
+    uint32_t nseed = 0;
+    if (nneed) {
+      for (int64_t j = cursor; j >= 0 && nseed < nneed; j--)
+        if (!x.taken[j]) seedlist[nseed++] = (uint32_t)j;
+    }
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < K; i++) {
+      chain_t *c = &ch[i];
+      if (c->done) continue;
+      c->prop_kind = PROP_NONE;
+      if (c->mode == MODE_NEED_SEED) {
+        if (rank < nseed) {
+          c->prop_kind = PROP_SEED;
+          c->prop_rid = seedlist[rank];
+        } else { /* no reads left (reorder.h:593-599) */
+          if (c->prev_unmatched) ob_push_s(&c->ob, (uint32_t)c->prev);
+          c->done = 1;
+          alive--;
+        }
+        rank++;
+        continue;
+      }
+      if (!c->retrying) {
+        st->iterations++;
+        if (c->num_reads_thr % 1000000 == 0) {
+          if ((float)c->num_unmatched_past_1M_thr > STOP_CRITERIA_REORDER * 1000000) c->stop_searching = 1;
+          c->num_unmatched_past_1M_thr = 0;
+        }
+        c->num_reads_thr++;
+      }
+      if (!c->stop_searching) {
+        uint32_t k; int sh, rv;
+        if (rounds_search(&x, &c->c, &k, &sh, &rv)) {
+          c->prop_kind = PROP_MATCH; c->prop_rid = k; c->prop_shift = sh; c->prop_rev = rv;
+        }
+      }
+    }
+    for (uint32_t i = 0; i < K; i++)
+      if (!ch[i].done && ch[i].prop_kind != PROP_NONE && resv[ch[i].prop_rid] > i) resv[ch[i].prop_rid] = i;
+    /* ---- phase B: resolve + apply */
+    for (uint32_t i = 0; i < K; i++) {
+      chain_t *c = &ch[i];
+      if (c->done) continue;
+      if (c->prop_kind != PROP_NONE && resv[c->prop_rid] != i) { /* lost the read */
+        st->lost++;
+        if (c->mode == MODE_SEARCH) c->retrying = 1;
+        continue;
+      }
+      if (c->prop_kind == PROP_MATCH) {
+        const int shift = c->prop_shift;
+        x.taken[c->prop_rid] = 1;
+        c->retrying = 0;
+        c->current = c->prop_rid;
+        int ref_len_old = c->c.ref_len;
+        updaterefcount(read + (size_t)c->current * W, &c->c, 0, c->prop_rev, shift, len[c->current], L, W, st);
+        char rcch;
+        if (!c->prop_rev) { /* reorder.h:490-497,:508 */
+          if (!c->left_search) {
+            c->cur_read_pos = c->ref_pos + shift;
+            c->ref_pos = c->cur_read_pos;
+          } else {
+            c->cur_read_pos = c->ref_pos + ref_len_old - shift - len[c->current];
+            c->ref_pos = c->ref_pos + ref_len_old - shift - c->c.ref_len;
+          }
+          rcch = c->left_search ? 'r' : 'd';
+        } else { /* reorder.h:528-535,:546 */
+          if (!c->left_search) {
+            c->cur_read_pos = c->ref_pos + ref_len_old + shift - len[c->current];
+            c->ref_pos = c->ref_pos + ref_len_old + shift - c->c.ref_len;
+          } else {
+            c->cur_read_pos = c->ref_pos - shift;
+            c->ref_pos = c->cur_read_pos;
+          }
+          rcch = c->left_search ? 'd' : 'r';
+        }
+        if (c->prev_unmatched) ob_push(&c->ob, (uint32_t)c->prev, 'd', '0', 0, len[c->prev]);
+        ob_push(&c->ob, (uint32_t)c->current, rcch, '1', c->cur_read_pos, len[c->current]);
+        c->prev_unmatched = 0;
+      } else if (c->prop_kind == PROP_SEED) { /* reorder.h:580-587,:600-613 */
+        x.taken[c->prop_rid] = 1;
+        c->current = c->prop_rid;
+        c->unmatched++;
+        updaterefcount(read + (size_t)c->current * W, &c->c, 1, 0, 0, len[c->current], L, W, st);
+        c->ref_pos = 0; c->cur_read_pos = 0;
+        if (c->prev_unmatched) ob_push_s(&c->ob, (uint32_t)c->prev);
+        c->prev_unmatched = 1;
+        c->first_rid = c->current;
+        c->prev = c->current;
+        c->mode = MODE_SEARCH;
+      } else if (c->mode == MODE_SEARCH) { /* search failed (reorder.h:559-575) */
+        c->retrying = 0;
+        c->num_unmatched_past_1M_thr++;
+        if (!c->left_search) {
+          c->left_search = 1;
+          updaterefcount(read + (size_t)c->first_rid * W, &c->c, 1, 1, 0, len[c->first_rid], L, W, st);
+          c->ref_pos = 0; c->cur_read_pos = 0;
+        } else {
+          c->left_search = 0;
+          c->mode = MODE_NEED_SEED;
+        }
+      }
+    }
+    if (nseed) cursor = (int64_t)seedlist[nseed - 1] - 1;
+  }
+
+  /* assemble: chain i -> tid i % num_thr, chains ascending inside a tid */
+  uint64_t nm = 0, ns = 0;
+  for (int t = 0; t < num_thr; t++) {
+    if (out->tid_off) out->tid_off[t] = nm;
+    if (out->tid_off_s) out->tid_off_s[t] = ns;
+    for (uint32_t i = (uint32_t)t; i < K; i += (uint32_t)num_thr) {
+      outbuf_t *o = &ch[i].ob;
+      memcpy(out->order + nm, o->order, o->n * sizeof(uint32_t));
+      memcpy(out->rc + nm, o->rc, o->n);
+      memcpy(out->flag + nm, o->flag, o->n);
+      memcpy(out->pos + nm, o->pos, o->n * sizeof(int64_t));
+      memcpy(out->rlen + nm, o->rlen, o->n * sizeof(uint16_t));
+      memcpy(out->order_s + ns, o->order_s, o->ns * sizeof(uint32_t));
+      nm += o->n;
+      ns += o->ns;
+    }
+  }
+  if (out->tid_off) out->tid_off[num_thr] = nm;
+  if (out->tid_off_s) out->tid_off_s[num_thr] = ns;
+  out->n_matched = nm;
+  out->n_single = ns;
+  for (uint32_t i = 0; i < K; i++) { st->unmatched += ch[i].unmatched; ob_free(&ch[i].ob); }
+  free(ch); free(seedlist); free(resv); free(x.taken);
+  if (n > 0) for (int l = 0; l < 2; l++) dict_free(&x.dict[l]);
+  return 0;
+}
+
+/* ------------------------------------------------------------ writetofile */
+
+size_t orc_write_dna_stream(const uint64_t *read, const uint16_t *len, int L, const uint32_t *order,
+                            const char *rc, uint64_t cnt, uint8_t *dst) { /* reorder.h:667-687 */
+  int W = orc_limbs(L);
+  size_t p = 0;
+  char s[ORC_MAX_READ_LEN + 1], s1[ORC_MAX_READ_LEN + 1];
+  for (uint64_t i = 0; i < cnt; i++) {
+    uint32_t current = order[i];
+    if (!rc || rc[i] == 'd') {
+      uint16_t l = len[current];
+      size_t nb = ((uint32_t)l + 3) / 4;
+      memcpy(dst + p, &l, 2);
+      memcpy(dst + p + 2, read + (size_t)current * W, nb);
+      p += 2 + nb;
+    } else {
+      bits_to_string(read + (size_t)current * W, W, s, len[current]);
+      reverse_complement(s, s1, len[current]);
+      p += orc_pack_read(s1, len[current], dst + p);
+    }
+  }
+  return p;
+}
+
+/* exported for tests/test_oracle_vs_ref.py: Hamming over bases [lo,hi) */
+int orc_hamming_range(const uint64_t *a, const uint64_t *b, int W, int lo, int hi) {
+  return hamming_range(a, b, W, lo, hi);
+}
+
+/* exported for unit tests of the consensus arithmetic: one updaterefcount()
+ * call on caller-held state (cnt is [4][512] int32, A C T G rows). */
+void orc_updaterefcount(const uint64_t *cur, int32_t *cnt, uint64_t *ref, uint64_t *revref,
+                        int *ref_len, int resetcount, int rev, int shift, int cur_readlen,
+                        int max_readlen) {
+  cons_t *c = (cons_t *)calloc(1, sizeof(cons_t));
+  orc_stats st;
+  memset(&st, 0, sizeof(st));
+  int W = orc_limbs(max_readlen);
+  memcpy(c->cnt, cnt, sizeof(c->cnt));
+  c->ref_len = *ref_len;
+  updaterefcount(cur, c, resetcount, rev, shift, cur_readlen, max_readlen, W, &st);
+  memcpy(cnt, c->cnt, sizeof(c->cnt));
+  memcpy(ref, c->ref, sizeof(uint64_t) * W);
+  memcpy(revref, c->revref, sizeof(uint64_t) * W);
+  *ref_len = c->ref_len;
+  free(c);
+}

@@ -1,0 +1,107 @@
+/*
+ * oracle/reorder_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of SPRING's read-reordering stage
+ * (/root/reference/src/reorder.h + bitset_util.{h,cpp}).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (spring_amd/csrc) never links or calls it.
+ *
+ * Two algorithms are exported:
+ *   orc_reorder_serial  -- literal single-thread restatement of
+ *                          reorder_main<N>() at `-t 1` (mutable CSR bins with
+ *                          the reference's tail-sentinel encoding).
+ *   orc_reorder_rounds  -- the deterministic K-chain schedule this repo's GPU
+ *                          path implements (immutable bins + taken[] flags,
+ *                          lock-step rounds, lowest chain id wins a contested
+ *                          read).  K = 1 must equal orc_reorder_serial
+ *                          byte for byte (tests/test_oracle.py).
+ *
+ * Pinning status: see oracle/README.md ("parity partially pinned").
+ */
+#ifndef SPRING_ORACLE_REORDER_H_
+#define SPRING_ORACLE_REORDER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_READ_LEN 511 /* params.h:22 */
+#define ORC_WMAX 16          /* ceil(2*511/64) */
+
+typedef struct {
+  uint64_t unmatched;       /* contig seeds ("were unmatched", reorder.h:633) */
+  uint64_t search_calls;    /* search_match() invocations                    */
+  uint64_t probes;          /* dictionary probes that passed the bounds test  */
+  uint64_t keyok;           /* probes whose key exists and bin is non-empty   */
+  uint64_t cands;           /* Hamming evaluations                            */
+  uint64_t hits;            /* Hamming <= THRESH_REORDER                      */
+  uint64_t updates;         /* updaterefcount() calls                         */
+  uint64_t iterations;      /* while(!done) iterations summed over chains     */
+  uint64_t rounds;          /* lock-step rounds (rounds schedule only)        */
+  uint64_t lost;            /* proposals that lost a contested read           */
+} orc_stats;
+
+/* limbs per read: (2*L-1)/64+1  (call_template_functions.cpp:10) */
+int orc_limbs(int max_readlen);
+
+/* readDnaFile (reorder.h:222-244): records of u16 len + ceil(len/4) bytes.
+ * read must hold n*W zeroed limbs.  Returns bytes consumed or -1. */
+int64_t orc_load_dna(const uint8_t *dna, size_t nbytes, uint32_t n, int max_readlen,
+                     uint64_t *read, uint16_t *len);
+
+/* write_dna_in_bits (util.cpp:269-294) for ACGT strings; returns bytes written. */
+size_t orc_pack_read(const char *s, int len, uint8_t *dst);
+
+/* Outputs (caller allocates n entries each).  Matched stream = what the
+ * reference writes to read_order.bin.<tid>/read_rev.txt.<tid>/tempflag.txt.<tid>
+ * /temppos.txt.<tid>/read_lengths.bin.<tid>, concatenated in tid order
+ * (tid_off[num_thr+1] delimits them).  order_s = read_order.bin.singleton. */
+typedef struct {
+  uint32_t *order;
+  char *rc;
+  char *flag;
+  int64_t *pos;
+  uint16_t *rlen;
+  uint32_t *order_s;
+  uint64_t *tid_off;   /* num_thr+1 entries */
+  uint64_t *tid_off_s; /* num_thr+1 entries (singleton stream per tid) */
+  uint64_t n_matched;
+  uint64_t n_single;
+} orc_out;
+
+int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
+                       orc_out *out, orc_stats *st);
+
+int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
+                       uint32_t num_chains, int num_thr, orc_out *out, orc_stats *st);
+
+/* writetofile (reorder.h:643-730): byte stream of temp.dna.<tid> for a slice
+ * of the matched stream (rc may be NULL => all 'd', i.e. the singleton file).
+ * Returns bytes written into dst (capacity must be >= cnt*(2+ceil(L/4))). */
+size_t orc_write_dna_stream(const uint64_t *read, const uint16_t *len, int max_readlen,
+                            const uint32_t *order, const char *rc, uint64_t cnt, uint8_t *dst);
+
+/* constructdictionary (bitset_util.h:74-221) restated: returns arrays so the
+ * test can compare with the real reference build in oracle/_ref.
+ * keys_out: numkeys sorted unique keys; startpos_out: numkeys+1; read_id_out:
+ * dict_numreads.  Buffers sized n (+1).  Returns numkeys, *dict_numreads set. */
+uint32_t orc_build_dict(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
+                        int which, uint64_t *keys_out, uint32_t *startpos_out,
+                        uint32_t *read_id_out, uint32_t *dict_numreads);
+
+/* bbhashdict::findpos/remove (bitset_util.cpp:20-63) on one bin laid out in
+ * read_id[0..cap) with startpos {0,cap}.  Used to pin the tail encoding
+ * against the real reference.  Returns live count after the call. */
+int64_t orc_bin_remove(uint32_t *read_id, uint32_t cap, uint8_t *empty_bin, int64_t current);
+int64_t orc_bin_live(const uint32_t *read_id, uint32_t cap);
+
+/* dictionary windows (reorder.h:751-759) */
+void orc_dict_windows(int max_readlen, int start[2], int end[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

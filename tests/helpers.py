@@ -1,0 +1,101 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+
+import readsets as rs
+from oracle import pyoracle as po
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("order", "rc", "flag", "pos", "rlen", "order_s")
+
+
+def fastq_clean_reads(path):
+    """Reads of a FASTQ without 'N' (what preprocess.cpp:295-304 hands to reorder)."""
+    out = []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    for i in range(1, len(lines), 4):
+        r = lines[i].strip()
+        if b"N" not in r:
+            out.append(r)
+    return out
+
+
+def named_set(name):
+    """-> (dna bytes, n, max_readlen).  Small sets the oracle finishes in seconds."""
+    if name == "test_1":
+        reads = fastq_clean_reads(os.path.join(GOLDEN, "test_1.fastq"))
+        return rs.pack_var(reads), len(reads), max(len(r) for r in reads)
+    if name == "test_1+2":  # paired-end pool: file-1 reads then file-2 reads (reorder.h:233-242)
+        r1 = fastq_clean_reads(os.path.join(GOLDEN, "test_1.fastq"))
+        r2 = fastq_clean_reads(os.path.join(GOLDEN, "test_2.fastq"))
+        reads = r1 + r2
+        return rs.pack_var(reads), len(reads), max(len(r) for r in reads)
+    if name == "syn2k_100":
+        a = rs.np_reads(101, 2000 * 100 // 30, 2000, 100, 0.01)
+        return rs.pack_fixed(a), 2000, 100
+    if name == "syn5k_150":
+        a = rs.np_reads(102, 5000 * 150 // 25, 5000, 150, 0.01)
+        return rs.pack_fixed(a), 5000, 150
+    if name == "syn20k_100":
+        a = rs.np_reads(103, 20000 * 100 // 25, 20000, 100, 0.01)
+        return rs.pack_fixed(a), 20000, 100
+    if name == "syn3k_64":  # L < 100: dictionary windows shorter than 32 bases (reorder.h:752-759)
+        a = rs.np_reads(104, 3000 * 64 // 25, 3000, 64, 0.01)
+        return rs.pack_fixed(a), 3000, 64
+    if name == "syn2k_251":  # W = 8 limbs
+        a = rs.np_reads(105, 2000 * 251 // 25, 2000, 251, 0.005)
+        return rs.pack_fixed(a), 2000, 251
+    if name == "var2k":  # variable length 50..150: the three reverse sub-cases + len<=dict.end exclusion
+        reads = rs.var_length_reads(106, 12000, 2000, 50, 150, 0.01)
+        return rs.pack_var(reads), len(reads), max(len(r) for r in reads)
+    if name == "var_short":  # many reads too short for dict 1 / both dicts
+        reads = rs.var_length_reads(107, 6000, 1500, 20, 100, 0.01)
+        return rs.pack_var(reads), len(reads), max(len(r) for r in reads)
+    if name == "heavy":  # one bin with >1000 reads: MAX_SEARCH_REORDER cap + removal encodings
+        a = rs.heavy_bin_reads(108, 1500, 1500, 100, 0.02)
+        return rs.pack_fixed(a), a.shape[0], 100
+    if name == "repeat10k":
+        a = rs.np_reads_repeat(109, 40000, 10000, 100, 0.02)
+        return rs.pack_fixed(a), 10000, 100
+    if name == "dups":  # exact duplicates of few reads
+        base = rs.np_reads(110, 3000, 40, 100, 0.0)
+        a = np.repeat(base, 30, axis=0)
+        np.random.default_rng(5).shuffle(a, axis=0)
+        return rs.pack_fixed(a), a.shape[0], 100
+    if name == "one":
+        a = rs.np_reads(111, 1000, 1, 100, 0.0)
+        return rs.pack_fixed(a), 1, 100
+    if name == "two_same":
+        a = np.repeat(rs.np_reads(112, 1000, 1, 100, 0.0), 2, axis=0)
+        return rs.pack_fixed(a), 2, 100
+    if name == "empty":
+        return b"", 0, 100
+    raise KeyError(name)
+
+
+SMALL_SETS = ["test_1", "test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k", "var_short",
+              "heavy", "repeat10k", "dups", "one", "two_same", "empty"]
+
+
+def check_invariants(res, read, ln, L, n):
+    """Properties every legal reorder output has (any chain count)."""
+    order, order_s = res["order"], res["order_s"]
+    allr = np.concatenate([order, order_s]).astype(np.int64)
+    assert len(allr) == n
+    assert np.array_equal(np.sort(allr), np.arange(n)), "output is not a permutation of the clean reads"
+    assert set(np.unique(res["rc"]).tolist()) <= {ord("d"), ord("r")}
+    assert set(np.unique(res["flag"]).tolist()) <= {ord("0"), ord("1")}
+    assert np.array_equal(res["rlen"], ln[order])
+    f0 = res["flag"] == ord("0")
+    assert np.all(res["pos"][f0] == 0) and np.all(res["rc"][f0] == ord("d"))
+    if len(order):
+        assert res["flag"][0] == ord("0")
+        # every contig has >= 2 reads: a '0' is never followed by another '0' / end of a tid stream
+        toff = [int(x) for x in res["tid_off"]]
+        for a, b in zip(toff[:-1], toff[1:]):
+            if b > a:
+                fl = res["flag"][a:b]
+                assert fl[0] == ord("0") and fl[-1] == ord("1")
+                assert not np.any((fl[:-1] == ord("0")) & (fl[1:] == ord("0")))

@@ -1,0 +1,131 @@
+"""CPU tests of the oracle itself (no GPU): known answers recorded from the reference,
+K=1 rounds schedule == literal serial restatement, invariants for K>1, golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import readsets as rs
+from helpers import GOLDEN, KEYS, SMALL_SETS, check_invariants, named_set
+from oracle import pyoracle as po
+
+
+def _load(name):
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    return read, ln, n, L
+
+
+def test_dict_windows_match_survey_table():
+    # SURVEY.md section 8 header: L=100 -> [18..49],[50..81]; L=150 -> [43..74],[75..106]
+    assert po.dict_windows(100) == ([18, 50], [49, 81])
+    assert po.dict_windows(150) == ([43, 75], [74, 106])
+    assert po.limbs(100) == 4 and po.limbs(150) == 5 and po.limbs(511) == 16 and po.limbs(32) == 1
+
+
+def test_reference_fixture_test_1_all_singletons():
+    """util/test_1.fastq: 38 clean reads, all singletons, order 0,37,36,...,1."""
+    read, ln, n, L = _load("test_1")
+    assert n == 38
+    r = po.reorder_serial(read, ln, L)
+    assert len(r["order"]) == 0
+    assert r["order_s"].tolist() == [0] + list(range(37, 0, -1))
+    assert r["stats"]["unmatched"] == 38
+
+
+@pytest.mark.slow
+def test_known_answer_1M_100bp_reference_counters():
+    """counters the surveyor recorded from the real reference
+    (instrumented reorder.h, -t 1) on numpy default_rng(7), G=4 Mb, 1 M x 100 bp, 1 % subs."""
+    n, L = 1_000_000, 100
+    a = rs.np_reads(7, 4_000_000, n, L, 0.01)
+    read, ln = po.load_dna(rs.pack_fixed(a), n, L)
+    r = po.reorder_serial(read, ln, L)
+    st = r["stats"]
+    assert st["unmatched"] == 96_389
+    assert len(r["order_s"]) == 93_011
+    assert st["search_calls"] == 28_782_325
+    assert st["probes"] == 44_478_214
+    assert st["keyok"] == 927_453
+    assert st["cands"] == 928_070
+    assert st["hits"] == 903_611
+    assert st["updates"] == 1_096_389
+    check_invariants(r, read, ln, L, n)
+
+
+@pytest.mark.slow
+def test_known_answer_1M_150bp_reference_counters():
+    """1 M x 150 bp (default_rng(11), G = 6 Mb)."""
+    n, L = 1_000_000, 150
+    a = rs.np_reads(11, 6_000_000, n, L, 0.01)
+    read, ln = po.load_dna(rs.pack_fixed(a), n, L)
+    r = po.reorder_serial(read, ln, L)
+    st = r["stats"]
+    assert st["unmatched"] == 137_664
+    assert len(r["order_s"]) == 127_731
+    assert st["probes"] == 92_923_476
+    assert st["cands"] == 996_385
+
+
+@pytest.mark.parametrize("name", SMALL_SETS)
+def test_rounds_k1_equals_serial(name):
+    read, ln, n, L = _load(name)
+    a = po.reorder_serial(read, ln, L)
+    b = po.reorder_rounds(read, ln, L, 1, 1)
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), (name, k)
+    assert a["stats"]["unmatched"] == b["stats"]["unmatched"]
+    for k in ("search_calls", "probes", "keyok", "cands", "hits", "updates", "iterations"):
+        assert a["stats"][k] == b["stats"][k], (name, k)
+    check_invariants(a, read, ln, L, n)
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "var2k", "heavy", "repeat10k", "dups", "test_1+2"])
+@pytest.mark.parametrize("K,T", [(2, 1), (5, 2), (64, 8), (1000, 3)])
+def test_rounds_invariants(name, K, T):
+    read, ln, n, L = _load(name)
+    r = po.reorder_rounds(read, ln, L, K, T)
+    check_invariants(r, read, ln, L, n)
+    assert len(r["tid_off"]) == T + 1 and int(r["tid_off"][-1]) == len(r["order"])
+    # deterministic
+    r2 = po.reorder_rounds(read, ln, L, K, T)
+    for k in KEYS:
+        assert np.array_equal(r[k], r2[k])
+
+
+def test_more_chains_than_reads():
+    read, ln, n, L = _load("two_same")
+    r = po.reorder_rounds(read, ln, L, 16, 4)  # floor(N/K)=0: only chain 0 starts (reorder.h:411-420)
+    assert r["order"].tolist() == [0, 1] and len(r["order_s"]) == 0
+    assert bytes(r["flag"]) == b"01"
+
+
+def test_write_dna_stream_roundtrip():
+    read, ln, n, L = _load("var2k")
+    r = po.reorder_serial(read, ln, L)
+    s = po.write_dna_stream(read, ln, L, r["order"], r["rc"])
+    back, bl = po.load_dna(s, len(r["order"]), L)
+    d = r["rc"] == ord("d")
+    assert np.array_equal(back[d], read[r["order"][d]])
+    assert np.array_equal(bl, ln[r["order"]])
+    # 'r' records are reverse complements: applying the transform twice gives the read back
+    rr = np.flatnonzero(~d)
+    if len(rr):
+        s2 = po.write_dna_stream(back, bl, L, rr.astype(np.uint32), np.full(len(rr), ord("r"), np.uint8))
+        b2, _ = po.load_dna(s2, len(rr), L)
+        assert np.array_equal(b2, read[r["order"][rr]])
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "var2k", "heavy"])
+def test_golden_fixtures(name):
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from the oracle after it
+    reproduced the reference's recorded counters; they freeze the expected byte streams."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    read, ln, n, L = _load(name)
+    a = po.reorder_serial(read, ln, L)
+    for k in KEYS:
+        assert np.array_equal(a[k], g[k]), (name, k)
+    for K in (4, 64):
+        b = po.reorder_rounds(read, ln, L, K, 2)
+        for k in KEYS:
+            assert np.array_equal(b[k], g["K%d_%s" % (K, k)]), (name, K, k)
