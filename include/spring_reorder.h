@@ -1,0 +1,152 @@
+/*
+ * include/spring_reorder.h -- C ABI of libspring_reorder_hip.so
+ *
+ * MI355X-native replacement for SPRING's read-reordering stage.  Every entry
+ * point names the reference interface it replaces (paths relative to
+ * /root/reference/src).  Plain pointers and sizes only; the library owns all
+ * device memory, the caller owns every host buffer it passes in.
+ *
+ * Return value: 0 on success, negative on error (see SPRING_REORDER_E_*);
+ * spring_reorder_last_error() returns a thread-local message.  The reference
+ * signals errors by throwing std::runtime_error (call_template_functions.cpp:60,
+ * main.cpp:140-166); INTEGRATION.md shows the 10-line shim that converts.
+ */
+#ifndef SPRING_REORDER_H_
+#define SPRING_REORDER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPRING_REORDER_E_ARG (-1)     /* bad argument (e.g. max_readlen > 511: "Wrong bitset size.") */
+#define SPRING_REORDER_E_IO (-2)      /* file missing / short / unwritable                         */
+#define SPRING_REORDER_E_HIP (-3)     /* HIP runtime error (no device, out of memory, ...)         */
+#define SPRING_REORDER_E_STATE (-4)   /* entry points called out of order                          */
+
+typedef struct spring_reorder_ctx spring_reorder_ctx;
+
+typedef struct {
+  int32_t device;       /* HIP device ordinal; -1 = current device                                */
+  uint32_t num_chains;  /* K concurrent greedy chains (= reference threads, reorder.h:351);
+                           1 reproduces `-t 1` byte for byte; 0 = auto (from N)                    */
+  int32_t num_thr;      /* number of per-tid output sets to emit (cp.num_thr, reorder.h:748)      */
+  int32_t collect_stats;/* 1: count reference-equivalent probes / key hits / Hamming evaluations  */
+  int32_t time_search;  /* 1: bracket every search-kernel launch with HIP events (bench roofline) */
+  int32_t force_literal_update; /* 1: consensus update always through the literal lane-0 path (tests) */
+  int32_t rounds_per_sync;      /* rounds enqueued between host termination checks; 0 = auto      */
+  int32_t reserved;
+} spring_reorder_opts;
+
+typedef struct {
+  /* work counters (reference-equivalent, see DESIGN.md "Algorithmic bytes") */
+  uint64_t n_reads, n_matched, n_single, unmatched;
+  uint64_t probes, keyok, cands, hits, iterations, rounds, lost;
+  uint64_t numkeys[2], dict_numreads[2];
+  /* device-side wall clock of the stages, milliseconds (HIP events on the library's stream) */
+  double ms_unpack, ms_dict, ms_chains, ms_finalize, ms_total;
+  /* search kernel: summed launch durations and launch count (only when time_search=1) */
+  double ms_search_kernel;
+  uint64_t search_launches;
+  uint64_t device_bytes;   /* bytes of HBM the context holds */
+} spring_reorder_stats;
+
+void spring_reorder_default_opts(spring_reorder_opts *o);
+const char *spring_reorder_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Drop-in stage: replaces
+ *     void spring::call_reorder(const std::string &temp_dir, compression_params &cp)
+ *     (call_template_functions.h:9, body call_template_functions.cpp:9-63)
+ *     -> reorder_main<bitset_size>(temp_dir, cp)            (reorder.h:732-786)
+ * Reads  temp_dir/input_clean_1.dna (+ _2.dna when paired_end) and DELETES them
+ * (reorder.h:232,241); writes, for every tid in [0,num_thr):
+ *   read_order.bin.<tid> (u32 LE)      read_rev.txt.<tid> (gzip, 'd'/'r')
+ *   tempflag.txt.<tid> (gzip, '0'/'1') temppos.txt.<tid> (gzip, i64 LE)
+ *   read_lengths.bin.<tid> (gzip, u16) temp.dna.<tid> (u16 len + 2-bit bases, RC applied)
+ * and temp.dna.singleton, read_order.bin.singleton, temp.dna.singleton.count
+ * (reorder.h:355-368, :643-730), i.e. exactly what encoder_main<> opens
+ * (encoder.h:580-593).  Fields used from compression_params: max_readlen,
+ * num_thr, paired_end, num_reads_clean[0..1] (reorder.h:747-763).
+ */
+int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, int32_t paired_end,
+                       uint32_t num_reads_clean_0, uint32_t num_reads_clean_1,
+                       const spring_reorder_opts *opts /* NULL = defaults */);
+
+/* ---------------------------------------------------------------------------
+ * Stage pieces on in-memory buffers (tests, bench, pipelines that keep reads
+ * in memory).  Call order: create -> load_* -> build_dict -> run_chains ->
+ * finalize -> download/emit -> destroy.
+ */
+int spring_reorder_create(spring_reorder_ctx **ctx, const spring_reorder_opts *opts);
+void spring_reorder_destroy(spring_reorder_ctx *ctx);
+
+/* readDnaFile (reorder.h:222-244): `dna` = n records of u16 len + ceil(len/4)
+ * bytes (util.cpp:269-294), file 1 records followed by file 2 records.
+ * Host buffer -> HBM copy, then the unpack kernel builds the limb array. */
+int spring_reorder_load_dna(spring_reorder_ctx *ctx, const uint8_t *dna, size_t nbytes, uint32_t n,
+                            uint32_t max_readlen);
+
+/* Same, but the record stream is already resident in HBM (d_dna is a device
+ * pointer the caller owns; fixed_len != 0 promises every record has
+ * len == max_readlen so record i starts at i*(2+ceil(L/4))). */
+int spring_reorder_load_dna_device(spring_reorder_ctx *ctx, const void *d_dna, size_t nbytes, uint32_t n,
+                                   uint32_t max_readlen, int32_t fixed_len);
+
+/* constructdictionary (bitset_util.h:74-221) for both dictionaries of
+ * reorder.h:751-759: keys -> sort -> unique -> exact hash table + CSR bins. */
+int spring_reorder_build_dict(spring_reorder_ctx *ctx);
+
+/* reorder() (reorder.h:320-641): the greedy chain search, K chains in
+ * lock-step rounds (search_match reorder.h:246-318, updaterefcount :110-220). */
+int spring_reorder_run_chains(spring_reorder_ctx *ctx);
+
+/* Gathers the per-chain emissions into the per-tid streams (the replay side of
+ * writetofile, reorder.h:643-730). */
+int spring_reorder_finalize(spring_reorder_ctx *ctx);
+
+int spring_reorder_get_stats(spring_reorder_ctx *ctx, spring_reorder_stats *st);
+
+/* Copies the streams to host arrays sized n_matched / n_single (get_stats) and
+ * num_thr+1 for the offsets: what the reference writes to read_order.bin.<tid>,
+ * read_rev.txt.<tid>, tempflag.txt.<tid>, temppos.txt.<tid>, read_lengths.bin.<tid>
+ * (concatenated in tid order) and read_order.bin.singleton.  Any pointer may be NULL. */
+int spring_reorder_download(spring_reorder_ctx *ctx, uint32_t *order, char *rc, char *flag, int64_t *pos,
+                            uint16_t *rlen, uint32_t *order_s, uint64_t *tid_off, uint64_t *tid_off_s);
+
+/* temp.dna.<tid> (tid >= 0) or temp.dna.singleton (tid = -1) byte stream, built
+ * on the device (reverse complement + 2-bit repack, reorder.h:667-687,
+ * util.cpp:269-294).  dst may be NULL to query *nbytes. */
+int spring_reorder_emit_dna(spring_reorder_ctx *ctx, int32_t tid, uint8_t *dst, size_t cap, size_t *nbytes);
+
+/* Test hook: bins of dictionary `which` for the given keys, as
+ * bbhashdict::findpos would return them on the untouched dictionary
+ * (bitset_util.cpp:20-35).  bin_size[i] = 0xffffffff when the key is absent;
+ * ids are concatenated into bin_ids (capacity ids_cap). */
+int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uint64_t *keys, uint32_t nkeys,
+                               uint32_t *bin_size, uint32_t *bin_ids, size_t ids_cap);
+
+/* Test hook: limb array + lengths as the unpack kernel produced them. */
+int spring_reorder_download_reads(spring_reorder_ctx *ctx, uint64_t *limbs /* n*W */, uint16_t *len);
+
+/* ---------------------------------------------------------------------------
+ * Synthetic input for bench.py / tests: uniform random
+ * genome of G bases, n reads of length L at uniform positions, i.i.d.
+ * substitutions at rate err_ppm/1e6, 50 % reverse complemented, no N.  A
+ * counter-based generator (splitmix64 of the index), so the host and the
+ * device version produce identical bytes.  Output = .dna record stream.
+ */
+size_t spring_synth_dna_bytes(uint32_t n, uint32_t L);
+int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
+/* generates straight into HBM owned by the context and loads it (fixed_len). */
+int spring_reorder_load_synth(spring_reorder_ctx *ctx, uint32_t n, uint32_t L, uint64_t G, uint64_t seed,
+                              uint32_t err_ppm);
+/* copies the device-generated record stream back (tests). */
+int spring_reorder_download_dna(spring_reorder_ctx *ctx, uint8_t *dst, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRING_REORDER_H_ */

@@ -1,0 +1,6 @@
+"""spring_amd -- MI355X-native replacement for SPRING's read-reordering stage
+(reference src/reorder.h + bitset_util.{h,cpp}).  Python is only the host-side
+mirror of the stage interface; all compute is in lib/libspring_reorder_hip.so
+(hand-written HIP for gfx950).  There is no CPU fallback: importing works
+anywhere, running requires the built library and a GPU."""
+from .reorder import (ReorderError, ReorderOpts, ReorderStage, call_reorder, reorder_dna, synth_dna_host)  # noqa: F401

@@ -1,0 +1,81 @@
+"""ctypes binding of lib/libspring_reorder_hip.so (C ABI: include/spring_reorder.h)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libspring_reorder_hip.so")
+
+EXPORTS = [
+    "spring_reorder_default_opts", "spring_reorder_last_error", "spring_reorder_run", "spring_reorder_create",
+    "spring_reorder_destroy", "spring_reorder_load_dna", "spring_reorder_load_dna_device",
+    "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
+    "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
+    "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
+    "spring_synth_dna_host", "spring_reorder_load_synth", "spring_reorder_download_dna",
+]
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("num_chains", C.c_uint32), ("num_thr", C.c_int32),
+                ("collect_stats", C.c_int32), ("time_search", C.c_int32), ("force_literal_update", C.c_int32),
+                ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = ([(k, C.c_uint64) for k in ("n_reads", "n_matched", "n_single", "unmatched", "probes", "keyok",
+                                          "cands", "hits", "iterations", "rounds", "lost")]
+                + [("numkeys", C.c_uint64 * 2), ("dict_numreads", C.c_uint64 * 2)]
+                + [(k, C.c_double) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize", "ms_total",
+                                             "ms_search_kernel")]
+                + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64)])
+
+    def asdict(self):
+        d = {}
+        for k, _ in self._fields_:
+            v = getattr(self, k)
+            d[k] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; fails loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "spring_amd: %s is missing. Build it with `python -m spring_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u8p = C.c_void_p, C.c_void_p
+    L.spring_reorder_default_opts.argtypes = [C.POINTER(Opts)]
+    L.spring_reorder_last_error.restype = C.c_char_p
+    L.spring_reorder_run.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
+                                     C.POINTER(Opts)]
+    L.spring_reorder_create.argtypes = [C.POINTER(vp), C.POINTER(Opts)]
+    L.spring_reorder_destroy.argtypes = [vp]
+    L.spring_reorder_destroy.restype = None
+    L.spring_reorder_load_dna.argtypes = [vp, u8p, C.c_size_t, C.c_uint32, C.c_uint32]
+    L.spring_reorder_load_dna_device.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int32]
+    L.spring_reorder_build_dict.argtypes = [vp]
+    L.spring_reorder_run_chains.argtypes = [vp]
+    L.spring_reorder_finalize.argtypes = [vp]
+    L.spring_reorder_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.spring_reorder_download.argtypes = [vp] + [vp] * 8
+    L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.spring_reorder_dict_lookup.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, vp, C.c_size_t]
+    L.spring_reorder_download_reads.argtypes = [vp, vp, vp]
+    L.spring_synth_dna_bytes.restype = C.c_size_t
+    L.spring_synth_dna_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    L.spring_synth_dna_host.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.spring_reorder_load_synth.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.spring_reorder_download_dna.argtypes = [vp, u8p, C.c_size_t]
+    for name in EXPORTS:
+        if name not in ("spring_reorder_last_error", "spring_reorder_destroy", "spring_synth_dna_bytes",
+                        "spring_reorder_default_opts"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

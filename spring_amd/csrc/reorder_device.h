@@ -1,0 +1,104 @@
+// spring_amd/csrc/reorder_device.h -- device-side data layout shared by the
+// kernels (reorder_kernels.hip) and the host pipeline (reorder_pipeline.cpp).
+#ifndef SPRING_REORDER_DEVICE_H_
+#define SPRING_REORDER_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sr {
+
+constexpr int MAX_READ_LEN = 511;   // params.h:22
+constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
+constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
+constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in LDS
+constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
+
+enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
+enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2 };
+
+// Per-chain state (one greedy chain == one reference OpenMP thread, reorder.h:351-431).
+struct __attribute__((aligned(16))) Chain {
+  uint64_t ref[16];      // consensus, 2 bits/base (reorder.h:371)
+  uint64_t revref[16];   // its reverse complement
+  long long ref_pos;     // reorder.h:397
+  int32_t ref_len;
+  uint32_t current, prev, first_rid;
+  uint32_t prop_rid;
+  int32_t prop_shift;
+  uint32_t num_reads_thr, num_unmatched_past;   // early-stop window (reorder.h:380-381)
+  uint32_t n_emit, n_single, unmatched;
+  uint8_t done, prev_unmatched, left_search, stop_searching;
+  uint8_t mode, retrying, prop_kind, prop_rev;
+  uint8_t cnt_buf, finishing, pad0, pad1;
+  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost;
+};
+
+struct Globals {
+  long long cursor;   // every read above it is taken (== min over threads of remainingpos, reorder.h:402)
+  uint32_t alive;     // chains not done
+  uint32_t nrec;      // matched-stream records appended
+  uint32_t nsing;     // singleton records appended
+  uint32_t pad;
+};
+
+struct DevParams {
+  // reads
+  const uint64_t *reads;  // n * S limbs (S = limb stride, power of two >= W, <= 16)
+  const uint16_t *lens;
+  uint32_t n;
+  int L, W, S, Lpad, maxshift, uniform_len, force_literal;
+  // dictionaries (reorder.h:751-759)
+  int dstart[2], dend[2];
+  uint32_t numkeys[2];
+  const uint64_t *tab[2];
+  uint64_t bmask[2];
+  const uint32_t *ids[2];
+  // shared mutable state
+  uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
+  uint32_t *resv;     // lowest chain id that proposed read r this round (0xffffffff = none)
+  uint32_t *needy;    // bitmap over chains waiting for a seed
+  Globals *glob;
+  // chains
+  uint32_t K;
+  Chain *chains;
+  int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong
+  // append-order emission buffers (+ chain, seq for the final scatter)
+  uint32_t *e_order; char *e_rc; char *e_flag; long long *e_pos; uint16_t *e_len; uint32_t *e_chain; uint32_t *e_seq;
+  uint32_t *s_order; uint32_t *s_chain; uint32_t *s_seq;
+  // final streams (tid-major, chain ascending inside a tid)
+  uint32_t *f_order; char *f_rc; char *f_flag; long long *f_pos; uint16_t *f_len; uint32_t *f_order_s;
+};
+
+// launchers (reorder_kernels.hip)
+void launch_unpack(hipStream_t st, const uint8_t *dna, const uint64_t *off, uint32_t n, int L, int W, int S,
+                   uint32_t rec_fixed, uint64_t *reads, uint16_t *lens);
+void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int dend, uint32_t *flag);
+void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
+                 int S, int dstart, int dend, uint64_t *keys, uint32_t *vals);
+void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
+                       uint32_t numkeys, uint64_t *tab, uint64_t bmask);
+void launch_dict_lookup(hipStream_t st, const uint64_t *tab, uint64_t bmask, const uint64_t *keys, uint32_t nkeys,
+                        uint32_t *start, uint32_t *count);
+void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
+void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n);
+void launch_init_chains(hipStream_t st, const DevParams &P);
+void launch_search(hipStream_t st, const DevParams &P, bool stats);
+void launch_apply(hipStream_t st, const DevParams &P);
+void launch_scatter(hipStream_t st, const DevParams &P, uint32_t nrec, uint32_t nsing, const uint64_t *off_m,
+                    const uint64_t *off_s);
+void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz);
+void launch_emit_dna(hipStream_t st, const uint64_t *reads, const uint16_t *lens, int S, const uint32_t *order,
+                     const char *rc, uint64_t cnt, const uint64_t *off, uint32_t rec_fixed, uint8_t *dst);
+void launch_synth(hipStream_t st, uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t thr24);
+
+hipError_t sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
+                      const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
+hipError_t rle(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *in, size_t n, uint64_t *uniq,
+               uint32_t *counts, uint32_t *nruns);
+hipError_t excl_scan_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n);
+hipError_t excl_scan_u32_to_u64(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint64_t *out,
+                                size_t n);
+
+}  // namespace sr
+#endif

@@ -1,0 +1,829 @@
+// spring_amd/csrc/reorder_kernels.hip
+//
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64) for SPRING's read-reordering
+// stage, plus their launch wrappers.  Reference behaviour: /root/reference/src
+// reorder.h + bitset_util.{h,cpp}; each kernel names the loop it replaces.
+// No MFMA here: everything is 64-bit integer / bit work bounded by random HBM
+// access.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "reorder_device.h"
+#include "synth_common.h"
+
+namespace sr {
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+
+// orders LDS traffic between lanes of one wavefront (no block barrier: the
+// waves of a block run independent chains and may exit early)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+  uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// 64 bits starting at bit `bitpos` (may be negative / beyond the read) of a limb
+// array staged in LDS with LDS_PAD zero limbs on both sides; `s` points at limb 0.
+__device__ __forceinline__ uint64_t lds_window(const uint64_t *s, int bitpos) {
+  int li = bitpos >> 6, off = bitpos & 63;
+  uint64_t lo = s[li], hi = s[li + 1];
+  return off ? (lo >> off) | (hi << (64 - off)) : lo;
+}
+
+__device__ __forceinline__ uint64_t spread32(uint32_t x) {
+  uint64_t v = x;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v;
+}
+
+__device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uint32_t rid) {
+  return (taken[rid >> 6] >> (rid & 63)) & 1ull;
+}
+
+// exact key -> (start,count) map: buckets of 4 slots, one 64-byte line each:
+// [k0 k1 k2 k3 m0 m1 m2 m3], m = start | count<<32, m==0 marks an empty slot.
+// Replaces boomphf lookup + findpos + key re-check (reorder.h:271-285).
+__device__ __forceinline__ bool tab_lookup(const uint64_t *__restrict__ tab, uint64_t bmask, uint64_t key,
+                                           uint32_t &start, uint32_t &count) {
+  uint64_t b = mix64(key) & bmask;
+  for (;;) {
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(tab + b * 8);
+    ulonglong2 k01 = p[0], k23 = p[1], m01 = p[2], m23 = p[3];
+    uint64_t m;
+    if (m01.x == 0) return false;
+    if (k01.x == key) { m = m01.x; goto found; }
+    if (m01.y == 0) return false;
+    if (k01.y == key) { m = m01.y; goto found; }
+    if (m23.x == 0) return false;
+    if (k23.x == key) { m = m23.x; goto found; }
+    if (m23.y == 0) return false;
+    if (k23.y == key) { m = m23.y; goto found; }
+    b = (b + 1) & bmask;
+    continue;
+  found:
+    start = (uint32_t)m;
+    count = (uint32_t)(m >> 32);
+    return true;
+  }
+}
+
+// ------------------------------------------------------- K1 unpack (readDnaFile)
+// reorder.h:222-244: u16 len + ceil(len/4) raw bytes -> zero padded limbs.
+__global__ void k_unpack(const uint8_t *__restrict__ dna, const uint64_t *__restrict__ off, uint32_t n,
+                         int L, int W, int S, uint32_t rec_fixed, uint64_t *__restrict__ reads,
+                         uint16_t *__restrict__ lens) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t i = t / (uint32_t)S;
+  int j = (int)(t % (uint32_t)S);
+  if (i >= n) return;
+  uint64_t o = off ? off[i] : i * (uint64_t)rec_fixed;
+  uint32_t len = (uint32_t)dna[o] | ((uint32_t)dna[o + 1] << 8);
+  if (j == 0) lens[i] = (uint16_t)len;
+  uint32_t nb = (len + 3) / 4;
+  uint64_t v = 0;
+  if (j < W) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      uint32_t pos = 8u * j + b;
+      if (pos < nb) v |= (uint64_t)dna[o + 2 + pos] << (8 * b);
+    }
+  }
+  reads[i * S + j] = v;
+}
+
+// ------------------------------------------------ K2 key extraction (bitset_util.h:83-105)
+__global__ void k_flag_in_dict(const uint16_t *__restrict__ lens, uint32_t n, int dend,
+                               uint32_t *__restrict__ flag) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = lens[i] > dend ? 1u : 0u;
+}
+
+__global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__restrict__ lens,
+                       const uint32_t *__restrict__ slot /* exclusive scan of flags, or null */, uint32_t n,
+                       int S, int dstart, int dend, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (slot && !(lens[i] > dend)) return;
+  const uint64_t *r = reads + (uint64_t)i * S;
+  int bitpos = 2 * dstart, nbits = 2 * (dend - dstart + 1);
+  int li = bitpos >> 6, offb = bitpos & 63;
+  uint64_t v = r[li] >> offb;
+  if (offb && li + 1 < S) v |= r[li + 1] << (64 - offb);
+  if (nbits < 64) v &= (1ull << nbits) - 1;
+  uint32_t o = slot ? slot[i] : i;
+  keys[o] = v;
+  vals[o] = i;
+}
+
+// ------------------------------------------------ K3 table insert (bitset_util.h:122-217)
+__global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
+                             const uint32_t *__restrict__ ucount, uint32_t numkeys, uint64_t *tab,
+                             uint64_t bmask) {
+  uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= numkeys) return;
+  uint64_t key = ukeys[u];
+  uint64_t meta = (uint64_t)ustart[u] | ((uint64_t)ucount[u] << 32);
+  uint64_t b = mix64(key) & bmask;
+  for (;;) {
+    unsigned long long *m = reinterpret_cast<unsigned long long *>(tab + b * 8 + 4);
+    for (int s = 0; s < 4; s++) {
+      if (atomicCAS(m + s, 0ull, (unsigned long long)meta) == 0ull) {
+        tab[b * 8 + s] = key;
+        return;
+      }
+    }
+    b = (b + 1) & bmask;
+  }
+}
+
+__global__ void k_dict_lookup(const uint64_t *__restrict__ tab, uint64_t bmask, const uint64_t *__restrict__ keys,
+                              uint32_t nkeys, uint32_t *__restrict__ start, uint32_t *__restrict__ count) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nkeys) return;
+  uint32_t s = 0, c = 0xffffffffu;
+  if (!tab_lookup(tab, bmask, keys[i], s, c)) { s = 0; c = 0xffffffffu; }
+  start[i] = s;
+  count[i] = c;
+}
+
+// ---------------------------------------------------------------- misc init
+__global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void k_init_taken(uint64_t *taken, uint64_t nwords, uint32_t n) {
+  uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint64_t v = 0;
+  if ((w + 1) * 64 > n) {  // bits >= n never become seeds
+    int valid = (int)((int64_t)n - (int64_t)w * 64);
+    v = valid <= 0 ? ~0ull : (valid >= 64 ? 0ull : (~0ull << valid));
+  }
+  taken[w] = v;
+}
+
+// --------------------------------------------------------- consensus update
+//
+// updaterefcount (reorder.h:110-220) for one chain by one wavefront.
+// Counts live in HBM as int4 per position (A,C,T,G order of reorder.h:120),
+// two buffers per chain (read cur, write nxt) so lanes never race on shifted
+// columns.  Position-parallel for every case that has no in-place aliasing;
+// the aliasing case (reverse, read longer than ref_len+shift) and the
+// test-only force_literal mode run the reference loops literally on an LDS
+// copy from lane 0.
+
+struct WaveLds {
+  uint64_t refs[2][LDS_LIMBS];   // ref / revref with zero padding (search)
+  uint64_t rd[16];               // limbs of the read being merged
+  uint8_t code[512];             // consensus codes (2-bit SPRING code per position)
+  int32_t cnt[4][512];           // literal path only
+};
+
+__device__ __forceinline__ int cidx_of_code(int code) {  // SPRING code A0 G1 C2 T3 -> count row A0 C1 T2 G3
+  return code == 0 ? 0 : code == 1 ? 3 : code == 2 ? 1 : 2;
+}
+__device__ __forceinline__ int code_of_cidx(int c) {  // inttochar {A,C,T,G} -> SPRING code
+  return c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 3 : 1;
+}
+// base i of the string `current` of updaterefcount: the read, or its reverse complement
+__device__ __forceinline__ int cur_base(const uint64_t *rd, int i, int n, bool rev) {
+  int q = rev ? n - 1 - i : i;
+  int code = (int)((rd[q >> 5] >> (2 * (q & 31))) & 3ull);
+  return rev ? 3 - code : code;
+}
+
+// packs LDS codes[0..R) into limbs (ballot based) and writes ref + revref
+__device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int W, int lane, Chain *c) {
+  wave_sync();
+  int nblk = (R + 63) >> 6;
+  for (int k = 0; k < 8; k++) {
+    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+    if (k < nblk) {
+      int p = k * 64 + lane;
+      int cf = 0, cr = 0;
+      if (p < R) {
+        cf = ws->code[p];
+        cr = 3 - ws->code[R - 1 - p];
+      }
+      f0 = __ballot(cf & 1); f1 = __ballot(cf & 2);
+      r0 = __ballot(cr & 1); r1 = __ballot(cr & 2);
+    }
+    if (lane == 0) {
+      if (2 * k < 16) {
+        c->ref[2 * k] = spread32((uint32_t)f0) | (spread32((uint32_t)f1) << 1);
+        c->revref[2 * k] = spread32((uint32_t)r0) | (spread32((uint32_t)r1) << 1);
+      }
+      if (2 * k + 1 < 16) {
+        c->ref[2 * k + 1] = spread32((uint32_t)(f0 >> 32)) | (spread32((uint32_t)(f1 >> 32)) << 1);
+        c->revref[2 * k + 1] = spread32((uint32_t)(r0 >> 32)) | (spread32((uint32_t)(r1 >> 32)) << 1);
+      }
+    }
+  }
+}
+
+// literal loops of reorder.h:133-212 on the LDS copy (lane 0 only)
+__device__ void update_literal_lane0(WaveLds *ws, bool reset, bool rev, int shift, int n, int &ref_len, int M) {
+  int32_t(*count)[512] = ws->cnt;
+  const uint64_t *rd = ws->rd;
+#define CB(i) cidx_of_code(cur_base(rd, (i), n, rev))
+  if (reset) {
+    for (int j = 0; j < 4; j++)
+      for (int i = 0; i < M; i++) count[j][i] = 0;
+    for (int i = 0; i < n; i++) count[CB(i)][i] = 1;
+    ref_len = n;
+    for (int i = 0; i < n; i++) ws->code[i] = (uint8_t)cur_base(rd, i, n, rev);
+    return;
+  }
+  if (!rev) {
+    for (int i = 0; i < ref_len - shift; i++) {
+      for (int j = 0; j < 4; j++) count[j][i] = count[j][i + shift];
+      if (i < n) count[CB(i)][i] += 1;
+    }
+    for (int i = ref_len - shift; i < n; i++) {
+      for (int j = 0; j < 4; j++) count[j][i] = 0;
+      count[CB(i)][i] = 1;
+    }
+    ref_len = max(ref_len - shift, n);
+  } else {
+    if (n - shift >= ref_len) {
+      for (int i = n - shift - ref_len; i < n - shift; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = count[j][i - (n - shift - ref_len)];
+        count[CB(i)][i] += 1;
+      }
+      for (int i = 0; i < n - shift - ref_len; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = 0;
+        count[CB(i)][i] = 1;
+      }
+      for (int i = n - shift; i < n; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = 0;
+        count[CB(i)][i] = 1;
+      }
+      ref_len = n;
+    } else if (ref_len + shift <= M) {
+      for (int i = ref_len - n + shift; i < ref_len; i++) count[CB(i - (ref_len - n + shift))][i] += 1;
+      for (int i = ref_len; i < ref_len + shift; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = 0;
+        count[CB(i - (ref_len - n + shift))][i] = 1;
+      }
+      ref_len = ref_len + shift;
+    } else {
+      for (int i = 0; i < M - shift; i++)
+        for (int j = 0; j < 4; j++) count[j][i] = count[j][i + (ref_len + shift - M)];
+      for (int i = M - n; i < M - shift; i++) count[CB(i - (M - n))][i] += 1;
+      for (int i = M - shift; i < M; i++) {
+        for (int j = 0; j < 4; j++) count[j][i] = 0;
+        count[CB(i - (M - n))][i] = 1;
+      }
+      ref_len = M;
+    }
+  }
+#undef CB
+  for (int i = 0; i < ref_len; i++) {
+    int mx = 0, ind = 0;
+    for (int j = 0; j < 4; j++)
+      if (count[j][i] > mx) { mx = count[j][i]; ind = j; }
+    ws->code[i] = (uint8_t)code_of_cidx(ind);
+  }
+}
+
+// one updaterefcount() call for chain c; rid = read merged in.  Returns new ref_len.
+__device__ int wave_update(const DevParams &P, Chain *c, uint32_t cid, WaveLds *ws, uint32_t rid, bool reset,
+                           bool rev, int shift, int lane) {
+  const int M = P.L, W = P.W;
+  const int n = P.uniform_len ? P.L : (int)P.lens[rid];
+  int R = c->ref_len;
+  if (lane < 16) ws->rd[lane] = lane < W ? P.reads[(uint64_t)rid * P.S + lane] : 0ull;
+  wave_sync();
+  const int cb = c->cnt_buf;
+  const int4 *cur = P.cnt + ((uint64_t)cid * 2 + cb) * P.Lpad;
+  int4 *nxt = P.cnt + ((uint64_t)cid * 2 + (cb ^ 1)) * P.Lpad;
+  int Rn;
+  bool literal = P.force_literal || (!reset && rev && (n - shift > R));
+  if (literal) {
+    for (int p = lane; p < M; p += 64) {
+      int4 v = reset ? make_int4(0, 0, 0, 0) : cur[p];
+      ws->cnt[0][p] = v.x; ws->cnt[1][p] = v.y; ws->cnt[2][p] = v.z; ws->cnt[3][p] = v.w;
+    }
+    wave_sync();
+    Rn = R;
+    if (lane == 0) update_literal_lane0(ws, reset, rev, shift, n, Rn, M);
+    Rn = __shfl(Rn, 0, 64);
+    wave_sync();
+    for (int p = lane; p < M; p += 64) nxt[p] = make_int4(ws->cnt[0][p], ws->cnt[1][p], ws->cnt[2][p], ws->cnt[3][p]);
+  } else {
+    // case parameters: out position p < hiP gets (p<cpy_hi ? cur[p+src_off] : 0) + (add_lo<=p<add_hi ? onehot(base p-add_lo+0) : 0)
+    int hiP, cpy_hi, src_off, add_lo, add_hi;
+    if (reset) { hiP = M; cpy_hi = 0; src_off = 0; add_lo = 0; add_hi = n; Rn = n; }
+    else if (!rev) { Rn = max(R - shift, n); hiP = Rn; cpy_hi = R - shift; src_off = shift; add_lo = 0; add_hi = n; }
+    else if (n - shift >= R) { /* == R here: no aliasing */ Rn = n; hiP = n; cpy_hi = R; src_off = 0; add_lo = 0; add_hi = n; }
+    else if (R + shift <= M) { Rn = R + shift; hiP = Rn; cpy_hi = R; src_off = 0; add_lo = R - n + shift; add_hi = Rn; }
+    else { Rn = M; hiP = M; cpy_hi = M - shift; src_off = R + shift - M; add_lo = M - n; add_hi = M; }
+    for (int p = lane; p < hiP; p += 64) {
+      int4 v = make_int4(0, 0, 0, 0);
+      if (p < cpy_hi) v = cur[p + src_off];
+      int code = -1;
+      if (p >= add_lo && p < add_hi) {
+        code = cur_base(ws->rd, p - add_lo, n, rev);
+        int ci = cidx_of_code(code);
+        if (ci == 0) v.x++; else if (ci == 1) v.y++; else if (ci == 2) v.z++; else v.w++;
+      }
+      nxt[p] = v;
+      if (p < Rn) {
+        int out;
+        if (reset) out = code;  // consensus = the read itself (reorder.h:133-142,214)
+        else {
+          int mx = 0, ind = 0;
+          if (v.x > mx) { mx = v.x; ind = 0; }
+          if (v.y > mx) { mx = v.y; ind = 1; }
+          if (v.z > mx) { mx = v.z; ind = 2; }
+          if (v.w > mx) { mx = v.w; ind = 3; }
+          out = code_of_cidx(ind);
+        }
+        ws->code[p] = (uint8_t)out;
+      }
+    }
+  }
+  pack_consensus(ws, Rn, W, lane, c);
+  if (lane == 0) { c->ref_len = Rn; c->cnt_buf = (uint8_t)(cb ^ 1); }
+  return Rn;
+}
+
+// ----------------------------------------------------------- chain start-up
+// reorder.h:405-431 with the critical section entered in chain-id order.
+__global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
+  __shared__ WaveLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t cid = blockIdx.x * 4 + wave;
+  if (cid >= P.K) return;
+  Chain *c = &P.chains[cid];
+  WaveLds *ws = &lds[wave];
+  const uint32_t step = P.n / P.K;
+  const uint32_t seed = cid * step;
+  bool start = P.n > 0 && (cid == 0 || step > 0);
+  if (lane == 0) {
+    c->done = start ? 0 : 1;
+    if (start) {
+      atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
+      atomicAdd(&P.glob->alive, 1u);
+      c->unmatched = 1; c->current = seed; c->prev = seed; c->first_rid = seed; c->prev_unmatched = 1;
+    }
+  }
+  if (!start) return;
+  wave_update(P, c, cid, ws, seed, true, false, 0, lane);
+}
+
+// ------------------------------------------------------------ K4 search (phase A)
+//
+// One wavefront per chain.  search_match + shift loop (reorder.h:246-318,
+// :479-558): 64 probes per batch, lane = 4*(shift%16) + 2*rev + dict, so lane
+// order == the reference's priority order (shift, fwd before rev, dict 0
+// before 1) and the first set bit of the hit ballot is the reference's winner.
+// Chains that need a new contig seed instead pick the (rank+1)-th highest
+// untaken read at or below the global cursor (reorder.h:576-592).
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_search(DevParams P) {
+  __shared__ uint64_t s_refs[4][2][LDS_LIMBS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t cid = blockIdx.x * 4 + wave;
+  if (cid >= P.K) return;
+  Chain *c = &P.chains[cid];
+  if (c->done) return;
+
+  if (c->mode == MODE_NEED_SEED) {
+    // rank among seed-needing chains (by chain id)
+    int r = 0;
+    const uint32_t nw = (P.K + 31) / 32;
+    for (uint32_t w = lane; w < nw; w += 64) {
+      uint32_t v = P.needy[w];
+      if (w * 32 + 32 <= cid) r += __popc(v);
+      else if (w * 32 <= cid) r += __popc(v & ((1u << (cid - w * 32)) - 1u));
+    }
+    uint32_t need = (uint32_t)wave_sum_i(r) + 1;
+    long long top = P.glob->cursor;
+    long long seed = -1;
+    while (top >= 0) {
+      const long long wtop = top >> 6, w = wtop - lane;
+      uint64_t u = 0;
+      if (w >= 0) {
+        u = ~P.taken[w];
+        if (w == wtop) {
+          int bits = (int)(top & 63) + 1;
+          if (bits < 64) u &= (1ull << bits) - 1;
+        }
+      }
+      int cnt = __popcll(u);
+      int incl = wave_incl_scan_i(cnt, lane);
+      uint32_t total = (uint32_t)__shfl(incl, 63, 64);
+      if (total >= need) {
+        uint64_t m = __ballot((uint32_t)incl >= need);
+        int wl = __ffsll((unsigned long long)m) - 1;
+        int before = __shfl(incl - cnt, wl, 64);
+        uint64_t uu = shfl_u64(u, wl);
+        int kth = (int)need - before;  // kth highest set bit of uu
+        for (int t = 1; t < kth; t++) uu &= ~(1ull << (63 - __clzll(uu)));
+        seed = (wtop - wl) * 64 + (63 - __clzll(uu));
+        break;
+      }
+      need -= total;
+      top = (wtop - 64) * 64 + 63;
+    }
+    if (lane == 0) {
+      if (seed >= 0) {
+        c->prop_kind = PROP_SEED;
+        c->prop_rid = (uint32_t)seed;
+        atomicMin(&P.resv[seed], cid);
+      } else {
+        c->prop_kind = PROP_NONE;
+        c->finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
+      }
+    }
+    return;
+  }
+
+  // ---- search mode
+  bool stop = c->stop_searching;
+  if (!c->retrying) {  // iteration start bookkeeping (reorder.h:433-439), once per iteration
+    uint32_t nr = c->num_reads_thr;
+    if (nr % 1000000u == 0) {
+      if ((float)c->num_unmatched_past > 0.5f * 1000000) stop = true;
+      if (lane == 0) { c->num_unmatched_past = 0; c->stop_searching = stop; }
+    }
+    if (lane == 0) { c->num_reads_thr = nr + 1; if (STATS) c->st_iter++; }
+  }
+  if (stop) { if (lane == 0) c->prop_kind = PROP_NONE; return; }
+
+  const int W = P.W, ref_len = c->ref_len;
+  uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
+  if (lane < LDS_LIMBS) {
+    int i = lane - LDS_PAD;
+    bool in = i >= 0 && i < W;
+    s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
+    s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
+  }
+  wave_sync();
+
+  const int l = lane & 1, rev = (lane >> 1) & 1;
+  const int ds = P.dstart[l], de = P.dend[l];
+  const int klen2 = 2 * (de - ds + 1);
+  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
+  const uint64_t *__restrict__ tab = P.tab[l];
+  const uint64_t bmask = P.bmask[l];
+  const uint32_t *__restrict__ ids = P.ids[l];
+  const uint64_t *sx = rev ? srev : sref;
+  const int nbatch = (P.maxshift + 15) >> 4;
+  uint64_t st_p = 0, st_k = 0, st_c = 0;
+  bool found = false;
+  uint32_t frid = 0;
+  int fshift = 0, frev = 0;
+  for (int b = 0; b < nbatch; b++) {
+    const int shift = b * 16 + (lane >> 2);
+    bool valid = shift < P.maxshift;
+    if (!rev) valid = valid && (de + shift < ref_len);
+    else valid = valid && (de < ref_len + shift) && (ds > shift);
+    bool hit = false, keyok = false;
+    uint32_t rid = 0, ncand = 0;
+    if (valid && P.numkeys[l] > 0) {
+      const int kb = rev ? 2 * (ds - shift) : 2 * (ds + shift);
+      const uint64_t key = lds_window(sx, kb) & kmask;
+      uint32_t start, count;
+      if (tab_lookup(tab, bmask, key, start, count)) {
+        const int bitshift = rev ? -2 * shift : 2 * shift;
+        const int lo = rev ? shift : 0;
+        const int mref = rev ? ref_len + shift : ref_len - shift;
+        int live = 0;
+        for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
+          const uint32_t r = ids[start + j];
+          if (is_taken(P.taken, r)) continue;
+          live++; keyok = true; ncand++;
+          const int clen = P.uniform_len ? P.L : (int)P.lens[r];
+          const int m = clen < mref ? clen : mref;
+          const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
+          const int blo = 2 * lo, bhi = 2 * m;
+          int h = 0;
+          for (int i = 0; i < W; i++) {
+            const int s0 = i * 64;
+            if (s0 >= bhi) break;
+            if (s0 + 64 <= blo) continue;
+            uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
+            if (blo > s0) x &= ~0ull << (blo - s0);
+            if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
+            h += __popcll(x);
+          }
+          if (h <= THRESH) { hit = true; rid = r; break; }
+        }
+      }
+    }
+    const uint64_t hm = __ballot(hit);
+    if (STATS) {  // what the reference would have executed: everything up to and including the winner
+      const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
+      const uint64_t le = win == 63 ? ~0ull : ((1ull << (win + 1)) - 1);
+      st_p += __popcll(__ballot(valid) & le);
+      st_k += __popcll(__ballot(keyok) & le);
+      st_c += (uint64_t)wave_sum_i(lane <= win ? (int)ncand : 0);
+    }
+    if (hm) {
+      const int win = __ffsll((unsigned long long)hm) - 1;
+      frid = (uint32_t)__shfl((int)rid, win, 64);
+      fshift = b * 16 + (win >> 2);
+      frev = (win >> 1) & 1;
+      found = true;
+      break;
+    }
+  }
+  if (lane == 0) {
+    if (STATS) { c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c; }
+    if (found) {
+      c->prop_kind = PROP_MATCH; c->prop_rid = frid; c->prop_shift = fshift; c->prop_rev = (uint8_t)frev;
+      atomicMin(&P.resv[frid], cid);
+    } else {
+      c->prop_kind = PROP_NONE;
+    }
+  }
+}
+
+// ------------------------------------------------------------- K5/K6 apply (phase B)
+//
+// Resolves the round's proposals (lowest chain id holds resv[rid]) and applies
+// the winner's step: claim, consensus update, position bookkeeping and
+// emission (reorder.h:484-515, :522-553), or the failure path (reorder.h:559-615).
+__device__ __forceinline__ void emit_rec(const DevParams &P, Chain *c, uint32_t cid, uint32_t idx, uint32_t rid,
+                                         char rc, char flag, long long pos, uint32_t seq) {
+  P.e_order[idx] = rid; P.e_rc[idx] = rc; P.e_flag[idx] = flag; P.e_pos[idx] = pos;
+  P.e_len[idx] = P.uniform_len ? (uint16_t)P.L : P.lens[rid];
+  P.e_chain[idx] = cid; P.e_seq[idx] = seq;
+}
+__device__ __forceinline__ void emit_single(const DevParams &P, Chain *c, uint32_t cid, uint32_t rid) {
+  uint32_t idx = atomicAdd(&P.glob->nsing, 1u);
+  P.s_order[idx] = rid; P.s_chain[idx] = cid; P.s_seq[idx] = c->n_single++;
+}
+
+__global__ __launch_bounds__(256) void k_apply(DevParams P) {
+  __shared__ WaveLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t cid = blockIdx.x * 4 + wave;
+  if (cid >= P.K) return;
+  Chain *c = &P.chains[cid];
+  if (c->done) return;
+  WaveLds *ws = &lds[wave];
+  const int kind = c->prop_kind;
+
+  if (c->finishing) {  // seed-needing chain found the pool empty
+    if (lane == 0) {
+      if (c->prev_unmatched) emit_single(P, c, cid, c->prev);
+      c->done = 1; c->finishing = 0;
+      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+      atomicSub(&P.glob->alive, 1u);
+    }
+    return;
+  }
+  if (kind != PROP_NONE && P.resv[c->prop_rid] != cid) {  // lost the read: retry next round
+    if (lane == 0) {
+      if (c->mode == MODE_SEARCH) c->retrying = 1;
+      c->st_lost++;
+    }
+    return;
+  }
+  if (kind == PROP_MATCH) {
+    const uint32_t rid = c->prop_rid;
+    const int shift = c->prop_shift;
+    const bool rev = c->prop_rev;
+    const int R_old = c->ref_len;
+    const int n = P.uniform_len ? P.L : (int)P.lens[rid];
+    const int R_new = wave_update(P, c, cid, ws, rid, false, rev, shift, lane);
+    if (lane == 0) {
+      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+      const bool left = c->left_search;
+      long long ref_pos = c->ref_pos, cur_pos;
+      char rcch;
+      if (!rev) {  // reorder.h:490-497, :508
+        if (!left) { cur_pos = ref_pos + shift; ref_pos = cur_pos; }
+        else { cur_pos = ref_pos + R_old - shift - n; ref_pos = ref_pos + R_old - shift - R_new; }
+        rcch = left ? 'r' : 'd';
+      } else {  // reorder.h:528-535, :546
+        if (!left) { cur_pos = ref_pos + R_old + shift - n; ref_pos = ref_pos + R_old + shift - R_new; }
+        else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
+        rcch = left ? 'd' : 'r';
+      }
+      const uint32_t cnt = c->prev_unmatched ? 2u : 1u;
+      uint32_t idx = atomicAdd(&P.glob->nrec, cnt);
+      uint32_t seq = c->n_emit;
+      if (c->prev_unmatched) emit_rec(P, c, cid, idx++, c->prev, 'd', '0', 0, seq++);
+      emit_rec(P, c, cid, idx, rid, rcch, '1', cur_pos, seq++);
+      c->n_emit = seq;
+      c->prev_unmatched = 0; c->current = rid; c->ref_pos = ref_pos; c->retrying = 0;
+    }
+  } else if (kind == PROP_SEED) {  // reorder.h:580-587, :600-613
+    const uint32_t rid = c->prop_rid;
+    wave_update(P, c, cid, ws, rid, true, false, 0, lane);
+    if (lane == 0) {
+      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+      atomicMin((long long *)&P.glob->cursor, (long long)rid - 1);
+      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+      if (c->prev_unmatched) emit_single(P, c, cid, c->prev);
+      c->unmatched++;
+      c->prev_unmatched = 1; c->first_rid = rid; c->prev = rid; c->current = rid;
+      c->ref_pos = 0; c->mode = MODE_SEARCH;
+    }
+  } else if (c->mode == MODE_SEARCH) {  // search failed (reorder.h:559-575)
+    const bool left = c->left_search;
+    if (!left) wave_update(P, c, cid, ws, c->first_rid, true, true, 0, lane);
+    if (lane == 0) {
+      c->retrying = 0;
+      c->num_unmatched_past++;
+      if (!left) { c->left_search = 1; c->ref_pos = 0; }
+      else {
+        c->left_search = 0; c->mode = MODE_NEED_SEED;
+        atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------ K7 finalize / emit
+__global__ void k_scatter_matched(DevParams P, uint32_t nrec, const uint64_t *__restrict__ off_m) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrec) return;
+  uint64_t d = off_m[P.e_chain[i]] + P.e_seq[i];
+  P.f_order[d] = P.e_order[i]; P.f_rc[d] = P.e_rc[i]; P.f_flag[d] = P.e_flag[i];
+  P.f_pos[d] = P.e_pos[i]; P.f_len[d] = P.e_len[i];
+}
+__global__ void k_scatter_single(DevParams P, uint32_t nsing, const uint64_t *__restrict__ off_s) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsing) return;
+  P.f_order_s[off_s[P.s_chain[i]] + P.s_seq[i]] = P.s_order[i];
+}
+
+// record sizes of a temp.dna stream (writetofile, reorder.h:667-687)
+__global__ void k_rec_size(const uint32_t *__restrict__ order, const uint16_t *__restrict__ lens, uint64_t cnt,
+                           uint32_t *__restrict__ sz) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt) sz[i] = 2u + ((uint32_t)lens[order[i]] + 3u) / 4u;
+}
+// 'd': u16 len + raw bytes; 'r': reverse complement re-packed (util.cpp:269-294, :376-381)
+__global__ void k_emit_dna(const uint64_t *__restrict__ reads, const uint16_t *__restrict__ lens, int S,
+                           const uint32_t *__restrict__ order, const char *__restrict__ rc, uint64_t cnt,
+                           const uint64_t *__restrict__ off, uint32_t rec_fixed, uint8_t *__restrict__ dst) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const uint32_t rid = order[i];
+  const uint32_t len = lens[rid];
+  const uint64_t *r = reads + (uint64_t)rid * S;
+  uint8_t *o = dst + (off ? off[i] : i * (uint64_t)rec_fixed);
+  o[0] = (uint8_t)(len & 0xff); o[1] = (uint8_t)(len >> 8);
+  const uint32_t nb = (len + 3) / 4;
+  const bool rev = rc && rc[i] == 'r';
+  for (uint32_t b = 0; b < nb; b++) {
+    uint32_t v = 0;
+    if (!rev) v = (uint32_t)(r[b >> 3] >> (8 * (b & 7))) & 0xffu;
+    else {
+      for (uint32_t q = 0; q < 4; q++) {
+        uint32_t j = 4 * b + q;
+        if (j < len) {
+          uint32_t s = len - 1 - j;
+          uint32_t code = (uint32_t)(r[s >> 5] >> (2 * (s & 31))) & 3u;
+          v |= (3u - code) << (2 * q);
+        }
+      }
+    }
+    o[2 + b] = (uint8_t)v;
+  }
+}
+
+// ------------------------------------------------------------- synthetic reads
+__global__ void k_synth(uint8_t *__restrict__ dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed,
+                        uint32_t thr24) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t rec = 2u + (L + 3) / 4;
+  uint8_t *o = dst + i * rec;
+  uint64_t pos; uint32_t rc;
+  syn_read_params(seed, G, L, i, &pos, &rc);
+  o[0] = (uint8_t)(L & 0xff); o[1] = (uint8_t)(L >> 8);
+  for (uint32_t b = 0; b < (L + 3) / 4; b++) {
+    uint32_t v = 0;
+    for (uint32_t q = 0; q < 4; q++) {
+      uint32_t j = 4 * b + q;
+      if (j < L) v |= syn_nat_to_spring(syn_read_base(seed, G, L, thr24, i, j, pos, rc)) << (2 * q);
+    }
+    o[2 + b] = (uint8_t)v;
+  }
+}
+
+// ================================================================== launchers
+#define GRID1(n, bs) dim3((unsigned)(((uint64_t)(n) + (bs) - 1) / (bs)))
+
+void launch_unpack(hipStream_t st, const uint8_t *dna, const uint64_t *off, uint32_t n, int L, int W, int S,
+                   uint32_t rec_fixed, uint64_t *reads, uint16_t *lens) {
+  if (!n) return;
+  uint64_t tot = (uint64_t)n * S;
+  hipLaunchKernelGGL(k_unpack, GRID1(tot, 256), dim3(256), 0, st, dna, off, n, L, W, S, rec_fixed, reads, lens);
+}
+void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int dend, uint32_t *flag) {
+  hipLaunchKernelGGL(k_flag_in_dict, GRID1(n, 256), dim3(256), 0, st, lens, n, dend, flag);
+}
+void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
+                 int S, int dstart, int dend, uint64_t *keys, uint32_t *vals) {
+  hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
+}
+void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
+                       uint32_t numkeys, uint64_t *tab, uint64_t bmask) {
+  if (!numkeys) return;
+  hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, numkeys, tab, bmask);
+}
+void launch_dict_lookup(hipStream_t st, const uint64_t *tab, uint64_t bmask, const uint64_t *keys, uint32_t nkeys,
+                        uint32_t *start, uint32_t *count) {
+  if (!nkeys) return;
+  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, tab, bmask, keys, nkeys, start, count);
+}
+void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_fill_u32, GRID1(n, 256), dim3(256), 0, st, p, n, v);
+}
+void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n) {
+  if (!nwords) return;
+  hipLaunchKernelGGL(k_init_taken, GRID1(nwords, 256), dim3(256), 0, st, taken, nwords, n);
+}
+void launch_init_chains(hipStream_t st, const DevParams &P) {
+  hipLaunchKernelGGL(k_init_chains, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+}
+void launch_search(hipStream_t st, const DevParams &P, bool stats) {
+  if (stats) hipLaunchKernelGGL(k_search<true>, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(k_search<false>, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+}
+void launch_apply(hipStream_t st, const DevParams &P) {
+  hipLaunchKernelGGL(k_apply, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+}
+void launch_scatter(hipStream_t st, const DevParams &P, uint32_t nrec, uint32_t nsing, const uint64_t *off_m,
+                    const uint64_t *off_s) {
+  if (nrec) hipLaunchKernelGGL(k_scatter_matched, GRID1(nrec, 256), dim3(256), 0, st, P, nrec, off_m);
+  if (nsing) hipLaunchKernelGGL(k_scatter_single, GRID1(nsing, 256), dim3(256), 0, st, P, nsing, off_s);
+}
+void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz) {
+  if (!cnt) return;
+  hipLaunchKernelGGL(k_rec_size, GRID1(cnt, 256), dim3(256), 0, st, order, lens, cnt, sz);
+}
+void launch_emit_dna(hipStream_t st, const uint64_t *reads, const uint16_t *lens, int S, const uint32_t *order,
+                     const char *rc, uint64_t cnt, const uint64_t *off, uint32_t rec_fixed, uint8_t *dst) {
+  if (!cnt) return;
+  hipLaunchKernelGGL(k_emit_dna, GRID1(cnt, 256), dim3(256), 0, st, reads, lens, S, order, rc, cnt, off, rec_fixed, dst);
+}
+void launch_synth(hipStream_t st, uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t thr24) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_synth, GRID1(n, 256), dim3(256), 0, st, dst, n, L, G, seed, thr24);
+}
+
+// ------------------------------------------------- rocPRIM plumbing (sort / RLE / scan)
+hipError_t sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
+                      const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, end_bit, st);
+}
+hipError_t rle(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *in, size_t n, uint64_t *uniq,
+               uint32_t *counts, uint32_t *nruns) {
+  return rocprim::run_length_encode(tmp, tmp_bytes, in, n, uniq, counts, nruns, st);
+}
+hipError_t excl_scan_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n) {
+  return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), st);
+}
+hipError_t excl_scan_u32_to_u64(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint64_t *out,
+                                size_t n) {
+  return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), st);
+}
+
+}  // namespace sr

@@ -1,0 +1,685 @@
+// spring_amd/csrc/reorder_pipeline.cpp
+//
+// Host side of the reorder stage: owns the device memory, sequences the HIP
+// kernels of reorder_kernels.hip on one stream and implements the in-memory
+// half of the C ABI declared in include/spring_reorder.h.  Mirrors
+// reorder_main<N>() (reference src/reorder.h:732-786): load -> dictionaries ->
+// chains -> streams.  There is no CPU fallback anywhere in this file: every
+// stage runs on the GPU or the call fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "reorder_device.h"
+#include "spring_reorder.h"
+#include "synth_common.h"
+
+namespace sr {
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace sr
+
+using namespace sr;
+
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(SPRING_REORDER_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+enum { ST_CREATED = 0, ST_LOADED = 1, ST_DICT = 2, ST_CHAINS = 3, ST_FINAL = 4 };
+
+struct DictDev {
+  int start = 0, end = 0;
+  uint32_t numkeys = 0, numreads = 0;
+  uint64_t bmask = 0;
+  uint64_t *tab = nullptr;
+  uint32_t *ids = nullptr;
+};
+
+struct spring_reorder_ctx {
+  spring_reorder_opts o;
+  int dev = 0;
+  hipStream_t st = nullptr;
+  int stage = ST_CREATED;
+  std::vector<void *> allocs;
+  uint64_t dev_bytes = 0;
+  // input
+  uint8_t *d_dna = nullptr;  // record stream (owned unless borrowed)
+  bool dna_borrowed = false;
+  size_t dna_bytes = 0;
+  uint64_t *d_off = nullptr;
+  uint32_t n = 0;
+  int L = 0, W = 0, S = 0, Lpad = 0;
+  bool uniform = true;
+  uint64_t *d_reads = nullptr;
+  uint16_t *d_lens = nullptr;
+  DictDev dict[2];
+  DevParams P;
+  uint32_t K = 0;
+  uint32_t nrec = 0, nsing = 0;
+  std::vector<uint64_t> tid_off, tid_off_s;
+  spring_reorder_stats stats;
+  hipEvent_t ev[8];
+  bool ev_ok = false;
+
+  int dmalloc(void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(SPRING_REORDER_E_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    allocs.push_back(*p);
+    dev_bytes += bytes;
+    return 0;
+  }
+  void dfree(void *p) {
+    if (!p) return;
+    auto it = std::find(allocs.begin(), allocs.end(), p);
+    if (it != allocs.end()) allocs.erase(it);
+    (void)hipFree(p);
+  }
+};
+
+#define DMALLOC(ptr, bytes)                                   \
+  do {                                                        \
+    int r_ = ctx->dmalloc((void **)&(ptr), (bytes));          \
+    if (r_) return r_;                                        \
+  } while (0)
+
+extern "C" {
+
+void spring_reorder_default_opts(spring_reorder_opts *o) {
+  memset(o, 0, sizeof(*o));
+  o->device = -1;
+  o->num_chains = 0;
+  o->num_thr = 1;
+}
+
+const char *spring_reorder_last_error(void) { return g_err.c_str(); }
+
+int spring_reorder_create(spring_reorder_ctx **out, const spring_reorder_opts *opts) {
+  if (!out) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  spring_reorder_opts o;
+  if (opts) o = *opts; else spring_reorder_default_opts(&o);
+  if (o.num_thr <= 0) return fail(SPRING_REORDER_E_ARG, "num_thr must be >= 1");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(SPRING_REORDER_E_HIP, "no HIP device");
+  int dev = o.device;
+  if (dev < 0) HIPCHK(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(SPRING_REORDER_E_ARG, "device %d out of range (%d devices)", dev, ndev);
+  HIPCHK(hipSetDevice(dev));
+  spring_reorder_ctx *ctx = new spring_reorder_ctx();
+  ctx->o = o;
+  ctx->dev = dev;
+  memset(&ctx->P, 0, sizeof(ctx->P));
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  HIPCHK(hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking));
+  for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
+  ctx->ev_ok = true;
+  *out = ctx;
+  return 0;
+}
+
+void spring_reorder_destroy(spring_reorder_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->dev);
+  if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+  for (void *p : ctx->allocs) (void)hipFree(p);
+  if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->st) (void)hipStreamDestroy(ctx->st);
+  delete ctx;
+}
+
+static int setup_geometry(spring_reorder_ctx *ctx, uint32_t n, uint32_t max_readlen) {
+  if (max_readlen == 0 || max_readlen > (uint32_t)MAX_READ_LEN)
+    return fail(SPRING_REORDER_E_ARG, "Wrong bitset size. (max_readlen=%u, supported 1..511)", max_readlen);
+  ctx->n = n;
+  ctx->L = (int)max_readlen;
+  ctx->W = (2 * ctx->L - 1) / 64 + 1;  // call_template_functions.cpp:10
+  int S = 1;
+  while (S < ctx->W) S <<= 1;
+  ctx->S = S;
+  ctx->Lpad = (ctx->L + 63) / 64 * 64;
+  // dictionary windows, reorder.h:751-759
+  const int L = ctx->L;
+  ctx->dict[0].start = L > 100 ? L / 2 - 32 : L / 2 - L * 32 / 100;
+  ctx->dict[0].end = L / 2 - 1;
+  ctx->dict[1].start = L / 2;
+  ctx->dict[1].end = L > 100 ? L / 2 - 1 + 32 : L / 2 - 1 + L * 32 / 100;
+  return 0;
+}
+
+static int unpack_on_device(spring_reorder_ctx *ctx) {
+  DMALLOC(ctx->d_reads, (size_t)std::max<uint32_t>(ctx->n, 1) * ctx->S * sizeof(uint64_t));
+  DMALLOC(ctx->d_lens, (size_t)std::max<uint32_t>(ctx->n, 1) * sizeof(uint16_t));
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->st));
+  const uint32_t rec = 2u + ((uint32_t)ctx->L + 3u) / 4u;
+  launch_unpack(ctx->st, ctx->d_dna, ctx->d_off, ctx->n, ctx->L, ctx->W, ctx->S, rec, ctx->d_reads, ctx->d_lens);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->st));
+  ctx->stage = ST_LOADED;
+  return 0;
+}
+
+// walks the record stream once on the host: validates it and decides whether
+// every read has len == max_readlen (then no offset array is needed).
+static int scan_records(const uint8_t *dna, size_t nbytes, uint32_t n, int L, bool &uniform,
+                        std::vector<uint64_t> &off) {
+  uniform = true;
+  off.resize(n);
+  size_t p = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (p + 2 > nbytes) return fail(SPRING_REORDER_E_IO, "record stream ends inside read %u", i);
+    uint32_t len = (uint32_t)dna[p] | ((uint32_t)dna[p + 1] << 8);
+    if ((int)len > L) return fail(SPRING_REORDER_E_ARG, "read %u has length %u > max_readlen %d", i, len, L);
+    if ((int)len != L) uniform = false;
+    off[i] = p;
+    p += 2 + (len + 3) / 4;
+    if (p > nbytes) return fail(SPRING_REORDER_E_IO, "record stream ends inside read %u", i);
+  }
+  return 0;
+}
+
+int spring_reorder_load_dna(spring_reorder_ctx *ctx, const uint8_t *dna, size_t nbytes, uint32_t n,
+                            uint32_t max_readlen) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_dna: context already loaded");
+  if (n && !dna) return fail(SPRING_REORDER_E_ARG, "dna is NULL");
+  HIPCHK(hipSetDevice(ctx->dev));
+  int r = setup_geometry(ctx, n, max_readlen);
+  if (r) return r;
+  std::vector<uint64_t> off;
+  r = scan_records(dna, nbytes, n, ctx->L, ctx->uniform, off);
+  if (r) return r;
+  ctx->dna_bytes = nbytes;
+  DMALLOC(ctx->d_dna, nbytes + 16);
+  if (nbytes) HIPCHK(hipMemcpyAsync(ctx->d_dna, dna, nbytes, hipMemcpyHostToDevice, ctx->st));
+  if (!ctx->uniform) {
+    DMALLOC(ctx->d_off, (size_t)n * sizeof(uint64_t));
+    HIPCHK(hipMemcpyAsync(ctx->d_off, off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->st));
+  }
+  r = unpack_on_device(ctx);
+  if (r) return r;
+  HIPCHK(hipStreamSynchronize(ctx->st));  // `off` (host) must outlive the copy
+  return 0;
+}
+
+int spring_reorder_load_dna_device(spring_reorder_ctx *ctx, const void *d_dna, size_t nbytes, uint32_t n,
+                                   uint32_t max_readlen, int32_t fixed_len) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_dna_device: context already loaded");
+  HIPCHK(hipSetDevice(ctx->dev));
+  int r = setup_geometry(ctx, n, max_readlen);
+  if (r) return r;
+  if (fixed_len) {
+    const size_t rec = 2u + (max_readlen + 3u) / 4u;
+    if (nbytes < rec * n) return fail(SPRING_REORDER_E_ARG, "device stream too short for %u fixed records", n);
+    ctx->uniform = true;
+    ctx->d_dna = (uint8_t *)d_dna;
+    ctx->dna_borrowed = true;
+    ctx->dna_bytes = nbytes;
+    return unpack_on_device(ctx);
+  }
+  // variable length: record starts are sequentially dependent -> walk a host copy
+  std::vector<uint8_t> h(nbytes);
+  if (nbytes) HIPCHK(hipMemcpy(h.data(), d_dna, nbytes, hipMemcpyDeviceToHost));
+  return spring_reorder_load_dna(ctx, h.data(), nbytes, n, max_readlen);
+}
+
+size_t spring_synth_dna_bytes(uint32_t n, uint32_t L) { return (size_t)n * (2u + (L + 3u) / 4u); }
+
+int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm) {
+  if (L == 0 || L > (uint32_t)MAX_READ_LEN || G < L) return fail(SPRING_REORDER_E_ARG, "bad synth geometry");
+  const uint32_t rec = 2u + (L + 3u) / 4u, thr = syn_err_thr24(err_ppm);
+  for (uint64_t i = 0; i < n; i++) {
+    uint8_t *o = dst + i * rec;
+    uint64_t pos; uint32_t rc;
+    syn_read_params(seed, G, L, i, &pos, &rc);
+    o[0] = (uint8_t)(L & 0xff); o[1] = (uint8_t)(L >> 8);
+    for (uint32_t b = 0; b < (L + 3) / 4; b++) {
+      uint32_t v = 0;
+      for (uint32_t q = 0; q < 4; q++) {
+        uint32_t j = 4 * b + q;
+        if (j < L) v |= syn_nat_to_spring(syn_read_base(seed, G, L, thr, i, j, pos, rc)) << (2 * q);
+      }
+      o[2 + b] = (uint8_t)v;
+    }
+  }
+  return 0;
+}
+
+int spring_reorder_load_synth(spring_reorder_ctx *ctx, uint32_t n, uint32_t L, uint64_t G, uint64_t seed,
+                              uint32_t err_ppm) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_synth: context already loaded");
+  if (L == 0 || L > (uint32_t)MAX_READ_LEN || G < L) return fail(SPRING_REORDER_E_ARG, "bad synth geometry");
+  HIPCHK(hipSetDevice(ctx->dev));
+  int r = setup_geometry(ctx, n, L);
+  if (r) return r;
+  ctx->uniform = true;
+  ctx->dna_bytes = spring_synth_dna_bytes(n, L);
+  DMALLOC(ctx->d_dna, ctx->dna_bytes + 16);
+  launch_synth(ctx->st, ctx->d_dna, n, L, G, seed, syn_err_thr24(err_ppm));
+  HIPCHK(hipGetLastError());
+  return unpack_on_device(ctx);
+}
+
+int spring_reorder_download_dna(spring_reorder_ctx *ctx, uint8_t *dst, size_t cap) {
+  if (!ctx || ctx->stage < ST_LOADED) return fail(SPRING_REORDER_E_STATE, "download_dna: nothing loaded");
+  if (cap < ctx->dna_bytes) return fail(SPRING_REORDER_E_ARG, "buffer too small");
+  HIPCHK(hipSetDevice(ctx->dev));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (ctx->dna_bytes) HIPCHK(hipMemcpy(dst, ctx->d_dna, ctx->dna_bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int spring_reorder_download_reads(spring_reorder_ctx *ctx, uint64_t *limbs, uint16_t *len) {
+  if (!ctx || ctx->stage < ST_LOADED) return fail(SPRING_REORDER_E_STATE, "download_reads: nothing loaded");
+  HIPCHK(hipSetDevice(ctx->dev));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (!ctx->n) return 0;
+  if (limbs)
+    HIPCHK(hipMemcpy2D(limbs, (size_t)ctx->W * 8, ctx->d_reads, (size_t)ctx->S * 8, (size_t)ctx->W * 8, ctx->n,
+                       hipMemcpyDeviceToHost));
+  if (len) HIPCHK(hipMemcpy(len, ctx->d_lens, (size_t)ctx->n * 2, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ------------------------------------------------------------ dictionaries
+static uint64_t pow2ceil(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_LOADED) return fail(SPRING_REORDER_E_STATE, "build_dict: load reads first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  const uint32_t n = ctx->n;
+  HIPCHK(hipEventRecord(ctx->ev[2], st));
+  for (int l = 0; l < 2; l++) {
+    DictDev &d = ctx->dict[l];
+    uint32_t m = 0;
+    uint32_t *d_slot = nullptr, *d_flag = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    if (n) {
+      if (ctx->uniform) {
+        m = ctx->L > d.end ? n : 0;
+      } else {  // reads with len <= end are not in this dictionary (bitset_util.h:98-105)
+        DMALLOC(d_flag, (size_t)n * 4);
+        DMALLOC(d_slot, (size_t)n * 4);
+        launch_flag_in_dict(st, ctx->d_lens, n, d.end, d_flag);
+        HIPCHK(excl_scan_u32(st, nullptr, tmp_bytes, d_flag, d_slot, n));
+        DMALLOC(d_tmp, tmp_bytes);
+        HIPCHK(excl_scan_u32(st, d_tmp, tmp_bytes, d_flag, d_slot, n));
+        uint32_t last_slot = 0, last_flag = 0;
+        HIPCHK(hipMemcpyAsync(&last_slot, d_slot + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&last_flag, d_flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        m = last_slot + last_flag;
+        ctx->dfree(d_tmp); d_tmp = nullptr;
+      }
+    }
+    d.numreads = m;
+    d.numkeys = 0;
+    if (m == 0) {
+      d.bmask = 0;
+      DMALLOC(d.tab, 64);
+      HIPCHK(hipMemsetAsync(d.tab, 0, 64, st));
+      DMALLOC(d.ids, 16);
+      if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
+      continue;
+    }
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    uint32_t *v_in = nullptr, *cnt = nullptr, *ustart = nullptr, *d_nruns = nullptr;
+    DMALLOC(k_in, (size_t)m * 8);
+    DMALLOC(k_out, (size_t)m * 8);
+    DMALLOC(v_in, (size_t)m * 4);
+    DMALLOC(d.ids, (size_t)m * 4);
+    launch_keys(st, ctx->d_reads, ctx->d_lens, ctx->uniform ? nullptr : d_slot, n, ctx->S, d.start, d.end, k_in, v_in);
+    HIPCHK(hipGetLastError());
+    const unsigned end_bit = (unsigned)(2 * (d.end - d.start + 1));
+    // stable LSD radix sort: equal keys keep ascending read id (bitset_util.h:192-210)
+    tmp_bytes = 0;
+    HIPCHK(sort_pairs(st, nullptr, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
+    DMALLOC(d_tmp, tmp_bytes);
+    HIPCHK(sort_pairs(st, d_tmp, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
+    ctx->dfree(d_tmp); d_tmp = nullptr;
+    // unique keys + run lengths (bitset_util.h:122-127), reuse k_in for the unique keys
+    DMALLOC(cnt, (size_t)m * 4);
+    DMALLOC(d_nruns, 16);
+    tmp_bytes = 0;
+    HIPCHK(rle(st, nullptr, tmp_bytes, k_out, m, k_in, cnt, d_nruns));
+    DMALLOC(d_tmp, tmp_bytes);
+    HIPCHK(rle(st, d_tmp, tmp_bytes, k_out, m, k_in, cnt, d_nruns));
+    uint32_t numkeys = 0;
+    HIPCHK(hipMemcpyAsync(&numkeys, d_nruns, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->dfree(d_tmp); d_tmp = nullptr;
+    d.numkeys = numkeys;
+    DMALLOC(ustart, (size_t)numkeys * 4);
+    tmp_bytes = 0;
+    HIPCHK(excl_scan_u32(st, nullptr, tmp_bytes, cnt, ustart, numkeys));
+    DMALLOC(d_tmp, tmp_bytes);
+    HIPCHK(excl_scan_u32(st, d_tmp, tmp_bytes, cnt, ustart, numkeys));
+    // exact hash table, 4-slot 64-byte buckets, load <= 0.4
+    const uint64_t nb = pow2ceil(std::max<uint64_t>(1, ((uint64_t)numkeys * 10 + 15) / 16));
+    d.bmask = nb - 1;
+    DMALLOC(d.tab, nb * 64);
+    HIPCHK(hipMemsetAsync(d.tab, 0, nb * 64, st));
+    launch_tab_insert(st, k_in, ustart, cnt, numkeys, d.tab, d.bmask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->dfree(d_tmp); ctx->dfree(k_in); ctx->dfree(k_out); ctx->dfree(v_in); ctx->dfree(cnt);
+    ctx->dfree(ustart); ctx->dfree(d_nruns);
+    if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
+  }
+  HIPCHK(hipEventRecord(ctx->ev[3], st));
+  ctx->stage = ST_DICT;
+  return 0;
+}
+
+int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uint64_t *keys, uint32_t nkeys,
+                               uint32_t *bin_size, uint32_t *bin_ids, size_t ids_cap) {
+  if (!ctx || ctx->stage < ST_DICT) return fail(SPRING_REORDER_E_STATE, "dict_lookup: build_dict first");
+  if (which < 0 || which > 1) return fail(SPRING_REORDER_E_ARG, "which must be 0 or 1");
+  HIPCHK(hipSetDevice(ctx->dev));
+  DictDev &d = ctx->dict[which];
+  uint64_t *dk = nullptr;
+  uint32_t *ds = nullptr, *dc = nullptr;
+  DMALLOC(dk, (size_t)nkeys * 8);
+  DMALLOC(ds, (size_t)nkeys * 4);
+  DMALLOC(dc, (size_t)nkeys * 4);
+  std::vector<uint32_t> hs(nkeys), hc(nkeys), hids(d.numreads);
+  if (nkeys) {
+    HIPCHK(hipMemcpyAsync(dk, keys, (size_t)nkeys * 8, hipMemcpyHostToDevice, ctx->st));
+    launch_dict_lookup(ctx->st, d.tab, d.bmask, dk, nkeys, ds, dc);
+    HIPCHK(hipMemcpyAsync(hs.data(), ds, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(hc.data(), dc, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
+  }
+  if (d.numreads) HIPCHK(hipMemcpyAsync(hids.data(), d.ids, (size_t)d.numreads * 4, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->dfree(dk); ctx->dfree(ds); ctx->dfree(dc);
+  size_t o = 0;
+  for (uint32_t i = 0; i < nkeys; i++) {
+    bin_size[i] = hc[i];
+    if (hc[i] == 0xffffffffu) continue;
+    if (o + hc[i] > ids_cap) return fail(SPRING_REORDER_E_ARG, "bin_ids too small");
+    memcpy(bin_ids + o, hids.data() + hs[i], (size_t)hc[i] * 4);
+    o += hc[i];
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ chains
+static uint32_t auto_chains(uint32_t n) {
+  uint64_t k = n >> 10;  // ~1000 reads per chain
+  if (k < 1) k = 1;
+  if (k > 16384) k = 16384;
+  return (uint32_t)k;
+}
+
+int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "run_chains: build_dict first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  const uint32_t n = ctx->n;
+  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n);
+  ctx->K = K;
+  DevParams &P = ctx->P;
+  P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
+  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2;  // reorder.h:750
+  P.uniform_len = ctx->uniform ? 1 : 0;
+  P.force_literal = ctx->o.force_literal_update ? 1 : 0;
+  for (int l = 0; l < 2; l++) {
+    P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
+    P.tab[l] = ctx->dict[l].tab; P.bmask[l] = ctx->dict[l].bmask; P.ids[l] = ctx->dict[l].ids;
+  }
+  const uint64_t nwords = ((uint64_t)n + 63) / 64;
+  const size_t nn = std::max<uint32_t>(n, 1);
+  DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
+  DMALLOC(P.resv, nn * 4);
+  DMALLOC(P.needy, ((size_t)K + 31) / 32 * 4);
+  DMALLOC(P.glob, sizeof(Globals));
+  DMALLOC(P.chains, (size_t)K * sizeof(Chain));
+  DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
+  DMALLOC(P.e_order, nn * 4); DMALLOC(P.e_rc, nn); DMALLOC(P.e_flag, nn); DMALLOC(P.e_pos, nn * 8);
+  DMALLOC(P.e_len, nn * 2); DMALLOC(P.e_chain, nn * 4); DMALLOC(P.e_seq, nn * 4);
+  DMALLOC(P.s_order, nn * 4); DMALLOC(P.s_chain, nn * 4); DMALLOC(P.s_seq, nn * 4);
+  P.K = K;
+
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  launch_init_taken(st, P.taken, nwords, n);
+  launch_fill_u32(st, P.resv, n, 0xffffffffu);
+  HIPCHK(hipMemsetAsync(P.needy, 0, ((size_t)K + 31) / 32 * 4, st));
+  HIPCHK(hipMemsetAsync(P.chains, 0, (size_t)K * sizeof(Chain), st));
+  Globals g;
+  memset(&g, 0, sizeof(g));
+  g.cursor = (long long)n - 1;
+  HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
+  launch_init_chains(st, P);
+  HIPCHK(hipGetLastError());
+
+  const bool stats = ctx->o.collect_stats != 0;
+  const bool timed = ctx->o.time_search != 0;
+  int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : (K >= 256 ? 16 : 256);
+  std::vector<hipEvent_t> tev;
+  if (timed) {
+    tev.resize(2 * (size_t)R);
+    for (auto &e : tev) HIPCHK(hipEventCreate(&e));
+  }
+  uint32_t *h_alive = nullptr;
+  HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
+  uint64_t rounds = 0;
+  double ms_search = 0;
+  uint64_t launches = 0;
+  HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  while (*h_alive) {
+    for (int r = 0; r < R; r++) {
+      if (timed) HIPCHK(hipEventRecord(tev[2 * r], st));
+      launch_search(st, P, stats);
+      if (timed) HIPCHK(hipEventRecord(tev[2 * r + 1], st));
+      launch_apply(st, P);
+    }
+    rounds += R;
+    HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (timed) {
+      for (int r = 0; r < R; r++) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, tev[2 * r], tev[2 * r + 1]));
+        ms_search += ms;
+      }
+      launches += R;
+    }
+  }
+  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  HIPCHK(hipStreamSynchronize(st));
+  (void)hipHostFree(h_alive);
+  for (auto &e : tev) (void)hipEventDestroy(e);
+  ctx->stats.rounds = rounds;
+  ctx->stats.ms_search_kernel = ms_search;
+  ctx->stats.search_launches = launches;
+  ctx->stage = ST_CHAINS;
+  return 0;
+}
+
+int spring_reorder_finalize(spring_reorder_ctx *ctx) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_CHAINS) return fail(SPRING_REORDER_E_STATE, "finalize: run_chains first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  DevParams &P = ctx->P;
+  const uint32_t K = ctx->K;
+  const int T = ctx->o.num_thr;
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  std::vector<Chain> hc(K);
+  Globals g;
+  HIPCHK(hipMemcpyAsync(hc.data(), P.chains, (size_t)K * sizeof(Chain), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&g, P.glob, sizeof(g), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  ctx->nrec = g.nrec;
+  ctx->nsing = g.nsing;
+  // chain i -> tid i % num_thr, chains ascending inside a tid (each per-tid file is a
+  // sequence of whole contigs, which is all the encoder needs: encoder.h:215-363)
+  std::vector<uint64_t> off_m(K), off_s(K);
+  ctx->tid_off.assign(T + 1, 0);
+  ctx->tid_off_s.assign(T + 1, 0);
+  uint64_t am = 0, as = 0;
+  spring_reorder_stats &s = ctx->stats;
+  s.unmatched = s.probes = s.keyok = s.cands = s.iterations = s.lost = 0;
+  for (int t = 0; t < T; t++) {
+    ctx->tid_off[t] = am;
+    ctx->tid_off_s[t] = as;
+    for (uint32_t i = (uint32_t)t; i < K; i += (uint32_t)T) {
+      off_m[i] = am; off_s[i] = as;
+      am += hc[i].n_emit; as += hc[i].n_single;
+    }
+  }
+  ctx->tid_off[T] = am;
+  ctx->tid_off_s[T] = as;
+  for (uint32_t i = 0; i < K; i++) {
+    s.unmatched += hc[i].unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
+    s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost;
+  }
+  if (am != g.nrec || as != g.nsing || am + as != ctx->n)
+    return fail(SPRING_REORDER_E_STATE, "internal: emission counts do not add up (%llu+%llu vs n=%u, nrec=%u nsing=%u)",
+                (unsigned long long)am, (unsigned long long)as, ctx->n, g.nrec, g.nsing);
+  s.n_reads = ctx->n; s.n_matched = am; s.n_single = as;
+  s.hits = am - (s.unmatched - as);  // matched records minus contig-start records
+  const size_t nm = std::max<uint64_t>(am, 1), ns = std::max<uint64_t>(as, 1);
+  DMALLOC(P.f_order, nm * 4); DMALLOC(P.f_rc, nm); DMALLOC(P.f_flag, nm); DMALLOC(P.f_pos, nm * 8);
+  DMALLOC(P.f_len, nm * 2); DMALLOC(P.f_order_s, ns * 4);
+  uint64_t *d_off_m = nullptr, *d_off_s = nullptr;
+  DMALLOC(d_off_m, (size_t)K * 8);
+  DMALLOC(d_off_s, (size_t)K * 8);
+  HIPCHK(hipMemcpyAsync(d_off_m, off_m.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_off_s, off_s.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
+  launch_scatter(st, P, g.nrec, g.nsing, d_off_m, d_off_s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  HIPCHK(hipStreamSynchronize(st));
+  ctx->dfree(d_off_m); ctx->dfree(d_off_s);
+  // the append-order buffers are no longer needed
+  ctx->dfree(P.e_order); ctx->dfree(P.e_rc); ctx->dfree(P.e_flag); ctx->dfree(P.e_pos); ctx->dfree(P.e_len);
+  ctx->dfree(P.e_chain); ctx->dfree(P.e_seq); ctx->dfree(P.s_order); ctx->dfree(P.s_chain); ctx->dfree(P.s_seq);
+  P.e_order = nullptr;
+  ctx->stage = ST_FINAL;
+  return 0;
+}
+
+int spring_reorder_get_stats(spring_reorder_ctx *ctx, spring_reorder_stats *out) {
+  if (!ctx || !out) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  HIPCHK(hipSetDevice(ctx->dev));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  spring_reorder_stats &s = ctx->stats;
+  auto el = [&](int a, int b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0;
+    return (double)ms;
+  };
+  if (ctx->stage >= ST_LOADED) s.ms_unpack = el(0, 1);
+  if (ctx->stage >= ST_DICT) s.ms_dict = el(2, 3);
+  if (ctx->stage >= ST_CHAINS) s.ms_chains = el(4, 5);
+  if (ctx->stage >= ST_FINAL) s.ms_finalize = el(6, 7);
+  s.ms_total = s.ms_unpack + s.ms_dict + s.ms_chains + s.ms_finalize;
+  for (int l = 0; l < 2; l++) { s.numkeys[l] = ctx->dict[l].numkeys; s.dict_numreads[l] = ctx->dict[l].numreads; }
+  s.n_reads = ctx->n;
+  s.device_bytes = ctx->dev_bytes;
+  *out = s;
+  return 0;
+}
+
+int spring_reorder_download(spring_reorder_ctx *ctx, uint32_t *order, char *rc, char *flag, int64_t *pos,
+                            uint16_t *rlen, uint32_t *order_s, uint64_t *tid_off, uint64_t *tid_off_s) {
+  if (!ctx || ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "download: finalize first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  DevParams &P = ctx->P;
+  const size_t nm = ctx->nrec, ns = ctx->nsing;
+  if (nm) {
+    if (order) HIPCHK(hipMemcpy(order, P.f_order, nm * 4, hipMemcpyDeviceToHost));
+    if (rc) HIPCHK(hipMemcpy(rc, P.f_rc, nm, hipMemcpyDeviceToHost));
+    if (flag) HIPCHK(hipMemcpy(flag, P.f_flag, nm, hipMemcpyDeviceToHost));
+    if (pos) HIPCHK(hipMemcpy(pos, P.f_pos, nm * 8, hipMemcpyDeviceToHost));
+    if (rlen) HIPCHK(hipMemcpy(rlen, P.f_len, nm * 2, hipMemcpyDeviceToHost));
+  }
+  if (ns && order_s) HIPCHK(hipMemcpy(order_s, P.f_order_s, ns * 4, hipMemcpyDeviceToHost));
+  if (tid_off) memcpy(tid_off, ctx->tid_off.data(), ctx->tid_off.size() * 8);
+  if (tid_off_s) memcpy(tid_off_s, ctx->tid_off_s.data(), ctx->tid_off_s.size() * 8);
+  return 0;
+}
+
+int spring_reorder_emit_dna(spring_reorder_ctx *ctx, int32_t tid, uint8_t *dst, size_t cap, size_t *nbytes) {
+  if (!ctx || ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "emit_dna: finalize first");
+  if (tid < -1 || tid >= ctx->o.num_thr) return fail(SPRING_REORDER_E_ARG, "tid out of range");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  DevParams &P = ctx->P;
+  const uint32_t *order;
+  const char *rc;
+  uint64_t cnt;
+  if (tid < 0) { order = P.f_order_s; rc = nullptr; cnt = ctx->nsing; }
+  else {
+    const uint64_t a = ctx->tid_off[tid], b = ctx->tid_off[tid + 1];
+    order = P.f_order + a; rc = P.f_rc + a; cnt = b - a;
+  }
+  const uint32_t rec = 2u + ((uint32_t)ctx->L + 3u) / 4u;
+  uint64_t total = 0;
+  uint64_t *d_off = nullptr;
+  uint32_t *d_sz = nullptr;
+  void *d_tmp = nullptr;
+  if (ctx->uniform) total = cnt * rec;
+  else if (cnt) {
+    DMALLOC(d_sz, cnt * 4);
+    DMALLOC(d_off, cnt * 8);
+    launch_rec_size(st, order, ctx->d_lens, cnt, d_sz);
+    size_t tb = 0;
+    HIPCHK(excl_scan_u32_to_u64(st, nullptr, tb, d_sz, d_off, cnt));
+    DMALLOC(d_tmp, tb);
+    HIPCHK(excl_scan_u32_to_u64(st, d_tmp, tb, d_sz, d_off, cnt));
+    uint64_t last_off = 0;
+    uint32_t last_sz = 0;
+    HIPCHK(hipMemcpyAsync(&last_off, d_off + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last_sz, d_sz + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    total = last_off + last_sz;
+  }
+  if (nbytes) *nbytes = total;
+  int ret = 0;
+  if (dst && total) {
+    if (cap < total) ret = fail(SPRING_REORDER_E_ARG, "emit_dna: buffer too small (%zu < %llu)", cap, (unsigned long long)total);
+    else {
+      uint8_t *d_dst = nullptr;
+      DMALLOC(d_dst, total);
+      launch_emit_dna(st, ctx->d_reads, ctx->d_lens, ctx->S, order, rc, cnt, d_off, rec, d_dst);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(dst, d_dst, total, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      ctx->dfree(d_dst);
+    }
+  }
+  ctx->dfree(d_sz); ctx->dfree(d_off); ctx->dfree(d_tmp);
+  return ret;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// spring_amd/csrc/synth_common.h
+//
+// Counter-based synthetic read generator: uniform random
+// genome, reads at uniform start positions, i.i.d. substitutions, 50 % reverse
+// complemented, no N, no indels.  Every value is a pure function of
+// (seed, index), so the host loop and the HIP kernel emit identical bytes and a
+// 100 M-read set never has to exist on the host.
+#ifndef SPRING_SYNTH_COMMON_H_
+#define SPRING_SYNTH_COMMON_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SYN_HD __host__ __device__ static inline
+#else
+#define SYN_HD static inline
+#endif
+
+SYN_HD uint64_t syn_sm64(uint64_t x) {  // splitmix64 finalizer
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// genome base (natural code A0 C1 G2 T3) at position p: 32 bases per hashed word
+SYN_HD uint32_t syn_genome_base(uint64_t seed, uint64_t p) {
+  uint64_t w = syn_sm64(seed ^ (0xA5A5A5A5ull + (p >> 5) * 0x9E3779B97F4A7C15ull));
+  return (uint32_t)(w >> (2 * (p & 31))) & 3u;
+}
+
+SYN_HD uint64_t syn_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// base j (natural code) of read i, after substitution and strand flip
+SYN_HD uint32_t syn_read_base(uint64_t seed, uint64_t G, uint32_t L, uint32_t err_thr24, uint64_t i,
+                              uint32_t j, uint64_t pos, uint32_t rc) {
+  uint32_t jj = rc ? (L - 1 - j) : j;  // position on the forward strand
+  uint32_t b = syn_genome_base(seed, pos + jj);
+  uint64_t e = syn_sm64((seed * 0x2545F4914F6CDD1Dull) ^ (i * 512ull + (jj >> 1)) ^ 0x5EEDull);
+  uint32_t h = (uint32_t)(e >> (32 * (jj & 1)));
+  if ((h & 0xFFFFFFu) < err_thr24) b = (b + 1u + ((h >> 24) % 3u)) & 3u;
+  return rc ? 3u - b : b;
+}
+
+SYN_HD void syn_read_params(uint64_t seed, uint64_t G, uint32_t L, uint64_t i, uint64_t *pos, uint32_t *rc) {
+  uint64_t h = syn_sm64(seed + 0x1234567ull + i * 0xD1342543DE82EF95ull);
+  *pos = syn_mulhi64(h, G - L + 1);
+  *rc = (uint32_t)(syn_sm64(h ^ 0xC0FFEEull) & 1u);
+}
+
+// natural code (A0 C1 G2 T3) -> SPRING 2-bit code (A0 G1 C2 T3, util.cpp:270-274)
+SYN_HD uint32_t syn_nat_to_spring(uint32_t b) { return (b == 1u) ? 2u : (b == 2u) ? 1u : b; }
+
+SYN_HD uint32_t syn_err_thr24(uint32_t err_ppm) { return (uint32_t)(((uint64_t)err_ppm << 24) / 1000000ull); }
+
+#endif

@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's stage interface.
+
+reference                                   here
+---------                                   ----
+spring::call_reorder(temp_dir, cp)          call_reorder(temp_dir, cp)         (file contract)
+reorder_main<N>: readDnaFile ->             ReorderStage.load_dna / load_synth
+  constructdictionary -> reorder ->         .build_dict() .run_chains()
+  writetofile                               .finalize() .streams() .emit_dna(tid)
+(call_template_functions.cpp:9-63, reorder.h:732-786)
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+
+class ReorderError(RuntimeError):
+    """Raised where the reference throws std::runtime_error (call_template_functions.cpp:60)."""
+
+
+@dataclass
+class ReorderOpts:
+    device: int = -1
+    num_chains: int = 0       # K greedy chains (= reference threads); 1 == `-t 1` byte for byte; 0 = auto
+    num_thr: int = 1          # number of per-tid output sets (cp.num_thr)
+    collect_stats: bool = False
+    time_search: bool = False
+    force_literal_update: bool = False
+    rounds_per_sync: int = 0
+
+    def to_c(self):
+        o = _lib.Opts()
+        _lib.lib().spring_reorder_default_opts(C.byref(o))
+        o.device, o.num_chains, o.num_thr = self.device, self.num_chains, self.num_thr
+        o.collect_stats, o.time_search = int(self.collect_stats), int(self.time_search)
+        o.force_literal_update, o.rounds_per_sync = int(self.force_literal_update), self.rounds_per_sync
+        return o
+
+
+def _chk(rc):
+    if rc != 0:
+        raise ReorderError("%s (code %d)" % (_lib.lib().spring_reorder_last_error().decode(), rc))
+
+
+class ReorderStage:
+    """One run of the stage on in-memory buffers; device memory is freed by close()."""
+
+    def __init__(self, opts: ReorderOpts = None):
+        self.opts = opts or ReorderOpts()
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        _chk(self._L.spring_reorder_create(C.byref(self._h), C.byref(self.opts.to_c())))
+        self.n = 0
+        self.max_readlen = 0
+
+    def close(self):
+        if self._h:
+            self._L.spring_reorder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # readDnaFile (reorder.h:222-244)
+    def load_dna(self, dna: bytes, n: int, max_readlen: int):
+        buf = np.frombuffer(dna, dtype=np.uint8)
+        _chk(self._L.spring_reorder_load_dna(self._h, buf.ctypes.data if len(buf) else None, len(buf), n,
+                                             max_readlen))
+        self.n, self.max_readlen = n, max_readlen
+
+    def load_dna_device(self, dptr: int, nbytes: int, n: int, max_readlen: int, fixed_len: bool):
+        _chk(self._L.spring_reorder_load_dna_device(self._h, C.c_void_p(dptr), nbytes, n, max_readlen,
+                                                    int(fixed_len)))
+        self.n, self.max_readlen = n, max_readlen
+
+    def load_synth(self, n, L, G, seed, err_ppm=10000):
+        _chk(self._L.spring_reorder_load_synth(self._h, n, L, G, seed, err_ppm))
+        self.n, self.max_readlen = n, L
+
+    def build_dict(self):  # constructdictionary (bitset_util.h:74-221)
+        _chk(self._L.spring_reorder_build_dict(self._h))
+
+    def run_chains(self):  # reorder() (reorder.h:320-641)
+        _chk(self._L.spring_reorder_run_chains(self._h))
+
+    def finalize(self):
+        _chk(self._L.spring_reorder_finalize(self._h))
+
+    def run(self):
+        self.build_dict()
+        self.run_chains()
+        self.finalize()
+        return self
+
+    def stats(self):
+        s = _lib.Stats()
+        _chk(self._L.spring_reorder_get_stats(self._h, C.byref(s)))
+        return s.asdict()
+
+    def streams(self):
+        """-> dict(order, rc, flag, pos, rlen, order_s, tid_off, tid_off_s): the contents of
+        read_order.bin.<tid>, read_rev.txt.<tid>, tempflag.txt.<tid>, temppos.txt.<tid>,
+        read_lengths.bin.<tid> (concatenated in tid order) and read_order.bin.singleton."""
+        st = self.stats()
+        nm, ns, T = st["n_matched"], st["n_single"], self.opts.num_thr
+        out = dict(order=np.zeros(max(nm, 1), np.uint32), rc=np.zeros(max(nm, 1), np.uint8),
+                   flag=np.zeros(max(nm, 1), np.uint8), pos=np.zeros(max(nm, 1), np.int64),
+                   rlen=np.zeros(max(nm, 1), np.uint16), order_s=np.zeros(max(ns, 1), np.uint32),
+                   tid_off=np.zeros(T + 1, np.uint64), tid_off_s=np.zeros(T + 1, np.uint64))
+        _chk(self._L.spring_reorder_download(self._h, *[out[k].ctypes.data for k in (
+            "order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s")]))
+        for k in ("order", "rc", "flag", "pos", "rlen"):
+            out[k] = out[k][:nm]
+        out["order_s"] = out["order_s"][:ns]
+        out["stats"] = st
+        return out
+
+    def emit_dna(self, tid: int) -> bytes:
+        """temp.dna.<tid> (tid >= 0) / temp.dna.singleton (tid = -1), built on the device."""
+        nb = C.c_size_t()
+        _chk(self._L.spring_reorder_emit_dna(self._h, tid, None, 0, C.byref(nb)))
+        buf = np.zeros(max(nb.value, 1), np.uint8)
+        _chk(self._L.spring_reorder_emit_dna(self._h, tid, buf.ctypes.data, nb.value, C.byref(nb)))
+        return buf[:nb.value].tobytes()
+
+    # test hooks
+    def dict_lookup(self, which, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        sizes = np.zeros(max(len(keys), 1), np.uint32)
+        ids = np.zeros(max(self.n, 1) * 2, np.uint32)
+        _chk(self._L.spring_reorder_dict_lookup(self._h, which, keys.ctypes.data, len(keys), sizes.ctypes.data,
+                                                ids.ctypes.data, len(ids)))
+        return sizes[:len(keys)], ids
+
+    def download_reads(self):
+        W = (2 * self.max_readlen - 1) // 64 + 1
+        limbs = np.zeros((max(self.n, 1), W), np.uint64)
+        ln = np.zeros(max(self.n, 1), np.uint16)
+        _chk(self._L.spring_reorder_download_reads(self._h, limbs.ctypes.data, ln.ctypes.data))
+        return limbs[:self.n], ln[:self.n]
+
+    def download_dna(self) -> bytes:
+        nb = self._L.spring_synth_dna_bytes(self.n, self.max_readlen)
+        buf = np.zeros(max(nb, 1), np.uint8)
+        _chk(self._L.spring_reorder_download_dna(self._h, buf.ctypes.data, nb))
+        return buf[:nb].tobytes()
+
+
+def reorder_dna(dna: bytes, n: int, max_readlen: int, opts: ReorderOpts = None):
+    """Whole stage on a host .dna record stream -> streams() dict."""
+    with ReorderStage(opts) as s:
+        s.load_dna(dna, n, max_readlen)
+        return s.run().streams()
+
+
+def synth_dna_host(n, L, G, seed, err_ppm=10000) -> bytes:
+    """Host version of the counter-based synthetic generator (identical bytes to load_synth)."""
+    L_ = _lib.lib()
+    nb = L_.spring_synth_dna_bytes(n, L)
+    buf = np.zeros(max(nb, 1), np.uint8)
+    _chk(L_.spring_synth_dna_host(buf.ctypes.data, n, L, G, seed, err_ppm))
+    return buf[:nb].tobytes()
+
+
+class CompressionParams:
+    """The compression_params fields the stage reads (reference util.h:30-51, reorder.h:747-763)."""
+
+    def __init__(self, max_readlen, num_reads_clean, num_thr=1, paired_end=False):
+        self.max_readlen = max_readlen
+        self.num_reads_clean = list(num_reads_clean) + [0] * (2 - len(num_reads_clean))
+        self.num_thr = num_thr
+        self.paired_end = paired_end
+
+
+def call_reorder(temp_dir: str, cp: CompressionParams, opts: ReorderOpts = None):
+    """spring::call_reorder(temp_dir, cp): consumes temp_dir/input_clean_{1,2}.dna, writes the
+    per-tid + singleton files of reorder.h:355-368,:643-730.  Raises ReorderError on failure."""
+    bitset_size = (2 * cp.max_readlen - 1) // 64 * 64 + 64
+    if cp.max_readlen <= 0 or bitset_size > 1024:
+        raise ReorderError("Wrong bitset size.")
+    o = (opts or ReorderOpts(num_thr=cp.num_thr)).to_c()
+    _chk(_lib.lib().spring_reorder_run(temp_dir.encode(), cp.max_readlen, cp.num_thr, int(cp.paired_end),
+                                       cp.num_reads_clean[0], cp.num_reads_clean[1], C.byref(o)))

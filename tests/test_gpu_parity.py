@@ -1,0 +1,211 @@
+"""GPU parity tests (run with `pytest -m gpu` on an MI355X): the HIP path, called through the
+C ABI (spring_amd._lib -> libspring_reorder_hip.so), against the CPU oracle on identical inputs.
+Bar: bit-exact (integer / byte / index work)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import readsets as rs
+from helpers import GOLDEN, KEYS, SMALL_SETS, check_invariants, named_set
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _sa():
+    import spring_amd
+    return spring_amd
+
+
+def _gpu(name, K, T=1, **kw):
+    sa = _sa()
+    dna, n, L = named_set(name)
+    return sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=K, num_thr=T, **kw))
+
+
+def _same(a, b, what):
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), (what, k, len(a[k]), len(b[k]))
+
+
+@pytest.mark.parametrize("name", ["test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k",
+                                  "var_short", "heavy", "one", "empty"])
+def test_unpack_matches_readDnaFile(name):
+    sa = _sa()
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    with sa.ReorderStage() as s:
+        s.load_dna(dna, n, L)
+        limbs, lens = s.download_reads()
+    assert np.array_equal(limbs, read) and np.array_equal(lens, ln)
+
+
+@pytest.mark.parametrize("name", ["test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k",
+                                  "var_short", "heavy", "dups"])
+def test_dictionary_matches_constructdictionary(name):
+    sa = _sa()
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    with sa.ReorderStage() as s:
+        s.load_dna(dna, n, L)
+        s.build_dict()
+        st = s.stats()
+        for which in (0, 1):
+            keys, sp, ids = po.build_dict(read, ln, L, which)
+            assert st["numkeys"][which] == len(keys) and st["dict_numreads"][which] == len(ids)
+            absent = keys ^ np.uint64(0x3333)
+            absent = absent[~np.isin(absent, keys)]
+            sizes, gids = s.dict_lookup(which, np.concatenate([keys, absent]))
+            assert np.array_equal(sizes[:len(keys)], np.diff(sp).astype(np.uint32))
+            assert np.all(sizes[len(keys):] == 0xFFFFFFFF)
+            assert np.array_equal(gids[:len(ids)], ids)  # same ids, same in-bin order, bins in key order
+
+
+@pytest.mark.parametrize("name", SMALL_SETS)
+def test_k1_bit_exact_vs_serial_oracle(name):
+    """K = 1 must reproduce the reference's `-t 1` order byte for byte."""
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_serial(read, ln, L)
+    got = _gpu(name, 1, collect_stats=True)
+    _same(got, want, name)
+    for k in ("unmatched", "probes", "keyok", "cands", "hits", "iterations"):
+        assert got["stats"][k] == want["stats"][k], (name, k, got["stats"][k], want["stats"][k])
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k", "var_short", "heavy",
+                                  "repeat10k", "dups", "test_1+2"])
+@pytest.mark.parametrize("K,T", [(2, 1), (5, 2), (64, 8), (1000, 3)])
+def test_chains_bit_exact_vs_rounds_oracle(name, K, T):
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, T)
+    got = _gpu(name, K, T, collect_stats=True)
+    _same(got, want, (name, K, T))
+    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+    for k in ("unmatched", "probes", "keyok", "cands", "hits", "iterations", "lost"):
+        assert got["stats"][k] == want["stats"][k], (name, K, k, got["stats"][k], want["stats"][k])
+    check_invariants(got, read, ln, L, n)
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "var2k", "var_short", "syn2k_251"])
+def test_literal_and_parallel_consensus_paths_agree(name):
+    a = _gpu(name, 8, 2)
+    b = _gpu(name, 8, 2, force_literal_update=True)
+    _same(a, b, name)
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "var2k", "heavy"])
+def test_golden_fixtures(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = _gpu(name, 1)
+    for k in KEYS:
+        assert np.array_equal(got[k], g[k]), (name, k)
+    for K in (4, 64):
+        got = _gpu(name, K, 2)
+        for k in KEYS:
+            assert np.array_equal(got[k], g["K%d_%s" % (K, k)]), (name, K, k)
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "var2k", "test_1+2"])
+def test_emit_dna_matches_writetofile(name):
+    sa = _sa()
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    T = 3
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=16, num_thr=T)) as s:
+        s.load_dna(dna, n, L)
+        out = s.run().streams()
+        for t in range(T):
+            a, b = int(out["tid_off"][t]), int(out["tid_off"][t + 1])
+            assert s.emit_dna(t) == po.write_dna_stream(read, ln, L, out["order"][a:b], out["rc"][a:b])
+        assert s.emit_dna(-1) == po.write_dna_stream(read, ln, L, out["order_s"], None)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_call_reorder_file_contract(tmp_path, paired):
+    """spring::call_reorder drop-in: consumes input_clean_*.dna, writes every file encoder_main<> opens."""
+    sa = _sa()
+    from spring_amd.reorder import CompressionParams
+    if paired:
+        d1, n1, L1 = named_set("syn2k_100")
+        d2, n2, L2 = named_set("syn3k_64")
+        dna, n, L = d1 + d2, n1 + n2, max(L1, L2)
+        (tmp_path / "input_clean_1.dna").write_bytes(d1)
+        (tmp_path / "input_clean_2.dna").write_bytes(d2)
+        cp = CompressionParams(L, [n1, n2], num_thr=4, paired_end=True)
+    else:
+        dna, n, L = named_set("var2k")
+        (tmp_path / "input_clean_1.dna").write_bytes(dna)
+        cp = CompressionParams(L, [n, 0], num_thr=4, paired_end=False)
+    K = 1
+    sa.call_reorder(str(tmp_path), cp, sa.ReorderOpts(num_chains=K, num_thr=4))
+    assert not (tmp_path / "input_clean_1.dna").exists()  # inputs are consumed (reorder.h:232,241)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_serial(read, ln, L)
+    # K=1 -> everything lands in tid 0; tids 1..3 must exist and be empty
+    for t in range(4):
+        for f in ("read_order.bin", "read_rev.txt", "tempflag.txt", "temppos.txt", "read_lengths.bin", "temp.dna"):
+            assert (tmp_path / ("%s.%d" % (f, t))).exists(), (f, t)
+    assert np.array_equal(np.fromfile(tmp_path / "read_order.bin.0", np.uint32), want["order"])
+    assert gzip.open(tmp_path / "read_rev.txt.0").read() == want["rc"].tobytes()
+    assert gzip.open(tmp_path / "tempflag.txt.0").read() == want["flag"].tobytes()
+    assert gzip.open(tmp_path / "temppos.txt.0").read() == want["pos"].tobytes()
+    assert gzip.open(tmp_path / "read_lengths.bin.0").read() == want["rlen"].tobytes()
+    assert (tmp_path / "temp.dna.0").read_bytes() == po.write_dna_stream(read, ln, L, want["order"], want["rc"])
+    assert (tmp_path / "temp.dna.singleton").read_bytes() == po.write_dna_stream(read, ln, L, want["order_s"], None)
+    assert np.array_equal(np.fromfile(tmp_path / "read_order.bin.singleton", np.uint32), want["order_s"])
+    assert np.fromfile(tmp_path / "temp.dna.singleton.count", np.uint32).tolist() == [len(want["order_s"])]
+    for t in range(1, 4):
+        assert (tmp_path / ("read_order.bin.%d" % t)).stat().st_size == 0
+        assert gzip.open(tmp_path / ("read_rev.txt.%d" % t)).read() == b""
+
+
+def test_error_behaviour():
+    sa = _sa()
+    from spring_amd.reorder import CompressionParams
+    with pytest.raises(sa.ReorderError, match="Wrong bitset size"):
+        sa.call_reorder("/tmp", CompressionParams(600, [1, 0]))
+    with pytest.raises(sa.ReorderError):
+        sa.call_reorder("/nonexistent_dir_xyz", CompressionParams(100, [1, 0]))
+    with sa.ReorderStage() as s:
+        with pytest.raises(sa.ReorderError):
+            s.run_chains()  # out of order
+        with pytest.raises(sa.ReorderError):
+            s.load_dna(b"\x64\x00\x00", 1, 100)  # truncated record
+
+
+def test_synth_host_equals_device():
+    sa = _sa()
+    n, L, G = 5000, 150, 30000
+    with sa.ReorderStage() as s:
+        s.load_synth(n, L, G, 11, 10000)
+        dev = s.download_dna()
+    assert dev == sa.synth_dna_host(n, L, G, 11, 10000)
+
+
+def test_config2_1M_100bp_k1_bit_exact():
+    """BASELINE config 2: 1 M synthetic 100 bp reads, bit-exact read order vs the CPU `-t 1` oracle
+    (the data set whose reference counters SURVEY.md section 8(c) records)."""
+    sa = _sa()
+    n, L = 1_000_000, 100
+    dna = rs.pack_fixed(rs.np_reads(7, 4_000_000, n, L, 0.01))
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_serial(read, ln, L)
+    got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=1, collect_stats=True))
+    _same(got, want, "1M")
+    assert got["stats"]["unmatched"] == 96_389 and got["stats"]["probes"] == 44_478_214
+    assert got["stats"]["cands"] == 928_070 and got["stats"]["keyok"] == 927_453
+
+
+def test_1M_150bp_many_chains_vs_rounds_oracle():
+    sa = _sa()
+    n, L, K, T = 1_000_000, 150, 4096, 8
+    dna = sa.synth_dna_host(n, L, n * L // 25, 5, 10000)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, T)
+    got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=K, num_thr=T))
+    _same(got, want, "1M150")
+    check_invariants(got, read, ln, L, n)
