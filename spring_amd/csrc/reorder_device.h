@@ -31,7 +31,7 @@ struct __attribute__((aligned(16))) Chain {
   uint8_t done, prev_unmatched, left_search, stop_searching;
   uint8_t mode, retrying, prop_kind, prop_rev;
   uint8_t cnt_buf, finishing, pad0, pad1;
-  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost;
+  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost, st_hits;
 };
 
 struct Globals {

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     }
   }
   if (lane == 0) {
-    if (STATS) { c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c; }
+    if (STATS) { c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c; if (found) c->st_hits++; }
     if (found) {
       c->prop_kind = PROP_MATCH; c->prop_rid = frid; c->prop_shift = fshift; c->prop_rev = (uint8_t)frev;
       atomicMin(&P.resv[frid], cid);

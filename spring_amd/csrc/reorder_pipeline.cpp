@@ -547,7 +547,7 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   ctx->tid_off_s.assign(T + 1, 0);
   uint64_t am = 0, as = 0;
   spring_reorder_stats &s = ctx->stats;
-  s.unmatched = s.probes = s.keyok = s.cands = s.iterations = s.lost = 0;
+  s.unmatched = s.probes = s.keyok = s.cands = s.iterations = s.lost = s.hits = 0;
   for (int t = 0; t < T; t++) {
     ctx->tid_off[t] = am;
     ctx->tid_off_s[t] = as;
@@ -560,13 +560,12 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   ctx->tid_off_s[T] = as;
   for (uint32_t i = 0; i < K; i++) {
     s.unmatched += hc[i].unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
-    s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost;
+    s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost; s.hits += hc[i].st_hits;
   }
   if (am != g.nrec || as != g.nsing || am + as != ctx->n)
     return fail(SPRING_REORDER_E_STATE, "internal: emission counts do not add up (%llu+%llu vs n=%u, nrec=%u nsing=%u)",
                 (unsigned long long)am, (unsigned long long)as, ctx->n, g.nrec, g.nsing);
   s.n_reads = ctx->n; s.n_matched = am; s.n_single = as;
-  s.hits = am - (s.unmatched - as);  // matched records minus contig-start records
   const size_t nm = std::max<uint64_t>(am, 1), ns = std::max<uint64_t>(as, 1);
   DMALLOC(P.f_order, nm * 4); DMALLOC(P.f_rc, nm); DMALLOC(P.f_flag, nm); DMALLOC(P.f_pos, nm * 8);
   DMALLOC(P.f_len, nm * 2); DMALLOC(P.f_order_s, ns * 4);
