@@ -1,0 +1,25 @@
+import sys, time, ctypes as C
+sys.path.insert(0, "/root/repo")
+import torch, numpy as np
+import spring_amd
+from spring_amd import _lib
+L_ = _lib.lib()
+def run(n, L, K, stats=False, timed=False, rps=0):
+    G = n * L // 25
+    nb = L_.spring_synth_dna_bytes(n, L)
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 11, 10000); assert rc == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s = spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8, collect_stats=stats, time_search=timed, rounds_per_sync=rps))
+    s.load_dna_device(buf.data_ptr(), nb, n, L, True)
+    s.run()
+    t1 = time.perf_counter()
+    st = s.stats()
+    s.close()
+    print("n=%d L=%d K=%d wall=%.3fs  unpack=%.1f dict=%.1f chains=%.1f final=%.1f ms rounds=%d unmatched=%d single=%d Mreads/s=%.2f search_ms=%.1f launches=%d lost=%d dev=%.1fGB" % (
+        n, L, K, t1-t0, st["ms_unpack"], st["ms_dict"], st["ms_chains"], st["ms_finalize"], st["rounds"], st["unmatched"], st["n_single"], n/(t1-t0)/1e6, st["ms_search_kernel"], st["search_launches"], st["lost"], st["device_bytes"]/1e9), flush=True)
+    return st
+for a in sys.argv[1:]:
+    n, L, K = [int(x) for x in a.split(",")[:3]]
+    run(n, L, K)

@@ -140,6 +140,8 @@ int spring_reorder_download_reads(spring_reorder_ctx *ctx, uint64_t *limbs /* n*
  */
 size_t spring_synth_dna_bytes(uint32_t n, uint32_t L);
 int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
+/* generates into a device buffer the caller owns (e.g. a torch uint8 tensor); stream = 0. */
+int spring_synth_dna_device(void *d_dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
 /* generates straight into HBM owned by the context and loads it (fixed_len). */
 int spring_reorder_load_synth(spring_reorder_ctx *ctx, uint32_t n, uint32_t L, uint64_t G, uint64_t seed,
                               uint32_t err_ppm);

@@ -11,7 +11,7 @@ EXPORTS = [
     "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
-    "spring_synth_dna_host", "spring_reorder_load_synth", "spring_reorder_download_dna",
+    "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
 ]
 
 
@@ -71,6 +71,7 @@ def lib():
     L.spring_synth_dna_bytes.restype = C.c_size_t
     L.spring_synth_dna_bytes.argtypes = [C.c_uint32, C.c_uint32]
     L.spring_synth_dna_host.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.spring_synth_dna_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_reorder_load_synth.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_reorder_download_dna.argtypes = [vp, u8p, C.c_size_t]
     for name in EXPORTS:

@@ -11,6 +11,7 @@ namespace sr {
 constexpr int MAX_READ_LEN = 511;   // params.h:22
 constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
 constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
+constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
 constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in LDS
 constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
 
@@ -18,27 +19,35 @@ enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
 enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2 };
 
 // Per-chain state (one greedy chain == one reference OpenMP thread, reorder.h:351-431).
-struct __attribute__((aligned(16))) Chain {
-  uint64_t ref[16];      // consensus, 2 bits/base (reorder.h:371)
-  uint64_t revref[16];   // its reverse complement
+// The 64-byte header is one cache line: a wave loads it once (4 x 16 B, broadcast)
+// and lane 0 stores it back once per kernel.
+struct __attribute__((aligned(16))) ChainHot {
   long long ref_pos;     // reorder.h:397
   int32_t ref_len;
-  uint32_t current, prev, first_rid;
+  uint32_t e_slot, prev, first_rid;   // e_slot: next free slot in this chain's matched-record chunk
   uint32_t prop_rid;
   int32_t prop_shift;
   uint32_t num_reads_thr, num_unmatched_past;   // early-stop window (reorder.h:380-381)
-  uint32_t n_emit, n_single, unmatched;
+  uint32_t n_emit, n_single, s_slot;     // s_slot: next free slot in the singleton chunk
   uint8_t done, prev_unmatched, left_search, stop_searching;
   uint8_t mode, retrying, prop_kind, prop_rev;
-  uint8_t cnt_buf, finishing, pad0, pad1;
-  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost, st_hits;
+  uint8_t cnt_buf, finishing, cursor_writer, pad1;
 };
+static_assert(sizeof(ChainHot) == 64, "ChainHot must be one 64-byte line");
+
+struct __attribute__((aligned(64))) Chain {
+  ChainHot h;
+  uint64_t ref[16];      // consensus, 2 bits/base (reorder.h:371)
+  uint64_t revref[16];   // its reverse complement
+  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost, st_hits, n_unmatched, st_pad;
+};
+static_assert(sizeof(Chain) == 384, "Chain layout");
 
 struct Globals {
   long long cursor;   // every read above it is taken (== min over threads of remainingpos, reorder.h:402)
   uint32_t alive;     // chains not done
-  uint32_t nrec;      // matched-stream records appended
-  uint32_t nsing;     // singleton records appended
+  uint32_t e_alloc;   // next unallocated chunk of the matched-record buffer
+  uint32_t s_alloc;   // next unallocated chunk of the singleton buffer
   uint32_t pad;
 };
 
@@ -47,7 +56,7 @@ struct DevParams {
   const uint64_t *reads;  // n * S limbs (S = limb stride, power of two >= W, <= 16)
   const uint16_t *lens;
   uint32_t n;
-  int L, W, S, Lpad, maxshift, uniform_len, force_literal;
+  int L, W, S, Lpad, maxshift, uniform_len;
   // dictionaries (reorder.h:751-759)
   int dstart[2], dend[2];
   uint32_t numkeys[2];
@@ -84,8 +93,8 @@ void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
 void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n);
 void launch_init_chains(hipStream_t st, const DevParams &P);
 void launch_search(hipStream_t st, const DevParams &P, bool stats);
-void launch_apply(hipStream_t st, const DevParams &P);
-void launch_scatter(hipStream_t st, const DevParams &P, uint32_t nrec, uint32_t nsing, const uint64_t *off_m,
+void launch_apply(hipStream_t st, const DevParams &P, bool literal);
+void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s);
 void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz);
 void launch_emit_dna(hipStream_t st, const uint64_t *reads, const uint16_t *lens, int S, const uint32_t *order,

@@ -203,17 +203,21 @@ __global__ void k_init_taken(uint64_t *taken, uint64_t nwords, uint32_t n) {
 //
 // updaterefcount (reorder.h:110-220) for one chain by one wavefront.
 // Counts live in HBM as int4 per position (A,C,T,G order of reorder.h:120),
-// two buffers per chain (read cur, write nxt) so lanes never race on shifted
-// columns.  Position-parallel for every case that has no in-place aliasing;
-// the aliasing case (reverse, read longer than ref_len+shift) and the
-// test-only force_literal mode run the reference loops literally on an LDS
-// copy from lane 0.
+// two buffers per chain (read cur, write nxt), so lanes never race on shifted
+// columns and a speculative update of a chain that then loses its read is
+// simply never committed (cnt_buf is not flipped).  Every case is
+// position-parallel, including the in-place aliasing case of the reference
+// (reverse match, read longer than ref_len+shift), which has the closed form
+//   new[p] = old[p mod d] + sum_{k=1..p/d} onehot(base[p mod d + k d]),  d = n-shift-ref_len.
+// The LITERAL template variant (tests only) instead runs the reference loops
+// verbatim from lane 0 on an LDS copy.
 
 struct WaveLds {
-  uint64_t refs[2][LDS_LIMBS];   // ref / revref with zero padding (search)
-  uint64_t rd[16];               // limbs of the read being merged
-  uint8_t code[512];             // consensus codes (2-bit SPRING code per position)
-  int32_t cnt[4][512];           // literal path only
+  uint64_t rd[16];    // limbs of the read being merged
+  uint8_t code[512];  // consensus codes (2-bit SPRING code per position)
+};
+struct WaveLdsLiteral {
+  int32_t cnt[4][512];
 };
 
 __device__ __forceinline__ int cidx_of_code(int code) {  // SPRING code A0 G1 C2 T3 -> count row A0 C1 T2 G3
@@ -228,15 +232,27 @@ __device__ __forceinline__ int cur_base(const uint64_t *rd, int i, int n, bool r
   int code = (int)((rd[q >> 5] >> (2 * (q & 31))) & 3ull);
   return rev ? 3 - code : code;
 }
+__device__ __forceinline__ void add_hot(int4 &v, int ci) {
+  v.x += ci == 0; v.y += ci == 1; v.z += ci == 2; v.w += ci == 3;
+}
+__device__ __forceinline__ int argmax_code(const int4 &v) {  // reorder.h:204-212: strict >, A,C,T,G order
+  int mx = 0, ind = 0;
+  if (v.x > mx) { mx = v.x; ind = 0; }
+  if (v.y > mx) { mx = v.y; ind = 1; }
+  if (v.z > mx) { mx = v.z; ind = 2; }
+  if (v.w > mx) { mx = v.w; ind = 3; }
+  return code_of_cidx(ind);
+}
 
-// packs LDS codes[0..R) into limbs (ballot based) and writes ref + revref
-__device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int W, int lane, Chain *c) {
+// packs LDS codes[0..R) into limbs (ballot based) and stores ref + revref
+__device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int lane, Chain *c) {
   wave_sync();
-  int nblk = (R + 63) >> 6;
+  const int nblk = (R + 63) >> 6;
+#pragma unroll
   for (int k = 0; k < 8; k++) {
     uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
     if (k < nblk) {
-      int p = k * 64 + lane;
+      const int p = k * 64 + lane;
       int cf = 0, cr = 0;
       if (p < R) {
         cf = ws->code[p];
@@ -245,22 +261,21 @@ __device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int W, int la
       f0 = __ballot(cf & 1); f1 = __ballot(cf & 2);
       r0 = __ballot(cr & 1); r1 = __ballot(cr & 2);
     }
-    if (lane == 0) {
-      if (2 * k < 16) {
-        c->ref[2 * k] = spread32((uint32_t)f0) | (spread32((uint32_t)f1) << 1);
-        c->revref[2 * k] = spread32((uint32_t)r0) | (spread32((uint32_t)r1) << 1);
-      }
-      if (2 * k + 1 < 16) {
-        c->ref[2 * k + 1] = spread32((uint32_t)(f0 >> 32)) | (spread32((uint32_t)(f1 >> 32)) << 1);
-        c->revref[2 * k + 1] = spread32((uint32_t)(r0 >> 32)) | (spread32((uint32_t)(r1 >> 32)) << 1);
-      }
+    // limbs 2k, 2k+1 of ref by lanes 0,1; of revref by lanes 2,3 (values are wave-uniform)
+    if (lane < 4) {
+      const bool hi = lane & 1, isrev = lane & 2;
+      const uint64_t a = isrev ? r0 : f0, b = isrev ? r1 : f1;
+      const uint64_t limb = spread32((uint32_t)(hi ? a >> 32 : a)) | (spread32((uint32_t)(hi ? b >> 32 : b)) << 1);
+      uint64_t *dst = isrev ? c->revref : c->ref;
+      dst[2 * k + (hi ? 1 : 0)] = limb;
     }
   }
 }
 
-// literal loops of reorder.h:133-212 on the LDS copy (lane 0 only)
-__device__ void update_literal_lane0(WaveLds *ws, bool reset, bool rev, int shift, int n, int &ref_len, int M) {
-  int32_t(*count)[512] = ws->cnt;
+// literal loops of reorder.h:133-212 on the LDS copy (lane 0 only; tests)
+__device__ void update_literal_lane0(WaveLds *ws, WaveLdsLiteral *wl, bool reset, bool rev, int shift, int n,
+                                     int &ref_len, int M) {
+  int32_t(*count)[512] = wl->cnt;
   const uint64_t *rd = ws->rd;
 #define CB(i) cidx_of_code(cur_base(rd, (i), n, rev))
   if (reset) {
@@ -323,70 +338,96 @@ __device__ void update_literal_lane0(WaveLds *ws, bool reset, bool rev, int shif
   }
 }
 
-// one updaterefcount() call for chain c; rid = read merged in.  Returns new ref_len.
-__device__ int wave_update(const DevParams &P, Chain *c, uint32_t cid, WaveLds *ws, uint32_t rid, bool reset,
-                           bool rev, int shift, int lane) {
+// Computes one updaterefcount() into the chain's spare count buffer and into
+// ws->code; nothing chain-visible is modified (commit = pack_consensus + header
+// write by the caller).  NP = positions per lane (ceil(Lpad/64) <= NP).
+// Returns the new ref_len.
+template <int NP, bool LITERAL>
+__device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t cid, WaveLds *ws, WaveLdsLiteral *wl,
+                                                   uint32_t rid, int n, bool reset, bool rev, int shift, int R,
+                                                   int cb, int lane) {
   const int M = P.L, W = P.W;
-  const int n = P.uniform_len ? P.L : (int)P.lens[rid];
-  int R = c->ref_len;
-  if (lane < 16) ws->rd[lane] = lane < W ? P.reads[(uint64_t)rid * P.S + lane] : 0ull;
-  wave_sync();
-  const int cb = c->cnt_buf;
-  const int4 *cur = P.cnt + ((uint64_t)cid * 2 + cb) * P.Lpad;
-  int4 *nxt = P.cnt + ((uint64_t)cid * 2 + (cb ^ 1)) * P.Lpad;
-  int Rn;
-  bool literal = P.force_literal || (!reset && rev && (n - shift > R));
-  if (literal) {
-    for (int p = lane; p < M; p += 64) {
-      int4 v = reset ? make_int4(0, 0, 0, 0) : cur[p];
-      ws->cnt[0][p] = v.x; ws->cnt[1][p] = v.y; ws->cnt[2][p] = v.z; ws->cnt[3][p] = v.w;
-    }
-    wave_sync();
-    Rn = R;
-    if (lane == 0) update_literal_lane0(ws, reset, rev, shift, n, Rn, M);
-    Rn = __shfl(Rn, 0, 64);
-    wave_sync();
-    for (int p = lane; p < M; p += 64) nxt[p] = make_int4(ws->cnt[0][p], ws->cnt[1][p], ws->cnt[2][p], ws->cnt[3][p]);
-  } else {
-    // case parameters: out position p < hiP gets (p<cpy_hi ? cur[p+src_off] : 0) + (add_lo<=p<add_hi ? onehot(base p-add_lo+0) : 0)
-    int hiP, cpy_hi, src_off, add_lo, add_hi;
-    if (reset) { hiP = M; cpy_hi = 0; src_off = 0; add_lo = 0; add_hi = n; Rn = n; }
-    else if (!rev) { Rn = max(R - shift, n); hiP = Rn; cpy_hi = R - shift; src_off = shift; add_lo = 0; add_hi = n; }
-    else if (n - shift >= R) { /* == R here: no aliasing */ Rn = n; hiP = n; cpy_hi = R; src_off = 0; add_lo = 0; add_hi = n; }
-    else if (R + shift <= M) { Rn = R + shift; hiP = Rn; cpy_hi = R; src_off = 0; add_lo = R - n + shift; add_hi = Rn; }
-    else { Rn = M; hiP = M; cpy_hi = M - shift; src_off = R + shift - M; add_lo = M - n; add_hi = M; }
-    for (int p = lane; p < hiP; p += 64) {
-      int4 v = make_int4(0, 0, 0, 0);
-      if (p < cpy_hi) v = cur[p + src_off];
-      int code = -1;
-      if (p >= add_lo && p < add_hi) {
-        code = cur_base(ws->rd, p - add_lo, n, rev);
-        int ci = cidx_of_code(code);
-        if (ci == 0) v.x++; else if (ci == 1) v.y++; else if (ci == 2) v.z++; else v.w++;
-      }
-      nxt[p] = v;
-      if (p < Rn) {
-        int out;
-        if (reset) out = code;  // consensus = the read itself (reorder.h:133-142,214)
-        else {
-          int mx = 0, ind = 0;
-          if (v.x > mx) { mx = v.x; ind = 0; }
-          if (v.y > mx) { mx = v.y; ind = 1; }
-          if (v.z > mx) { mx = v.z; ind = 2; }
-          if (v.w > mx) { mx = v.w; ind = 3; }
-          out = code_of_cidx(ind);
-        }
-        ws->code[p] = (uint8_t)out;
-      }
+  const int4 *__restrict__ cur = P.cnt + ((uint64_t)cid * 2 + cb) * P.Lpad;
+  int4 *__restrict__ nxt = P.cnt + ((uint64_t)cid * 2 + (cb ^ 1)) * P.Lpad;
+  // case parameters: out position p < hiP gets (p<cpy_hi ? cur[p+src_off] : 0) + (add_lo<=p<add_hi ? onehot(base[p-add_lo]) : 0)
+  int hiP, cpy_hi, src_off, add_lo, add_hi, Rn, d = 0;
+  bool alias = false;
+  if (reset) { hiP = M; cpy_hi = 0; src_off = 0; add_lo = 0; add_hi = n; Rn = n; }
+  else if (!rev) { Rn = max(R - shift, n); hiP = Rn; cpy_hi = R - shift; src_off = shift; add_lo = 0; add_hi = n; }
+  else if (n - shift >= R) { Rn = n; hiP = n; cpy_hi = R; src_off = 0; add_lo = 0; add_hi = n; d = n - shift - R; alias = d > 0; }
+  else if (R + shift <= M) { Rn = R + shift; hiP = Rn; cpy_hi = R; src_off = 0; add_lo = R - n + shift; add_hi = Rn; }
+  else { Rn = M; hiP = M; cpy_hi = M - shift; src_off = R + shift - M; add_lo = M - n; add_hi = M; }
+
+  // issue every load first: read limbs + this lane's old columns
+  uint64_t myl = 0;
+  if (lane < 16 && lane < W) myl = P.reads[(uint64_t)rid * P.S + lane];
+  int4 v[NP];
+  if (!LITERAL) {
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+      const int p = k * 64 + lane;
+      v[k] = make_int4(0, 0, 0, 0);
+      if (!alias) { if (p < cpy_hi) v[k] = cur[p + src_off]; }
+      else if (p >= d && p < n - shift) v[k] = cur[p % d];
     }
   }
-  pack_consensus(ws, Rn, W, lane, c);
-  if (lane == 0) { c->ref_len = Rn; c->cnt_buf = (uint8_t)(cb ^ 1); }
+  if (lane < 16) ws->rd[lane] = myl;
+  wave_sync();
+
+  if (LITERAL) {
+    for (int p = lane; p < M; p += 64) {
+      int4 t = reset ? make_int4(0, 0, 0, 0) : cur[p];
+      wl->cnt[0][p] = t.x; wl->cnt[1][p] = t.y; wl->cnt[2][p] = t.z; wl->cnt[3][p] = t.w;
+    }
+    wave_sync();
+    int Rl = R;
+    if (lane == 0) update_literal_lane0(ws, wl, reset, rev, shift, n, Rl, M);
+    Rl = __shfl(Rl, 0, 64);
+    wave_sync();
+    for (int p = lane; p < M; p += 64) nxt[p] = make_int4(wl->cnt[0][p], wl->cnt[1][p], wl->cnt[2][p], wl->cnt[3][p]);
+    return Rl;
+  }
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const int p = k * 64 + lane;
+    if (p < hiP) {
+      int4 t = v[k];
+      int code = 0;
+      if (!alias) {
+        if (p >= add_lo && p < add_hi) {
+          code = cur_base(ws->rd, p - add_lo, n, rev);
+          add_hot(t, cidx_of_code(code));
+        }
+      } else {  // reverse case 1 with d > 0 (reorder.h:159-174), closed form of the in-place loop
+        if (p >= d && p < n - shift) {
+          const int r = p % d;
+          for (int q = r + d; q <= p; q += d) add_hot(t, cidx_of_code(cur_base(ws->rd, q, n, rev)));
+        } else {
+          t = make_int4(0, 0, 0, 0);
+          add_hot(t, cidx_of_code(cur_base(ws->rd, p, n, rev)));
+        }
+      }
+      nxt[p] = t;
+      if (p < Rn) ws->code[p] = (uint8_t)(reset ? code : argmax_code(t));  // reset: consensus = the read itself
+    }
+  }
   return Rn;
+}
+
+__device__ __forceinline__ void load_hot(const Chain *c, ChainHot &h) {
+  const uint4 *s = reinterpret_cast<const uint4 *>(&c->h);
+  uint4 *d = reinterpret_cast<uint4 *>(&h);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+}
+__device__ __forceinline__ void store_hot(Chain *c, const ChainHot &h) {
+  uint4 *d = reinterpret_cast<uint4 *>(&c->h);
+  const uint4 *s = reinterpret_cast<const uint4 *>(&h);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
 // ----------------------------------------------------------- chain start-up
 // reorder.h:405-431 with the critical section entered in chain-id order.
+template <int NP>
 __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   __shared__ WaveLds lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -396,17 +437,25 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   WaveLds *ws = &lds[wave];
   const uint32_t step = P.n / P.K;
   const uint32_t seed = cid * step;
-  bool start = P.n > 0 && (cid == 0 || step > 0);
-  if (lane == 0) {
-    c->done = start ? 0 : 1;
-    if (start) {
-      atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
-      atomicAdd(&P.glob->alive, 1u);
-      c->unmatched = 1; c->current = seed; c->prev = seed; c->first_rid = seed; c->prev_unmatched = 1;
-    }
+  const bool start = P.n > 0 && (cid == 0 || step > 0);
+  ChainHot h;
+  memset(&h, 0, sizeof(h));
+  if (!start) {
+    h.done = 1;
+    if (lane == 0) store_hot(c, h);
+    return;
   }
-  if (!start) return;
-  wave_update(P, c, cid, ws, seed, true, false, 0, lane);
+  const int n = P.uniform_len ? P.L : (int)P.lens[seed];
+  const int Rn = wave_update_compute<NP, false>(P, cid, ws, nullptr, seed, n, true, false, 0, 0, 0, lane);
+  pack_consensus(ws, Rn, lane, c);
+  if (lane == 0) {
+    atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
+    h.prev = seed; h.first_rid = seed; h.prev_unmatched = 1;
+    h.e_slot = cid * CHUNK; h.s_slot = cid * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
+    h.ref_len = Rn; h.cnt_buf = 1;
+    store_hot(c, h);
+    c->n_unmatched = 1;
+  }
 }
 
 // ------------------------------------------------------------ K4 search (phase A)
@@ -424,18 +473,29 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   const uint32_t cid = blockIdx.x * 4 + wave;
   if (cid >= P.K) return;
   Chain *c = &P.chains[cid];
-  if (c->done) return;
+  ChainHot h;
+  load_hot(c, h);
+  // stage ref / revref in LDS right away (same dependency level as the header load)
+  if (lane < LDS_LIMBS) {
+    const int i = lane - LDS_PAD;
+    const bool in = i >= 0 && i < P.W;
+    s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
+    s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
+  }
+  if (h.done) return;
 
-  if (c->mode == MODE_NEED_SEED) {
+  if (h.mode == MODE_NEED_SEED) {
     // rank among seed-needing chains (by chain id)
-    int r = 0;
+    int r = 0, tot = 0;
     const uint32_t nw = (P.K + 31) / 32;
     for (uint32_t w = lane; w < nw; w += 64) {
       uint32_t v = P.needy[w];
+      tot += __popc(v);
       if (w * 32 + 32 <= cid) r += __popc(v);
       else if (w * 32 <= cid) r += __popc(v & ((1u << (cid - w * 32)) - 1u));
     }
-    uint32_t need = (uint32_t)wave_sum_i(r) + 1;
+    const uint32_t rank = (uint32_t)wave_sum_i(r), nneedy = (uint32_t)wave_sum_i(tot);
+    uint32_t need = rank + 1;
     long long top = P.glob->cursor;
     long long seed = -1;
     while (top >= 0) {
@@ -466,37 +526,40 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     }
     if (lane == 0) {
       if (seed >= 0) {
-        c->prop_kind = PROP_SEED;
-        c->prop_rid = (uint32_t)seed;
+        h.prop_kind = PROP_SEED;
+        h.prop_rid = (uint32_t)seed;
+        // the last-ranked needy chain proposes the lowest seed of the round: it alone moves the cursor
+        h.cursor_writer = rank + 1 == nneedy;
         atomicMin(&P.resv[seed], cid);
       } else {
-        c->prop_kind = PROP_NONE;
-        c->finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
+        h.prop_kind = PROP_NONE;
+        h.finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
       }
+      store_hot(c, h);
     }
     return;
   }
 
   // ---- search mode
-  bool stop = c->stop_searching;
-  if (!c->retrying) {  // iteration start bookkeeping (reorder.h:433-439), once per iteration
-    uint32_t nr = c->num_reads_thr;
-    if (nr % 1000000u == 0) {
-      if ((float)c->num_unmatched_past > 0.5f * 1000000) stop = true;
-      if (lane == 0) { c->num_unmatched_past = 0; c->stop_searching = stop; }
+  if (!h.retrying) {  // iteration start bookkeeping (reorder.h:433-439), once per iteration
+    if (h.num_reads_thr % 1000000u == 0) {
+      if ((float)h.num_unmatched_past > 0.5f * 1000000) h.stop_searching = 1;
+      h.num_unmatched_past = 0;
     }
-    if (lane == 0) { c->num_reads_thr = nr + 1; if (STATS) c->st_iter++; }
+    h.num_reads_thr++;
   }
-  if (stop) { if (lane == 0) c->prop_kind = PROP_NONE; return; }
+  const bool new_iter = !h.retrying;
+  if (h.stop_searching) {
+    if (lane == 0) {
+      h.prop_kind = PROP_NONE;
+      store_hot(c, h);
+      if (STATS && new_iter) c->st_iter++;
+    }
+    return;
+  }
 
-  const int W = P.W, ref_len = c->ref_len;
-  uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
-  if (lane < LDS_LIMBS) {
-    int i = lane - LDS_PAD;
-    bool in = i >= 0 && i < W;
-    s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
-    s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
-  }
+  const int W = P.W, ref_len = h.ref_len;
+  const uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
   wave_sync();
 
   const int l = lane & 1, rev = (lane >> 1) & 1;
@@ -506,6 +569,7 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   const uint64_t *__restrict__ tab = P.tab[l];
   const uint64_t bmask = P.bmask[l];
   const uint32_t *__restrict__ ids = P.ids[l];
+  const bool have_keys = P.numkeys[l] > 0;
   const uint64_t *sx = rev ? srev : sref;
   const int nbatch = (P.maxshift + 15) >> 4;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
@@ -519,7 +583,7 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     else valid = valid && (de < ref_len + shift) && (ds > shift);
     bool hit = false, keyok = false;
     uint32_t rid = 0, ncand = 0;
-    if (valid && P.numkeys[l] > 0) {
+    if (valid && have_keys) {
       const int kb = rev ? 2 * (ds - shift) : 2 * (ds + shift);
       const uint64_t key = lds_window(sx, kb) & kmask;
       uint32_t start, count;
@@ -536,7 +600,7 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
           const int m = clen < mref ? clen : mref;
           const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
           const int blo = 2 * lo, bhi = 2 * m;
-          int h = 0;
+          int hd = 0;
           for (int i = 0; i < W; i++) {
             const int s0 = i * 64;
             if (s0 >= bhi) break;
@@ -544,9 +608,9 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
             uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
             if (blo > s0) x &= ~0ull << (blo - s0);
             if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
-            h += __popcll(x);
+            hd += __popcll(x);
           }
-          if (h <= THRESH) { hit = true; rid = r; break; }
+          if (hd <= THRESH) { hit = true; rid = r; break; }
         }
       }
     }
@@ -568,12 +632,17 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     }
   }
   if (lane == 0) {
-    if (STATS) { c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c; if (found) c->st_hits++; }
     if (found) {
-      c->prop_kind = PROP_MATCH; c->prop_rid = frid; c->prop_shift = fshift; c->prop_rev = (uint8_t)frev;
+      h.prop_kind = PROP_MATCH; h.prop_rid = frid; h.prop_shift = fshift; h.prop_rev = (uint8_t)frev;
       atomicMin(&P.resv[frid], cid);
     } else {
-      c->prop_kind = PROP_NONE;
+      h.prop_kind = PROP_NONE;
+    }
+    store_hot(c, h);
+    if (STATS) {
+      c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c;
+      if (found) c->st_hits++;
+      if (new_iter) c->st_iter++;
     }
   }
 }
@@ -583,111 +652,143 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
 // Resolves the round's proposals (lowest chain id holds resv[rid]) and applies
 // the winner's step: claim, consensus update, position bookkeeping and
 // emission (reorder.h:484-515, :522-553), or the failure path (reorder.h:559-615).
-__device__ __forceinline__ void emit_rec(const DevParams &P, Chain *c, uint32_t cid, uint32_t idx, uint32_t rid,
-                                         char rc, char flag, long long pos, uint32_t seq) {
+// The consensus update is computed speculatively while the resv[] answer is in
+// flight and only committed by the winner.
+// Emission slots: each chain fills private CHUNK-slot chunks of the append buffers and only
+// touches the global allocator once per CHUNK records (a same-address atomic per record from
+// every chain serialises at ~11 ns each and dominated this kernel).
+__device__ __forceinline__ uint32_t take_slot(uint32_t &slot, uint32_t *alloc) {
+  const uint32_t s0 = slot;
+  uint32_t nx = s0 + 1;
+  if ((nx & (CHUNK - 1)) == 0) nx = atomicAdd(alloc, CHUNK);
+  slot = nx;
+  return s0;
+}
+__device__ __forceinline__ void emit_rec(const DevParams &P, ChainHot &h, uint32_t cid, uint32_t rid, char rc,
+                                         char flag, long long pos) {
+  const uint32_t idx = take_slot(h.e_slot, &P.glob->e_alloc);
   P.e_order[idx] = rid; P.e_rc[idx] = rc; P.e_flag[idx] = flag; P.e_pos[idx] = pos;
   P.e_len[idx] = P.uniform_len ? (uint16_t)P.L : P.lens[rid];
-  P.e_chain[idx] = cid; P.e_seq[idx] = seq;
+  P.e_chain[idx] = cid; P.e_seq[idx] = h.n_emit++;
 }
-__device__ __forceinline__ void emit_single(const DevParams &P, Chain *c, uint32_t cid, uint32_t rid) {
-  uint32_t idx = atomicAdd(&P.glob->nsing, 1u);
-  P.s_order[idx] = rid; P.s_chain[idx] = cid; P.s_seq[idx] = c->n_single++;
+__device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uint32_t cid, uint32_t rid) {
+  const uint32_t idx = take_slot(h.s_slot, &P.glob->s_alloc);
+  P.s_order[idx] = rid; P.s_chain[idx] = cid; P.s_seq[idx] = h.n_single++;
 }
 
+template <int NP, bool LITERAL>
 __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   __shared__ WaveLds lds[4];
+  __shared__ WaveLdsLiteral ldsl[LITERAL ? 4 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t cid = blockIdx.x * 4 + wave;
   if (cid >= P.K) return;
   Chain *c = &P.chains[cid];
-  if (c->done) return;
+  ChainHot h;
+  load_hot(c, h);
+  if (h.done) return;
   WaveLds *ws = &lds[wave];
-  const int kind = c->prop_kind;
+  WaveLdsLiteral *wl = &ldsl[LITERAL ? wave : 0];
+  const int kind = h.prop_kind;
 
-  if (c->finishing) {  // seed-needing chain found the pool empty
+  if (h.finishing) {  // seed-needing chain found the pool empty
     if (lane == 0) {
-      if (c->prev_unmatched) emit_single(P, c, cid, c->prev);
-      c->done = 1; c->finishing = 0;
+      if (h.prev_unmatched) emit_single(P, h, cid, h.prev);
+      h.done = 1; h.finishing = 0;
       atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
       atomicSub(&P.glob->alive, 1u);
+      store_hot(c, h);
     }
     return;
   }
-  if (kind != PROP_NONE && P.resv[c->prop_rid] != cid) {  // lost the read: retry next round
+  // who holds the read we proposed (load in flight while the update is computed)
+  const uint32_t owner = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;
+  const bool fail_path = kind == PROP_NONE && h.mode == MODE_SEARCH;
+  bool do_upd = false, ureset = false, urev = false;
+  uint32_t urid = 0;
+  int ushift = 0;
+  if (kind == PROP_MATCH) { do_upd = true; urid = h.prop_rid; urev = h.prop_rev; ushift = h.prop_shift; }
+  else if (kind == PROP_SEED) { do_upd = true; urid = h.prop_rid; ureset = true; }
+  else if (fail_path && !h.left_search) { do_upd = true; urid = h.first_rid; ureset = true; urev = true; }  // reorder.h:567
+  int n = P.L, R_new = h.ref_len;
+  const int R_old = h.ref_len;
+  if (do_upd) {
+    if (!P.uniform_len) n = (int)P.lens[urid];
+    R_new = wave_update_compute<NP, LITERAL>(P, cid, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf, lane);
+  }
+  if (kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
+    if (lane == 0) P.glob->cursor = (long long)h.prop_rid - 1;
+    h.cursor_writer = 0;
+  }
+  if (owner != cid) {  // lost the read: retry next round, nothing committed
     if (lane == 0) {
-      if (c->mode == MODE_SEARCH) c->retrying = 1;
+      if (h.mode == MODE_SEARCH) h.retrying = 1;
+      store_hot(c, h);
       c->st_lost++;
     }
     return;
   }
+  if (do_upd) {
+    pack_consensus(ws, R_new, lane, c);
+    h.ref_len = R_new;
+    h.cnt_buf ^= 1;
+  }
+  if (lane != 0) return;
   if (kind == PROP_MATCH) {
-    const uint32_t rid = c->prop_rid;
-    const int shift = c->prop_shift;
-    const bool rev = c->prop_rev;
-    const int R_old = c->ref_len;
-    const int n = P.uniform_len ? P.L : (int)P.lens[rid];
-    const int R_new = wave_update(P, c, cid, ws, rid, false, rev, shift, lane);
-    if (lane == 0) {
-      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
-      const bool left = c->left_search;
-      long long ref_pos = c->ref_pos, cur_pos;
-      char rcch;
-      if (!rev) {  // reorder.h:490-497, :508
-        if (!left) { cur_pos = ref_pos + shift; ref_pos = cur_pos; }
-        else { cur_pos = ref_pos + R_old - shift - n; ref_pos = ref_pos + R_old - shift - R_new; }
-        rcch = left ? 'r' : 'd';
-      } else {  // reorder.h:528-535, :546
-        if (!left) { cur_pos = ref_pos + R_old + shift - n; ref_pos = ref_pos + R_old + shift - R_new; }
-        else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
-        rcch = left ? 'd' : 'r';
-      }
-      const uint32_t cnt = c->prev_unmatched ? 2u : 1u;
-      uint32_t idx = atomicAdd(&P.glob->nrec, cnt);
-      uint32_t seq = c->n_emit;
-      if (c->prev_unmatched) emit_rec(P, c, cid, idx++, c->prev, 'd', '0', 0, seq++);
-      emit_rec(P, c, cid, idx, rid, rcch, '1', cur_pos, seq++);
-      c->n_emit = seq;
-      c->prev_unmatched = 0; c->current = rid; c->ref_pos = ref_pos; c->retrying = 0;
+    const uint32_t rid = h.prop_rid;
+    const int shift = ushift;
+    atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+    const bool left = h.left_search;
+    long long ref_pos = h.ref_pos, cur_pos;
+    char rcch;
+    if (!urev) {  // reorder.h:490-497, :508
+      if (!left) { cur_pos = ref_pos + shift; ref_pos = cur_pos; }
+      else { cur_pos = ref_pos + R_old - shift - n; ref_pos = ref_pos + R_old - shift - R_new; }
+      rcch = left ? 'r' : 'd';
+    } else {  // reorder.h:528-535, :546
+      if (!left) { cur_pos = ref_pos + R_old + shift - n; ref_pos = ref_pos + R_old + shift - R_new; }
+      else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
+      rcch = left ? 'd' : 'r';
     }
+    if (h.prev_unmatched) emit_rec(P, h, cid, h.prev, 'd', '0', 0);
+    emit_rec(P, h, cid, rid, rcch, '1', cur_pos);
+    h.prev_unmatched = 0; h.ref_pos = ref_pos; h.retrying = 0;
   } else if (kind == PROP_SEED) {  // reorder.h:580-587, :600-613
-    const uint32_t rid = c->prop_rid;
-    wave_update(P, c, cid, ws, rid, true, false, 0, lane);
-    if (lane == 0) {
-      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
-      atomicMin((long long *)&P.glob->cursor, (long long)rid - 1);
-      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
-      if (c->prev_unmatched) emit_single(P, c, cid, c->prev);
-      c->unmatched++;
-      c->prev_unmatched = 1; c->first_rid = rid; c->prev = rid; c->current = rid;
-      c->ref_pos = 0; c->mode = MODE_SEARCH;
-    }
-  } else if (c->mode == MODE_SEARCH) {  // search failed (reorder.h:559-575)
-    const bool left = c->left_search;
-    if (!left) wave_update(P, c, cid, ws, c->first_rid, true, true, 0, lane);
-    if (lane == 0) {
-      c->retrying = 0;
-      c->num_unmatched_past++;
-      if (!left) { c->left_search = 1; c->ref_pos = 0; }
-      else {
-        c->left_search = 0; c->mode = MODE_NEED_SEED;
-        atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));
-      }
+    const uint32_t rid = h.prop_rid;
+    atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+    atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+    if (h.prev_unmatched) emit_single(P, h, cid, h.prev);
+    c->n_unmatched++;
+    h.prev_unmatched = 1; h.first_rid = rid; h.prev = rid;
+    h.ref_pos = 0; h.mode = MODE_SEARCH;
+  } else if (fail_path) {  // search failed (reorder.h:559-575)
+    h.retrying = 0;
+    h.num_unmatched_past++;
+    if (!h.left_search) { h.left_search = 1; h.ref_pos = 0; }
+    else {
+      h.left_search = 0; h.mode = MODE_NEED_SEED;
+      atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));
     }
   }
+  store_hot(c, h);
 }
 
 // ------------------------------------------------------------ K7 finalize / emit
-__global__ void k_scatter_matched(DevParams P, uint32_t nrec, const uint64_t *__restrict__ off_m) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nrec) return;
-  uint64_t d = off_m[P.e_chain[i]] + P.e_seq[i];
+__global__ void k_scatter_matched(DevParams P, uint64_t cap, const uint64_t *__restrict__ off_m) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  const uint32_t ch = P.e_chain[i];
+  if (ch == 0xffffffffu) return;  // unused slot of a chunk
+  uint64_t d = off_m[ch] + P.e_seq[i];
   P.f_order[d] = P.e_order[i]; P.f_rc[d] = P.e_rc[i]; P.f_flag[d] = P.e_flag[i];
   P.f_pos[d] = P.e_pos[i]; P.f_len[d] = P.e_len[i];
 }
-__global__ void k_scatter_single(DevParams P, uint32_t nsing, const uint64_t *__restrict__ off_s) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nsing) return;
-  P.f_order_s[off_s[P.s_chain[i]] + P.s_seq[i]] = P.s_order[i];
+__global__ void k_scatter_single(DevParams P, uint64_t cap, const uint64_t *__restrict__ off_s) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  const uint32_t ch = P.s_chain[i];
+  if (ch == 0xffffffffu) return;
+  P.f_order_s[off_s[ch] + P.s_seq[i]] = P.s_order[i];
 }
 
 // record sizes of a temp.dna stream (writetofile, reorder.h:667-687)
@@ -780,20 +881,35 @@ void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_
   if (!nwords) return;
   hipLaunchKernelGGL(k_init_taken, GRID1(nwords, 256), dim3(256), 0, st, taken, nwords, n);
 }
+#define NP_DISPATCH(CALL)                                  \
+  do {                                                     \
+    const int np_ = P.Lpad / 64;                           \
+    if (np_ <= 1) { CALL(1); } else if (np_ == 2) { CALL(2); } else if (np_ == 3) { CALL(3); } \
+    else if (np_ == 4) { CALL(4); } else { CALL(8); }      \
+  } while (0)
+
 void launch_init_chains(hipStream_t st, const DevParams &P) {
-  hipLaunchKernelGGL(k_init_chains, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+#define CALL(N) hipLaunchKernelGGL(k_init_chains<N>, dim3((P.K + 3) / 4), dim3(256), 0, st, P)
+  NP_DISPATCH(CALL);
+#undef CALL
 }
 void launch_search(hipStream_t st, const DevParams &P, bool stats) {
   if (stats) hipLaunchKernelGGL(k_search<true>, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
   else hipLaunchKernelGGL(k_search<false>, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
 }
-void launch_apply(hipStream_t st, const DevParams &P) {
-  hipLaunchKernelGGL(k_apply, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
+  if (literal) {
+    hipLaunchKernelGGL((k_apply<8, true>), dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+    return;
+  }
+#define CALL(N) hipLaunchKernelGGL((k_apply<N, false>), dim3((P.K + 3) / 4), dim3(256), 0, st, P)
+  NP_DISPATCH(CALL);
+#undef CALL
 }
-void launch_scatter(hipStream_t st, const DevParams &P, uint32_t nrec, uint32_t nsing, const uint64_t *off_m,
+void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s) {
-  if (nrec) hipLaunchKernelGGL(k_scatter_matched, GRID1(nrec, 256), dim3(256), 0, st, P, nrec, off_m);
-  if (nsing) hipLaunchKernelGGL(k_scatter_single, GRID1(nsing, 256), dim3(256), 0, st, P, nsing, off_s);
+  if (cap_m) hipLaunchKernelGGL(k_scatter_matched, GRID1(cap_m, 256), dim3(256), 0, st, P, cap_m, off_m);
+  if (cap_s) hipLaunchKernelGGL(k_scatter_single, GRID1(cap_s, 256), dim3(256), 0, st, P, cap_s, off_s);
 }
 void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz) {
   if (!cnt) return;

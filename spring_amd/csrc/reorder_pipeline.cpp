@@ -71,7 +71,7 @@ struct spring_reorder_ctx {
   DictDev dict[2];
   DevParams P;
   uint32_t K = 0;
-  uint32_t nrec = 0, nsing = 0;
+  uint64_t nrec = 0, nsing = 0, cap = 0;
   std::vector<uint64_t> tid_off, tid_off_s;
   spring_reorder_stats stats;
   hipEvent_t ev[8];
@@ -262,6 +262,14 @@ int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint
   return 0;
 }
 
+int spring_synth_dna_device(void *d_dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm) {
+  if (!d_dst || L == 0 || L > (uint32_t)MAX_READ_LEN || G < L) return fail(SPRING_REORDER_E_ARG, "bad synth arguments");
+  launch_synth(nullptr, (uint8_t *)d_dst, n, L, G, seed, syn_err_thr24(err_ppm));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
 int spring_reorder_load_synth(spring_reorder_ctx *ctx, uint32_t n, uint32_t L, uint64_t G, uint64_t seed,
                               uint32_t err_ppm) {
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
@@ -448,7 +456,6 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
   P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2;  // reorder.h:750
   P.uniform_len = ctx->uniform ? 1 : 0;
-  P.force_literal = ctx->o.force_literal_update ? 1 : 0;
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
     P.tab[l] = ctx->dict[l].tab; P.bmask[l] = ctx->dict[l].bmask; P.ids[l] = ctx->dict[l].ids;
@@ -461,9 +468,13 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   DMALLOC(P.glob, sizeof(Globals));
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
-  DMALLOC(P.e_order, nn * 4); DMALLOC(P.e_rc, nn); DMALLOC(P.e_flag, nn); DMALLOC(P.e_pos, nn * 8);
-  DMALLOC(P.e_len, nn * 2); DMALLOC(P.e_chain, nn * 4); DMALLOC(P.e_seq, nn * 4);
-  DMALLOC(P.s_order, nn * 4); DMALLOC(P.s_chain, nn * 4); DMALLOC(P.s_seq, nn * 4);
+  // append buffers: n records + one partly filled CHUNK per chain
+  const size_t cap = (size_t)n + (size_t)K * CHUNK;
+  if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
+  ctx->cap = cap;
+  DMALLOC(P.e_order, cap * 4); DMALLOC(P.e_rc, cap); DMALLOC(P.e_flag, cap); DMALLOC(P.e_pos, cap * 8);
+  DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
+  DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
   P.K = K;
 
   HIPCHK(hipEventRecord(ctx->ev[4], st));
@@ -474,12 +485,17 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   Globals g;
   memset(&g, 0, sizeof(g));
   g.cursor = (long long)n - 1;
+  g.e_alloc = g.s_alloc = K * CHUNK;
+  g.alive = n == 0 ? 0 : (n / K > 0 ? K : 1);  // chains that get a seed (reorder.h:405-421)
+  launch_fill_u32(st, P.e_chain, cap, 0xffffffffu);
+  launch_fill_u32(st, P.s_chain, cap, 0xffffffffu);
   HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
   launch_init_chains(st, P);
   HIPCHK(hipGetLastError());
 
   const bool stats = ctx->o.collect_stats != 0;
   const bool timed = ctx->o.time_search != 0;
+  const bool literal = ctx->o.force_literal_update != 0;
   int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : (K >= 256 ? 16 : 256);
   std::vector<hipEvent_t> tev;
   if (timed) {
@@ -498,7 +514,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
       if (timed) HIPCHK(hipEventRecord(tev[2 * r], st));
       launch_search(st, P, stats);
       if (timed) HIPCHK(hipEventRecord(tev[2 * r + 1], st));
-      launch_apply(st, P);
+      launch_apply(st, P, literal);
     }
     rounds += R;
     HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
@@ -538,8 +554,6 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   HIPCHK(hipMemcpyAsync(hc.data(), P.chains, (size_t)K * sizeof(Chain), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&g, P.glob, sizeof(g), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  ctx->nrec = g.nrec;
-  ctx->nsing = g.nsing;
   // chain i -> tid i % num_thr, chains ascending inside a tid (each per-tid file is a
   // sequence of whole contigs, which is all the encoder needs: encoder.h:215-363)
   std::vector<uint64_t> off_m(K), off_s(K);
@@ -553,18 +567,21 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
     ctx->tid_off_s[t] = as;
     for (uint32_t i = (uint32_t)t; i < K; i += (uint32_t)T) {
       off_m[i] = am; off_s[i] = as;
-      am += hc[i].n_emit; as += hc[i].n_single;
+      am += hc[i].h.n_emit; as += hc[i].h.n_single;
     }
   }
   ctx->tid_off[T] = am;
   ctx->tid_off_s[T] = as;
   for (uint32_t i = 0; i < K; i++) {
-    s.unmatched += hc[i].unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
+    s.unmatched += hc[i].n_unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
     s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost; s.hits += hc[i].st_hits;
   }
-  if (am != g.nrec || as != g.nsing || am + as != ctx->n)
-    return fail(SPRING_REORDER_E_STATE, "internal: emission counts do not add up (%llu+%llu vs n=%u, nrec=%u nsing=%u)",
-                (unsigned long long)am, (unsigned long long)as, ctx->n, g.nrec, g.nsing);
+  if (am + as != ctx->n || g.e_alloc > ctx->cap + CHUNK || g.s_alloc > ctx->cap + CHUNK)
+    return fail(SPRING_REORDER_E_STATE, "internal: emission counts do not add up (%llu+%llu vs n=%u, alloc %u/%u cap %llu)",
+                (unsigned long long)am, (unsigned long long)as, ctx->n, g.e_alloc, g.s_alloc,
+                (unsigned long long)ctx->cap);
+  ctx->nrec = am;
+  ctx->nsing = as;
   s.n_reads = ctx->n; s.n_matched = am; s.n_single = as;
   const size_t nm = std::max<uint64_t>(am, 1), ns = std::max<uint64_t>(as, 1);
   DMALLOC(P.f_order, nm * 4); DMALLOC(P.f_rc, nm); DMALLOC(P.f_flag, nm); DMALLOC(P.f_pos, nm * 8);
@@ -574,7 +591,7 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   DMALLOC(d_off_s, (size_t)K * 8);
   HIPCHK(hipMemcpyAsync(d_off_m, off_m.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_off_s, off_s.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
-  launch_scatter(st, P, g.nrec, g.nsing, d_off_m, d_off_s);
+  launch_scatter(st, P, am ? ctx->cap : 0, as ? ctx->cap : 0, d_off_m, d_off_s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   HIPCHK(hipStreamSynchronize(st));
