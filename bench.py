@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s through the reorder stage on synthetic reads (BASELINE.json metric).
+
+One "step" = one pass of the whole stage (unpack -> dictionaries -> chains -> streams) over one
+batch of synthetic reads that is already resident in HBM as a .dna record stream when the timed
+region starts.  N=1 workload = BASELINE configs[2]: 100 M x 150 bp single-end.  For N>1 every
+rank runs the stage on its own independent read set (lane) -- no data-path collective -- so the
+job is weak-scaled; see DESIGN.md "Multi-GPU".
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
+search kernel and `cpu_baseline` (the C oracle timed on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--readlen", type=int, default=150)
+    ap.add_argument("--coverage", type=int, default=25)
+    ap.add_argument("--err-ppm", type=int, default=10000)
+    ap.add_argument("--chains", type=int, default=0, help="0 = library default")
+    ap.add_argument("--num-thr", type=int, default=8, help="per-tid output sets (reference default -t 8)")
+    ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_search(st, W):
+    """bytes the search needs, from counted work (reference-equivalent counters):
+    P*(8+8) [table slot + bin offsets] + Kv*(4+B) [first id + first read] + C*(4+B+2+1) [id, read, len, flag]."""
+    B = 8 * W
+    return st["probes"] * 16 + st["keyok"] * (4 + B) + st["cands"] * (7 + B)
+
+
+def main():
+    a = parse()
+    import torch
+    import spring_amd
+    from spring_amd import _lib
+    L_ = _lib.lib()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+
+    n, L = a.reads, a.readlen
+    G = max(n * L // a.coverage, 2 * L)
+    seed = 11 + 1000 * rank  # every rank (lane) has its own genome and reads
+    nb = L_.spring_synth_dna_bytes(n, L)
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, seed, a.err_ppm)
+    assert rc == 0, L_.spring_reorder_last_error()
+    torch.cuda.synchronize()
+
+    def one_pass(**kw):
+        s = spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=a.chains, num_thr=a.num_thr, **kw))
+        s.load_dna_device(buf.data_ptr(), nb, n, L, True)
+        s.run()
+        st = s.stats()
+        s.close()
+        return st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        st = one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        st = one_pass()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    total_reads = n * a.steps * world
+    value = total_reads / el / 1e6
+
+    out = {
+        "metric": "Mreads/s through reorder stage", "value": round(value, 3), "unit": "Mreads/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "%d x %d bp single-end synthetic reads per GPU (uniform genome %d bp, %dx coverage, "
+                        "%.1f%% substitutions, 50%% reverse-complemented), inputs resident in HBM as .dna records"
+                        % (n, L, G, a.coverage, a.err_ppm / 1e4),
+            "reads_per_gpu": n, "read_len": L, "chains": a.chains or "auto", "num_thr": a.num_thr,
+            "parallelism": "1 process per GPU, independent lanes" if world > 1 else "single GPU",
+            "stage_ms": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},
+            "unmatched": st["unmatched"], "singletons": st["n_single"], "rounds": st["rounds"],
+        },
+    }
+
+    if rank == 0 and world == 1 and not a.no_roofline:
+        # separate pass with per-launch HIP events on the search kernel + reference-equivalent work counters
+        sr = one_pass(collect_stats=True, time_search=True)
+        W = (2 * L - 1) // 64 + 1
+        alg = algorithmic_bytes_search(sr, W)
+        ms = sr["ms_search_kernel"]
+        launches = max(sr["search_launches"], 1)
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel": "sr::k_search", "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+            "algorithmic_bytes_per_launch": round(alg / launches, 1),
+            "algorithmic_bytes_per_read": round(alg / n, 1),
+            "work": {"probes": sr["probes"], "keyok": sr["keyok"], "cands": sr["cands"], "hits": sr["hits"]},
+        }
+    if rank == 0 and world == 1 and a.cpu_sample > 0:
+        # CPU baseline: the C restatement of the reference (-t 1 order), single thread, on a bounded
+        # sample of the same distribution (same generator, same coverage / error rate / read length).
+        from oracle import pyoracle as po
+        ns = min(a.cpu_sample, n)
+        dna = spring_amd.synth_dna_host(ns, L, max(ns * L // a.coverage, 2 * L), seed, a.err_ppm)
+        t0 = time.perf_counter()
+        read, ln = po.load_dna(dna, ns, L)
+        r = po.reorder_serial(read, ln, L)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(ns / tc / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": "%d x %d bp reads, same generator/coverage/error rate, C oracle (orc_reorder_serial: load + "
+                      "dictionaries + reorder), %.1f s" % (ns, L, tc),
+            "host_cpus": os.cpu_count(),
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,9 @@ typedef struct {
 
 void spring_reorder_default_opts(spring_reorder_opts *o);
 const char *spring_reorder_last_error(void);
+/* Contexts return their device blocks to a per-device pool on destroy (repeated runs then skip
+ * hipMalloc/hipFree, which cost about as much as the stage at 100 M reads); this releases the pool. */
+void spring_reorder_trim_pool(void);
 
 /* ---------------------------------------------------------------------------
  * Drop-in stage: replaces

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libspring_reorder_hip.so")
 
 EXPORTS = [
-    "spring_reorder_default_opts", "spring_reorder_last_error", "spring_reorder_run", "spring_reorder_create",
+    "spring_reorder_default_opts", "spring_reorder_last_error", "spring_reorder_trim_pool", "spring_reorder_run", "spring_reorder_create",
     "spring_reorder_destroy", "spring_reorder_load_dna", "spring_reorder_load_dna_device",
     "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
@@ -53,6 +53,7 @@ def lib():
     vp, u8p = C.c_void_p, C.c_void_p
     L.spring_reorder_default_opts.argtypes = [C.POINTER(Opts)]
     L.spring_reorder_last_error.restype = C.c_char_p
+    L.spring_reorder_trim_pool.restype = None
     L.spring_reorder_run.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
                                      C.POINTER(Opts)]
     L.spring_reorder_create.argtypes = [C.POINTER(vp), C.POINTER(Opts)]
@@ -76,7 +77,7 @@ def lib():
     L.spring_reorder_download_dna.argtypes = [vp, u8p, C.c_size_t]
     for name in EXPORTS:
         if name not in ("spring_reorder_last_error", "spring_reorder_destroy", "spring_synth_dna_bytes",
-                        "spring_reorder_default_opts"):
+                        "spring_reorder_default_opts", "spring_reorder_trim_pool"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

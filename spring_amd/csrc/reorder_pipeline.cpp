@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,6 +43,62 @@ using namespace sr;
       return fail(SPRING_REORDER_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// ---------------------------------------------------------------- device pool
+// hipMalloc/hipFree of the ~30 GB a 100 M-read run needs cost ~1 s per run, as much as
+// the stage itself.  Blocks released by a context are cached per device and handed to
+// the next context (sizes rounded to 2 MiB so repeated runs hit exactly).
+// spring_reorder_trim_pool() gives the memory back to the driver.
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_blocks;
+  std::unordered_map<void *, size_t> sizes;
+  size_t cached = 0;
+};
+DevPool g_pool[16];
+constexpr size_t POOL_GRAN = 2u << 20;
+
+hipError_t pool_alloc(int dev, size_t bytes, void **out, size_t *actual) {
+  const size_t want = (bytes + POOL_GRAN - 1) / POOL_GRAN * POOL_GRAN;
+  DevPool &p = g_pool[dev & 15];
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.free_blocks.lower_bound(want);
+    if (it != p.free_blocks.end() && it->first <= want + want / 4 + POOL_GRAN) {
+      *out = it->second; *actual = it->first;
+      p.cached -= it->first;
+      p.free_blocks.erase(it);
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, want);
+  if (e != hipSuccess) {  // give cached blocks back and retry once
+    std::lock_guard<std::mutex> lk(p.mu);
+    for (auto &kv : p.free_blocks) { (void)hipFree(kv.second); p.sizes.erase(kv.second); }
+    p.free_blocks.clear(); p.cached = 0;
+    (void)hipGetLastError();
+    e = hipMalloc(out, want);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.sizes[*out] = want;
+    *actual = want;
+  }
+  return e;
+}
+void pool_free(int dev, void *ptr) {
+  DevPool &p = g_pool[dev & 15];
+  std::lock_guard<std::mutex> lk(p.mu);
+  auto it = p.sizes.find(ptr);
+  if (it == p.sizes.end()) { (void)hipFree(ptr); return; }
+  p.free_blocks.emplace(it->second, ptr);
+  p.cached += it->second;
+}
+}  // namespace
+
 enum { ST_CREATED = 0, ST_LOADED = 1, ST_DICT = 2, ST_CHAINS = 3, ST_FINAL = 4 };
 
 struct DictDev {
@@ -57,7 +115,7 @@ struct spring_reorder_ctx {
   hipStream_t st = nullptr;
   int stage = ST_CREATED;
   std::vector<void *> allocs;
-  uint64_t dev_bytes = 0;
+  uint64_t dev_bytes = 0, peak_bytes = 0;
   // input
   uint8_t *d_dna = nullptr;  // record stream (owned unless borrowed)
   bool dna_borrowed = false;
@@ -79,17 +137,25 @@ struct spring_reorder_ctx {
 
   int dmalloc(void **p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
+    size_t actual = 0;
+    hipError_t e = pool_alloc(dev, bytes, p, &actual);
     if (e != hipSuccess) return fail(SPRING_REORDER_E_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     allocs.push_back(*p);
-    dev_bytes += bytes;
+    dev_bytes += actual;
+    peak_bytes = std::max(peak_bytes, dev_bytes);
     return 0;
   }
   void dfree(void *p) {
     if (!p) return;
     auto it = std::find(allocs.begin(), allocs.end(), p);
     if (it != allocs.end()) allocs.erase(it);
-    (void)hipFree(p);
+    {
+      std::lock_guard<std::mutex> lk(g_pool[dev & 15].mu);
+      auto sz = g_pool[dev & 15].sizes.find(p);
+      if (sz != g_pool[dev & 15].sizes.end()) dev_bytes -= std::min<uint64_t>(dev_bytes, sz->second);
+    }
+    (void)hipStreamSynchronize(st);  // the block may be handed to another stream next
+    pool_free(dev, p);
   }
 };
 
@@ -109,6 +175,18 @@ void spring_reorder_default_opts(spring_reorder_opts *o) {
 }
 
 const char *spring_reorder_last_error(void) { return g_err.c_str(); }
+
+void spring_reorder_trim_pool(void) {
+  for (int d = 0; d < 16; d++) {
+    DevPool &p = g_pool[d];
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.free_blocks.empty()) continue;
+    (void)hipSetDevice(d);
+    for (auto &kv : p.free_blocks) { (void)hipFree(kv.second); p.sizes.erase(kv.second); }
+    p.free_blocks.clear();
+    p.cached = 0;
+  }
+}
 
 int spring_reorder_create(spring_reorder_ctx **out, const spring_reorder_opts *opts) {
   if (!out) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
@@ -138,7 +216,7 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  for (void *p : ctx->allocs) (void)hipFree(p);
+  for (void *p : ctx->allocs) pool_free(ctx->dev, p);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
@@ -314,7 +392,17 @@ static uint64_t pow2ceil(uint64_t x) {
   return p;
 }
 
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define DBG_T(label)                                                                         \
+  do {                                                                                       \
+    if (dbg) { (void)hipStreamSynchronize(st); double t_ = now_ms(); fprintf(stderr, "[dict] %-14s %8.2f ms\n", label, t_ - t_last); t_last = t_; } \
+  } while (0)
+
 int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
+  const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;
+  double t_last = now_ms();
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage != ST_LOADED) return fail(SPRING_REORDER_E_STATE, "build_dict: load reads first");
   HIPCHK(hipSetDevice(ctx->dev));
@@ -361,15 +449,20 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     DMALLOC(k_out, (size_t)m * 8);
     DMALLOC(v_in, (size_t)m * 4);
     DMALLOC(d.ids, (size_t)m * 4);
+    DBG_T("alloc keys");
     launch_keys(st, ctx->d_reads, ctx->d_lens, ctx->uniform ? nullptr : d_slot, n, ctx->S, d.start, d.end, k_in, v_in);
     HIPCHK(hipGetLastError());
+    DBG_T("k_keys");
     const unsigned end_bit = (unsigned)(2 * (d.end - d.start + 1));
     // stable LSD radix sort: equal keys keep ascending read id (bitset_util.h:192-210)
     tmp_bytes = 0;
     HIPCHK(sort_pairs(st, nullptr, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
     DMALLOC(d_tmp, tmp_bytes);
+    DBG_T("alloc sorttmp");
     HIPCHK(sort_pairs(st, d_tmp, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
+    DBG_T("sort");
     ctx->dfree(d_tmp); d_tmp = nullptr;
+    DBG_T("free sorttmp");
     // unique keys + run lengths (bitset_util.h:122-127), reuse k_in for the unique keys
     DMALLOC(cnt, (size_t)m * 4);
     DMALLOC(d_nruns, 16);
@@ -382,6 +475,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     HIPCHK(hipStreamSynchronize(st));
     ctx->dfree(d_tmp); d_tmp = nullptr;
     d.numkeys = numkeys;
+    DBG_T("rle");
     DMALLOC(ustart, (size_t)numkeys * 4);
     tmp_bytes = 0;
     HIPCHK(excl_scan_u32(st, nullptr, tmp_bytes, cnt, ustart, numkeys));
@@ -390,13 +484,18 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     // exact hash table, 4-slot 64-byte buckets, load <= 0.4
     const uint64_t nb = pow2ceil(std::max<uint64_t>(1, ((uint64_t)numkeys * 10 + 15) / 16));
     d.bmask = nb - 1;
+    DBG_T("scan");
     DMALLOC(d.tab, nb * 64);
+    DBG_T("alloc tab");
     HIPCHK(hipMemsetAsync(d.tab, 0, nb * 64, st));
+    DBG_T("memset tab");
     launch_tab_insert(st, k_in, ustart, cnt, numkeys, d.tab, d.bmask);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    DBG_T("insert");
     ctx->dfree(d_tmp); ctx->dfree(k_in); ctx->dfree(k_out); ctx->dfree(v_in); ctx->dfree(cnt);
     ctx->dfree(ustart); ctx->dfree(d_nruns);
+    DBG_T("free temps");
     if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
   }
   HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -440,7 +539,7 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
 static uint32_t auto_chains(uint32_t n) {
   uint64_t k = n >> 10;  // ~1000 reads per chain
   if (k < 1) k = 1;
-  if (k > 16384) k = 16384;
+  if (k > 65536) k = 65536;
   return (uint32_t)k;
 }
 
@@ -621,7 +720,7 @@ int spring_reorder_get_stats(spring_reorder_ctx *ctx, spring_reorder_stats *out)
   s.ms_total = s.ms_unpack + s.ms_dict + s.ms_chains + s.ms_finalize;
   for (int l = 0; l < 2; l++) { s.numkeys[l] = ctx->dict[l].numkeys; s.dict_numreads[l] = ctx->dict[l].numreads; }
   s.n_reads = ctx->n;
-  s.device_bytes = ctx->dev_bytes;
+  s.device_bytes = ctx->peak_bytes;
   *out = s;
   return 0;
 }
