@@ -76,30 +76,30 @@ __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uin
   return (taken[rid >> 6] >> (rid & 63)) & 1ull;
 }
 
-// exact key -> (start,count) map: buckets of 4 slots, one 64-byte line each:
-// [k0 k1 k2 k3 m0 m1 m2 m3], m = start | count<<32, m==0 marks an empty slot.
-// Replaces boomphf lookup + findpos + key re-check (reorder.h:271-285).
-__device__ __forceinline__ bool tab_lookup(const uint64_t *__restrict__ tab, uint64_t bmask, uint64_t key,
-                                           uint32_t &start, uint32_t &count) {
-  uint64_t b = mix64(key) & bmask;
+// exact key -> (start,count) map in two levels (replaces boomphf lookup + findpos + key
+// re-check, reorder.h:271-285):
+//   fpt : 32-byte buckets [fp0 fp1 fp2 fp3 | idx0 idx1 idx2 idx3], fp = high 32 hash bits,
+//         idx = unique-key index + 1 (0 = empty slot).  One bucket = one 32-byte HBM fetch,
+//         the granularity random reads actually cost on MI355X (tools/random_gather_bench.hip:
+//         64 B/lane random reads run at 20 G/s, <= 32 B/lane at 48 G/s).  98 % of probes are
+//         absent keys and end here after a single fetch.
+//   urec: 16-byte record {key, start, count} per unique key, read only on a fingerprint match.
+__device__ __forceinline__ bool tab_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec,
+                                           uint64_t bmask, uint64_t key, uint32_t &start, uint32_t &count) {
+  const uint64_t h = mix64(key);
+  const uint32_t fp = (uint32_t)(h >> 32);
+  uint64_t b = h & bmask;
   for (;;) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(tab + b * 8);
-    ulonglong2 k01 = p[0], k23 = p[1], m01 = p[2], m23 = p[3];
-    uint64_t m;
-    if (m01.x == 0) return false;
-    if (k01.x == key) { m = m01.x; goto found; }
-    if (m01.y == 0) return false;
-    if (k01.y == key) { m = m01.y; goto found; }
-    if (m23.x == 0) return false;
-    if (k23.x == key) { m = m23.x; goto found; }
-    if (m23.y == 0) return false;
-    if (k23.y == key) { m = m23.y; goto found; }
+    const uint4 f = fpt[b * 2], x = fpt[b * 2 + 1];
+#define SLOT(F, I)                                                        \
+    if ((I) == 0) return false;                                           \
+    if ((F) == fp) {                                                      \
+      const ulonglong2 r = urec[(I) - 1];                                 \
+      if (r.x == key) { start = (uint32_t)r.y; count = (uint32_t)(r.y >> 32); return true; } \
+    }
+    SLOT(f.x, x.x) SLOT(f.y, x.y) SLOT(f.z, x.z) SLOT(f.w, x.w)
+#undef SLOT
     b = (b + 1) & bmask;
-    continue;
-  found:
-    start = (uint32_t)m;
-    count = (uint32_t)(m >> 32);
-    return true;
   }
 }
 
@@ -152,19 +152,22 @@ __global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__res
 }
 
 // ------------------------------------------------ K3 table insert (bitset_util.h:122-217)
+// one thread per unique key: writes its {key,start,count} record and claims a bucket slot.
 __global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
-                             const uint32_t *__restrict__ ucount, uint32_t numkeys, uint64_t *tab,
-                             uint64_t bmask) {
+                             const uint32_t *__restrict__ ucount, uint32_t numkeys, uint32_t *fpt,
+                             ulonglong2 *__restrict__ urec, uint64_t bmask) {
   uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= numkeys) return;
-  uint64_t key = ukeys[u];
-  uint64_t meta = (uint64_t)ustart[u] | ((uint64_t)ucount[u] << 32);
-  uint64_t b = mix64(key) & bmask;
+  const uint64_t key = ukeys[u];
+  urec[u] = make_ulonglong2(key, (uint64_t)ustart[u] | ((uint64_t)ucount[u] << 32));
+  const uint64_t h = mix64(key);
+  const uint32_t fp = (uint32_t)(h >> 32);
+  uint64_t b = h & bmask;
   for (;;) {
-    unsigned long long *m = reinterpret_cast<unsigned long long *>(tab + b * 8 + 4);
+    uint32_t *bk = fpt + b * 8;
     for (int s = 0; s < 4; s++) {
-      if (atomicCAS(m + s, 0ull, (unsigned long long)meta) == 0ull) {
-        tab[b * 8 + s] = key;
+      if (atomicCAS(bk + 4 + s, 0u, u + 1) == 0u) {
+        bk[s] = fp;
         return;
       }
     }
@@ -172,12 +175,13 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t 
   }
 }
 
-__global__ void k_dict_lookup(const uint64_t *__restrict__ tab, uint64_t bmask, const uint64_t *__restrict__ keys,
-                              uint32_t nkeys, uint32_t *__restrict__ start, uint32_t *__restrict__ count) {
+__global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, uint64_t bmask,
+                              const uint64_t *__restrict__ keys, uint32_t nkeys, uint32_t *__restrict__ start,
+                              uint32_t *__restrict__ count) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nkeys) return;
   uint32_t s = 0, c = 0xffffffffu;
-  if (!tab_lookup(tab, bmask, keys[i], s, c)) { s = 0; c = 0xffffffffu; }
+  if (!tab_lookup(fpt, urec, bmask, keys[i], s, c)) { s = 0; c = 0xffffffffu; }
   start[i] = s;
   count[i] = c;
 }
@@ -566,7 +570,8 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   const int ds = P.dstart[l], de = P.dend[l];
   const int klen2 = 2 * (de - ds + 1);
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
-  const uint64_t *__restrict__ tab = P.tab[l];
+  const uint4 *__restrict__ fpt = P.fpt[l];
+  const ulonglong2 *__restrict__ urec = P.urec[l];
   const uint64_t bmask = P.bmask[l];
   const uint32_t *__restrict__ ids = P.ids[l];
   const bool have_keys = P.numkeys[l] > 0;
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
       const int kb = rev ? 2 * (ds - shift) : 2 * (ds + shift);
       const uint64_t key = lds_window(sx, kb) & kmask;
       uint32_t start, count;
-      if (tab_lookup(tab, bmask, key, start, count)) {
+      if (tab_lookup(fpt, urec, bmask, key, start, count)) {
         const int bitshift = rev ? -2 * shift : 2 * shift;
         const int lo = rev ? shift : 0;
         const int mref = rev ? ref_len + shift : ref_len - shift;
@@ -864,14 +869,15 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
   hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
 }
 void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       uint32_t numkeys, uint64_t *tab, uint64_t bmask) {
+                       uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask) {
   if (!numkeys) return;
-  hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, numkeys, tab, bmask);
+  hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, numkeys,
+                     reinterpret_cast<uint32_t *>(fpt), urec, bmask);
 }
-void launch_dict_lookup(hipStream_t st, const uint64_t *tab, uint64_t bmask, const uint64_t *keys, uint32_t nkeys,
-                        uint32_t *start, uint32_t *count) {
+void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
+                        const uint64_t *keys, uint32_t nkeys, uint32_t *start, uint32_t *count) {
   if (!nkeys) return;
-  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, tab, bmask, keys, nkeys, start, count);
+  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bmask, keys, nkeys, start, count);
 }
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
   if (!n) return;

@@ -105,7 +105,8 @@ struct DictDev {
   int start = 0, end = 0;
   uint32_t numkeys = 0, numreads = 0;
   uint64_t bmask = 0;
-  uint64_t *tab = nullptr;
+  uint4 *fpt = nullptr;
+  ulonglong2 *urec = nullptr;
   uint32_t *ids = nullptr;
 };
 
@@ -437,8 +438,9 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     d.numkeys = 0;
     if (m == 0) {
       d.bmask = 0;
-      DMALLOC(d.tab, 64);
-      HIPCHK(hipMemsetAsync(d.tab, 0, 64, st));
+      DMALLOC(d.fpt, 64);
+      HIPCHK(hipMemsetAsync(d.fpt, 0, 64, st));
+      DMALLOC(d.urec, 16);
       DMALLOC(d.ids, 16);
       if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
       continue;
@@ -481,15 +483,16 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     HIPCHK(excl_scan_u32(st, nullptr, tmp_bytes, cnt, ustart, numkeys));
     DMALLOC(d_tmp, tmp_bytes);
     HIPCHK(excl_scan_u32(st, d_tmp, tmp_bytes, cnt, ustart, numkeys));
-    // exact hash table, 4-slot 64-byte buckets, load <= 0.4
+    // exact map: 4-slot 32-byte fingerprint buckets (load <= 0.4) + 16-byte records
     const uint64_t nb = pow2ceil(std::max<uint64_t>(1, ((uint64_t)numkeys * 10 + 15) / 16));
     d.bmask = nb - 1;
     DBG_T("scan");
-    DMALLOC(d.tab, nb * 64);
+    DMALLOC(d.fpt, nb * 32);
+    DMALLOC(d.urec, (size_t)numkeys * 16);
     DBG_T("alloc tab");
-    HIPCHK(hipMemsetAsync(d.tab, 0, nb * 64, st));
+    HIPCHK(hipMemsetAsync(d.fpt, 0, nb * 32, st));
     DBG_T("memset tab");
-    launch_tab_insert(st, k_in, ustart, cnt, numkeys, d.tab, d.bmask);
+    launch_tab_insert(st, k_in, ustart, cnt, numkeys, d.fpt, d.urec, d.bmask);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     DBG_T("insert");
@@ -517,7 +520,7 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
   std::vector<uint32_t> hs(nkeys), hc(nkeys), hids(d.numreads);
   if (nkeys) {
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)nkeys * 8, hipMemcpyHostToDevice, ctx->st));
-    launch_dict_lookup(ctx->st, d.tab, d.bmask, dk, nkeys, ds, dc);
+    launch_dict_lookup(ctx->st, d.fpt, d.urec, d.bmask, dk, nkeys, ds, dc);
     HIPCHK(hipMemcpyAsync(hs.data(), ds, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(hc.data(), dc, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
   }
@@ -557,7 +560,8 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   P.uniform_len = ctx->uniform ? 1 : 0;
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
-    P.tab[l] = ctx->dict[l].tab; P.bmask[l] = ctx->dict[l].bmask; P.ids[l] = ctx->dict[l].ids;
+    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bmask[l] = ctx->dict[l].bmask;
+    P.ids[l] = ctx->dict[l].ids;
   }
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
   const size_t nn = std::max<uint32_t>(n, 1);
