@@ -60,8 +60,8 @@ struct DevParams {
   // dictionaries (reorder.h:751-759)
   int dstart[2], dend[2];
   uint32_t numkeys[2];
-  const uint4 *fpt[2];        // fingerprint buckets (32 B each)
-  const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key
+  const uint4 *fpt[2];        // buckets [tag x4 | payload x4], 32 B each
+  const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key (multi-read bins)
   uint64_t bmask[2];
   const uint32_t *ids[2];
   // shared mutable state
@@ -87,9 +87,10 @@ void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int d
 void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
                  int S, int dstart, int dend, uint64_t *keys, uint32_t *vals);
 void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask);
+                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask);
 void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
-                        const uint64_t *keys, uint32_t nkeys, uint32_t *start, uint32_t *count);
+                        const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
+                        uint32_t *start, uint32_t *count);
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
 void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n);
 void launch_init_chains(hipStream_t st, const DevParams &P);

@@ -76,31 +76,42 @@ __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uin
   return (taken[rid >> 6] >> (rid & 63)) & 1ull;
 }
 
-// exact key -> (start,count) map in two levels (replaces boomphf lookup + findpos + key
-// re-check, reorder.h:271-285):
-//   fpt : 32-byte buckets [fp0 fp1 fp2 fp3 | idx0 idx1 idx2 idx3], fp = high 32 hash bits,
-//         idx = unique-key index + 1 (0 = empty slot).  One bucket = one 32-byte HBM fetch,
-//         the granularity random reads actually cost on MI355X (tools/random_gather_bench.hip:
-//         64 B/lane random reads run at 20 G/s, <= 32 B/lane at 48 G/s).  98 % of probes are
-//         absent keys and end here after a single fetch.
-//   urec: 16-byte record {key, start, count} per unique key, read only on a fingerprint match.
-__device__ __forceinline__ bool tab_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec,
-                                           uint64_t bmask, uint64_t key, uint32_t &start, uint32_t &count) {
-  const uint64_t h = mix64(key);
-  const uint32_t fp = (uint32_t)(h >> 32);
+// exact key -> bin map in two levels (replaces boomphf lookup + findpos + key re-check,
+// reorder.h:271-285):
+//   fpt : 32-byte buckets [tag0..3 | pay0..3]; tag = (31-bit hash fingerprint << 1) | single,
+//         tag 0 = empty slot.  One bucket = one 32-byte HBM fetch, the granularity random reads
+//         actually cost on MI355X (tools/random_gather_bench.hip: 64 B/lane random reads run at
+//         20 G/s, <= 32 B/lane at 48 G/s).  98 % of probes are absent keys and end here.
+//   single = 1: the bin holds exactly one read and pay IS that read id; the key is verified
+//         against the read's own window (as the reference does with the first read of a bin,
+//         reorder.h:282-285), so the hot path is bucket -> read: no offsets/ids hops.
+//   single = 0: pay indexes urec, a 16-byte record {key, start | count << 32}.
+__device__ __forceinline__ uint32_t fp31_of(uint64_t h) {
+  const uint32_t f = (uint32_t)(h >> 33);
+  return f ? f : 1u;
+}
+// kind of the (skip+1)-th slot whose fingerprint matches: 0 = none (key absent), 1 = multi, 2 = single
+__device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, uint64_t bmask, uint64_t h, int skip,
+                                        uint32_t &pay) {
+  const uint32_t fp = fp31_of(h);
   uint64_t b = h & bmask;
   for (;;) {
-    const uint4 f = fpt[b * 2], x = fpt[b * 2 + 1];
-#define SLOT(F, I)                                                        \
-    if ((I) == 0) return false;                                           \
-    if ((F) == fp) {                                                      \
-      const ulonglong2 r = urec[(I) - 1];                                 \
-      if (r.x == key) { start = (uint32_t)r.y; count = (uint32_t)(r.y >> 32); return true; } \
-    }
-    SLOT(f.x, x.x) SLOT(f.y, x.y) SLOT(f.z, x.z) SLOT(f.w, x.w)
+    const uint4 t = fpt[b * 2], x = fpt[b * 2 + 1];
+#define SLOT(T, X)                                              \
+    if ((T) == 0) return 0;                                     \
+    if (((T) >> 1) == fp && skip-- == 0) { pay = (X); return 1 + (int)((T) & 1u); }
+    SLOT(t.x, x.x) SLOT(t.y, x.y) SLOT(t.z, x.z) SLOT(t.w, x.w)
 #undef SLOT
     b = (b + 1) & bmask;
   }
+}
+// dictionary window of a read straight from its limbs ((read & mask1) >> 2*start, bitset_util.h:94-95)
+__device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ r, int S, int dstart, int klen2) {
+  const int bitpos = 2 * dstart, li = bitpos >> 6, off = bitpos & 63;
+  uint64_t v = r[li] >> off;
+  if (off && li + 1 < S) v |= r[li + 1] << (64 - off);
+  if (klen2 < 64) v &= (1ull << klen2) - 1;
+  return v;
 }
 
 // ------------------------------------------------------- K1 unpack (readDnaFile)
@@ -154,20 +165,23 @@ __global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__res
 // ------------------------------------------------ K3 table insert (bitset_util.h:122-217)
 // one thread per unique key: writes its {key,start,count} record and claims a bucket slot.
 __global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
-                             const uint32_t *__restrict__ ucount, uint32_t numkeys, uint32_t *fpt,
-                             ulonglong2 *__restrict__ urec, uint64_t bmask) {
+                             const uint32_t *__restrict__ ucount, const uint32_t *__restrict__ ids,
+                             uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, uint64_t bmask) {
   uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= numkeys) return;
   const uint64_t key = ukeys[u];
-  urec[u] = make_ulonglong2(key, (uint64_t)ustart[u] | ((uint64_t)ucount[u] << 32));
+  const uint32_t st = ustart[u], cn = ucount[u];
+  urec[u] = make_ulonglong2(key, (uint64_t)st | ((uint64_t)cn << 32));
   const uint64_t h = mix64(key);
-  const uint32_t fp = (uint32_t)(h >> 32);
+  const bool single = cn == 1;
+  const uint32_t tag = (fp31_of(h) << 1) | (single ? 1u : 0u);
+  const uint32_t pay = single ? ids[st] : u;
   uint64_t b = h & bmask;
   for (;;) {
     uint32_t *bk = fpt + b * 8;
-    for (int s = 0; s < 4; s++) {
-      if (atomicCAS(bk + 4 + s, 0u, u + 1) == 0u) {
-        bk[s] = fp;
+    for (int sl = 0; sl < 4; sl++) {
+      if (atomicCAS(bk + sl, 0u, tag) == 0u) {
+        bk[4 + sl] = pay;
         return;
       }
     }
@@ -175,13 +189,30 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t 
   }
 }
 
+// test hook: start/count of the bin of each key; single-read bins report count = 1 | 0x80000000
+// and the read id in start[]
 __global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, uint64_t bmask,
+                              const uint64_t *__restrict__ reads, int S, int dstart, int klen2,
                               const uint64_t *__restrict__ keys, uint32_t nkeys, uint32_t *__restrict__ start,
                               uint32_t *__restrict__ count) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nkeys) return;
+  const uint64_t key = keys[i], h = mix64(key);
   uint32_t s = 0, c = 0xffffffffu;
-  if (!tab_lookup(fpt, urec, bmask, keys[i], s, c)) { s = 0; c = 0xffffffffu; }
+  for (int skip = 0;; skip++) {
+    uint32_t pay;
+    const int kind = tab_find(fpt, bmask, h, skip, pay);
+    if (kind == 0) break;
+    if (kind == 1) {
+      const ulonglong2 r = urec[pay];
+      if (r.x != key) continue;
+      s = (uint32_t)r.y; c = (uint32_t)(r.y >> 32);
+      break;
+    }
+    if (read_window(reads + (uint64_t)pay * S, S, dstart, klen2) != key) continue;
+    s = pay; c = 1u | 0x80000000u;
+    break;
+  }
   start[i] = s;
   count[i] = c;
 }
@@ -462,6 +493,101 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   }
 }
 
+// ---- one batch of 64 probes of search_match (reorder.h:246-318) by one wavefront.
+// lane = 4*(shift%16) + 2*rev + dict: lane order == the reference's priority order inside the
+// batch (shift, forward before reverse, dict 0 before 1), so the first set bit of the hit
+// ballot is the reference's winner.  STATS counts what the reference would have executed:
+// every valid probe up to and including the winner.
+struct BatchOut {
+  uint32_t found, rid, win, pad;
+  uint64_t st_p, st_k, st_c;
+};
+
+template <bool STATS>
+__device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev, int b,
+                                            int lane, int ref_len, BatchOut &out) {
+  const int W = P.W;
+  const int l = lane & 1, rev = (lane >> 1) & 1;
+  const int ds = P.dstart[l], de = P.dend[l];
+  const int klen2 = 2 * (de - ds + 1);
+  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
+  const uint4 *__restrict__ fpt = P.fpt[l];
+  const ulonglong2 *__restrict__ urec = P.urec[l];
+  const uint64_t bmask = P.bmask[l];
+  const uint32_t *__restrict__ ids = P.ids[l];
+  const bool have_keys = P.numkeys[l] > 0;
+  const uint64_t *sx = rev ? srev : sref;
+  const int shift = b * 16 + (lane >> 2);
+  bool valid = shift < P.maxshift;
+  if (!rev) valid = valid && (de + shift < ref_len);
+  else valid = valid && (de < ref_len + shift) && (ds > shift);
+  bool hit = false, keyok = false;
+  uint32_t rid = 0, ncand = 0;
+  if (valid && have_keys) {
+    const int kb = rev ? 2 * (ds - shift) : 2 * (ds + shift);
+    const uint64_t key = lds_window(sx, kb) & kmask;
+    const uint64_t hsh = mix64(key);
+    const int bitshift = rev ? -2 * shift : 2 * shift;
+    const int lo = rev ? shift : 0;
+    const int mref = rev ? ref_len + shift : ref_len - shift;
+    // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
+    // (mask[0][..] / mask[shift][..] of reorder.h:291-301)
+    auto within_thresh = [&](uint32_t r) -> bool {
+      const int clen = P.uniform_len ? P.L : (int)P.lens[r];
+      const int m = clen < mref ? clen : mref;
+      const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
+      const int blo = 2 * lo, bhi = 2 * m;
+      int hd = 0;
+      for (int i = 0; i < W; i++) {
+        const int s0 = i * 64;
+        if (s0 >= bhi) break;
+        if (s0 + 64 <= blo) continue;
+        uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
+        if (blo > s0) x &= ~0ull << (blo - s0);
+        if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
+        hd += __popcll(x);
+      }
+      return hd <= THRESH;
+    };
+    for (int skip = 0;; skip++) {
+      uint32_t pay;
+      const int kind = tab_find(fpt, bmask, hsh, skip, pay);
+      if (kind == 0) break;  // key absent
+      if (kind == 2) {       // single-read bin: pay is the read id
+        if (read_window(P.reads + (uint64_t)pay * P.S, P.S, ds, klen2) != key) continue;  // fingerprint collision
+        if (!is_taken(P.taken, pay)) {
+          keyok = true; ncand = 1;
+          if (within_thresh(pay)) { hit = true; rid = pay; }
+        }
+        break;
+      }
+      const ulonglong2 rec = urec[pay];
+      if (rec.x != key) continue;  // fingerprint collision
+      const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
+      int live = 0;
+      for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
+        const uint32_t r = ids[start + j];
+        if (is_taken(P.taken, r)) continue;
+        live++; keyok = true; ncand++;
+        if (within_thresh(r)) { hit = true; rid = r; break; }
+      }
+      break;
+    }
+  }
+  const uint64_t hm = __ballot(hit);
+  const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
+  out.found = hm != 0;
+  out.win = (uint32_t)win;
+  out.rid = (uint32_t)__shfl((int)rid, win, 64);
+  out.st_p = out.st_k = out.st_c = 0;
+  if (STATS) {
+    const uint64_t le = win == 63 ? ~0ull : ((1ull << (win + 1)) - 1);
+    out.st_p = __popcll(__ballot(valid) & le);
+    out.st_k = __popcll(__ballot(keyok) & le);
+    out.st_c = (uint64_t)wave_sum_i(lane <= win ? (int)ncand : 0);
+  }
+}
+
 // ------------------------------------------------------------ K4 search (phase A)
 //
 // One wavefront per chain.  search_match + shift loop (reorder.h:246-318,
@@ -562,91 +688,30 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     return;
   }
 
-  const int W = P.W, ref_len = h.ref_len;
   const uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
   wave_sync();
-
-  const int l = lane & 1, rev = (lane >> 1) & 1;
-  const int ds = P.dstart[l], de = P.dend[l];
-  const int klen2 = 2 * (de - ds + 1);
-  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
-  const uint4 *__restrict__ fpt = P.fpt[l];
-  const ulonglong2 *__restrict__ urec = P.urec[l];
-  const uint64_t bmask = P.bmask[l];
-  const uint32_t *__restrict__ ids = P.ids[l];
-  const bool have_keys = P.numkeys[l] > 0;
-  const uint64_t *sx = rev ? srev : sref;
+  // batches of 16 shifts in priority order; most chains match in batch 0
   const int nbatch = (P.maxshift + 15) >> 4;
+  BatchOut o;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
-  bool found = false;
-  uint32_t frid = 0;
-  int fshift = 0, frev = 0;
+  int wb = 0;
   for (int b = 0; b < nbatch; b++) {
-    const int shift = b * 16 + (lane >> 2);
-    bool valid = shift < P.maxshift;
-    if (!rev) valid = valid && (de + shift < ref_len);
-    else valid = valid && (de < ref_len + shift) && (ds > shift);
-    bool hit = false, keyok = false;
-    uint32_t rid = 0, ncand = 0;
-    if (valid && have_keys) {
-      const int kb = rev ? 2 * (ds - shift) : 2 * (ds + shift);
-      const uint64_t key = lds_window(sx, kb) & kmask;
-      uint32_t start, count;
-      if (tab_lookup(fpt, urec, bmask, key, start, count)) {
-        const int bitshift = rev ? -2 * shift : 2 * shift;
-        const int lo = rev ? shift : 0;
-        const int mref = rev ? ref_len + shift : ref_len - shift;
-        int live = 0;
-        for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
-          const uint32_t r = ids[start + j];
-          if (is_taken(P.taken, r)) continue;
-          live++; keyok = true; ncand++;
-          const int clen = P.uniform_len ? P.L : (int)P.lens[r];
-          const int m = clen < mref ? clen : mref;
-          const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
-          const int blo = 2 * lo, bhi = 2 * m;
-          int hd = 0;
-          for (int i = 0; i < W; i++) {
-            const int s0 = i * 64;
-            if (s0 >= bhi) break;
-            if (s0 + 64 <= blo) continue;
-            uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
-            if (blo > s0) x &= ~0ull << (blo - s0);
-            if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
-            hd += __popcll(x);
-          }
-          if (hd <= THRESH) { hit = true; rid = r; break; }
-        }
-      }
-    }
-    const uint64_t hm = __ballot(hit);
-    if (STATS) {  // what the reference would have executed: everything up to and including the winner
-      const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
-      const uint64_t le = win == 63 ? ~0ull : ((1ull << (win + 1)) - 1);
-      st_p += __popcll(__ballot(valid) & le);
-      st_k += __popcll(__ballot(keyok) & le);
-      st_c += (uint64_t)wave_sum_i(lane <= win ? (int)ncand : 0);
-    }
-    if (hm) {
-      const int win = __ffsll((unsigned long long)hm) - 1;
-      frid = (uint32_t)__shfl((int)rid, win, 64);
-      fshift = b * 16 + (win >> 2);
-      frev = (win >> 1) & 1;
-      found = true;
-      break;
-    }
+    probe_batch<STATS>(P, sref, srev, b, lane, h.ref_len, o);
+    st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
+    if (o.found) { wb = b; break; }
   }
   if (lane == 0) {
-    if (found) {
-      h.prop_kind = PROP_MATCH; h.prop_rid = frid; h.prop_shift = fshift; h.prop_rev = (uint8_t)frev;
-      atomicMin(&P.resv[frid], cid);
+    if (o.found) {
+      h.prop_kind = PROP_MATCH; h.prop_rid = o.rid; h.prop_shift = wb * 16 + (int)(o.win >> 2);
+      h.prop_rev = (uint8_t)((o.win >> 1) & 1);
+      atomicMin(&P.resv[o.rid], cid);
     } else {
       h.prop_kind = PROP_NONE;
     }
     store_hot(c, h);
     if (STATS) {
       c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c;
-      if (found) c->st_hits++;
+      if (o.found) c->st_hits++;
       if (new_iter) c->st_iter++;
     }
   }
@@ -869,15 +934,17 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
   hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
 }
 void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask) {
+                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask) {
   if (!numkeys) return;
-  hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, numkeys,
+  hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
                      reinterpret_cast<uint32_t *>(fpt), urec, bmask);
 }
 void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
-                        const uint64_t *keys, uint32_t nkeys, uint32_t *start, uint32_t *count) {
+                        const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
+                        uint32_t *start, uint32_t *count) {
   if (!nkeys) return;
-  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bmask, keys, nkeys, start, count);
+  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bmask, reads, S, dstart,
+                     2 * (dend - dstart + 1), keys, nkeys, start, count);
 }
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
   if (!n) return;

@@ -492,7 +492,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     DBG_T("alloc tab");
     HIPCHK(hipMemsetAsync(d.fpt, 0, nb * 32, st));
     DBG_T("memset tab");
-    launch_tab_insert(st, k_in, ustart, cnt, numkeys, d.fpt, d.urec, d.bmask);
+    launch_tab_insert(st, k_in, ustart, cnt, d.ids, numkeys, d.fpt, d.urec, d.bmask);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     DBG_T("insert");
@@ -520,7 +520,7 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
   std::vector<uint32_t> hs(nkeys), hc(nkeys), hids(d.numreads);
   if (nkeys) {
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)nkeys * 8, hipMemcpyHostToDevice, ctx->st));
-    launch_dict_lookup(ctx->st, d.fpt, d.urec, d.bmask, dk, nkeys, ds, dc);
+    launch_dict_lookup(ctx->st, d.fpt, d.urec, d.bmask, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
     HIPCHK(hipMemcpyAsync(hs.data(), ds, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(hc.data(), dc, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
   }
@@ -529,6 +529,12 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
   ctx->dfree(dk); ctx->dfree(ds); ctx->dfree(dc);
   size_t o = 0;
   for (uint32_t i = 0; i < nkeys; i++) {
+    if (hc[i] != 0xffffffffu && (hc[i] & 0x80000000u)) {  // single-read bin: the bucket holds the read id itself
+      bin_size[i] = 1;
+      if (o + 1 > ids_cap) return fail(SPRING_REORDER_E_ARG, "bin_ids too small");
+      bin_ids[o++] = hs[i];
+      continue;
+    }
     bin_size[i] = hc[i];
     if (hc[i] == 0xffffffffu) continue;
     if (o + hc[i] > ids_cap) return fail(SPRING_REORDER_E_ARG, "bin_ids too small");
