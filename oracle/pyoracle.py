@@ -49,6 +49,8 @@ def lib():
                                          C.POINTER(OrcOut), C.POINTER(OrcStats)]
         L.orc_reorder_rounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                          C.POINTER(OrcOut), C.POINTER(OrcStats)]
+        L.orc_reorder_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
+                                      C.POINTER(OrcOut), C.POINTER(OrcStats)]
         L.orc_write_dna_stream.restype = C.c_size_t
         L.orc_write_dna_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_uint64, C.c_void_p]
@@ -154,6 +156,18 @@ def reorder_rounds(read, ln, L, num_chains, num_thr=1):
     st = OrcStats()
     rc = lib().orc_reorder_rounds(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr,
                                   C.byref(o), C.byref(st))
+    assert rc == 0
+    return _finish(o, arrs, st)
+
+
+def reorder_omp(read, ln, L, num_threads):
+    """CPU-baseline port: free-running OpenMP threads (non-deterministic for T > 1, like the reference)."""
+    n = len(ln)
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    o, arrs = _alloc_out(n, num_threads)
+    st = OrcStats()
+    rc = lib().orc_reorder_omp(read.ctypes.data, ln.ctypes.data, n, L, num_threads, C.byref(o), C.byref(st))
     assert rc == 0
     return _finish(o, arrs, st)
 

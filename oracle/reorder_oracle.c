@@ -948,3 +948,224 @@ void orc_updaterefcount(const uint64_t *cur, int32_t *cnt, uint64_t *ref, uint64
   *ref_len = c->ref_len;
   free(c);
 }
+
+/* ------------------------------------------------ OpenMP port (CPU baseline only)
+ *
+ * Free-running threads like the reference's `-t T` (reorder.h:351-627): one greedy chain per
+ * thread, shared taken[] claimed with compare-and-swap where the reference uses try-locks, a
+ * per-thread remainingpos for seed picking.  Like the reference it is NOT deterministic for
+ * T > 1 (threads race for reads); it exists so bench.py can time a multi-core CPU run of the
+ * same algorithm on the GPU box.  Bins are immutable + taken[] (cheaper than the reference's
+ * locked bin compaction, so this baseline is if anything faster than the reference).
+ * Dictionary build: parallel key extraction + parallel LSD radix sort (the reference sorts
+ * serially with std::sort, bitset_util.h:123).
+ */
+#ifdef _OPENMP
+#include <omp.h>
+
+typedef struct { uint64_t k; uint32_t v; } kv_t;
+
+static void par_radix_sort(kv_t *a, kv_t *tmp, size_t n, int nbits, int T) {
+  const int passes = (nbits + 7) / 8;
+  size_t *hist = (size_t *)malloc(sizeof(size_t) * 256 * (size_t)T);
+  for (int p = 0; p < passes; p++) {
+    const int sh = 8 * p;
+    memset(hist, 0, sizeof(size_t) * 256 * (size_t)T);
+#pragma omp parallel num_threads(T)
+    {
+      const int t = omp_get_thread_num();
+      const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+      size_t *h = hist + 256 * (size_t)t;
+      for (size_t i = lo; i < hi; i++) h[(a[i].k >> sh) & 255]++;
+#pragma omp barrier
+#pragma omp single
+      {
+        size_t run = 0;
+        for (int d = 0; d < 256; d++)
+          for (int tt = 0; tt < T; tt++) { size_t c = hist[256 * (size_t)tt + d]; hist[256 * (size_t)tt + d] = run; run += c; }
+      }
+      for (size_t i = lo; i < hi; i++) tmp[h[(a[i].k >> sh) & 255]++] = a[i];
+    }
+    kv_t *sw = a; a = tmp; tmp = sw;
+  }
+  if (passes & 1) memcpy(tmp, a, sizeof(kv_t) * n); /* result must end in the caller's `a` */
+  free(hist);
+}
+
+static void dict_build_par(dict_t *d, const uint64_t *read, const uint16_t *len, uint32_t n, int W, int T) {
+  kv_t *a = (kv_t *)malloc(sizeof(kv_t) * (n ? n : 1)), *tmp = (kv_t *)malloc(sizeof(kv_t) * (n ? n : 1));
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < n; i++)
+    if ((int)len[i] > d->end) { a[m].v = i; m++; }
+#pragma omp parallel for num_threads(T) schedule(static)
+  for (uint32_t j = 0; j < m; j++) a[j].k = read_key(read + (size_t)a[j].v * W, W, d);
+  par_radix_sort(a, tmp, m, 2 * (d->end - d->start + 1), T);
+  d->dict_numreads = m;
+  d->keys = (uint64_t *)malloc(sizeof(uint64_t) * (m ? m : 1));
+  d->startpos = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)m + 1));
+  d->read_id = (uint32_t *)malloc(sizeof(uint32_t) * (m ? m : 1));
+  uint32_t nk = 0;
+  for (uint32_t j = 0; j < m; j++) {
+    if (j == 0 || a[j].k != a[j - 1].k) { d->keys[nk] = a[j].k; d->startpos[nk] = j; nk++; }
+    d->read_id[j] = a[j].v;
+  }
+  d->startpos[nk] = m;
+  d->numkeys = nk;
+  d->empty_bin = (uint8_t *)calloc(nk ? nk : 1, 1);
+  uint64_t cap = 2;
+  while (cap < 2ull * nk) cap <<= 1;
+  d->hmask = cap - 1;
+  d->htab = (uint32_t *)calloc(cap, sizeof(uint32_t));
+  for (uint32_t i = 0; i < nk; i++) {
+    uint64_t h = mix64(d->keys[i]) & d->hmask;
+    while (d->htab[h]) h = (h + 1) & d->hmask;
+    d->htab[h] = i + 1;
+  }
+  free(a); free(tmp);
+}
+
+static inline int claim(uint8_t *taken, uint32_t r) {
+  uint8_t z = 0;
+  return __atomic_compare_exchange_n(&taken[r], &z, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED);
+}
+
+int orc_reorder_omp(const uint64_t *read, const uint16_t *len, uint32_t n, int L, int T, orc_out *out,
+                    orc_stats *st) {
+  if (T <= 0) return -1;
+  rctx_t x;
+  memset(&x, 0, sizeof(x));
+  memset(st, 0, sizeof(*st));
+  x.read = read; x.len = len; x.n = n; x.L = L; x.W = orc_limbs(L); x.maxshift = L / 2;
+  const int W = x.W;
+  int s[2], e[2];
+  orc_dict_windows(L, s, e);
+  for (int l = 0; l < 2; l++) { x.dict[l].start = s[l]; x.dict[l].end = e[l]; }
+  if (n > 0) for (int l = 0; l < 2; l++) dict_build_par(&x.dict[l], read, len, n, W, T);
+  x.taken = (uint8_t *)calloc(n ? n : 1, 1);
+  outbuf_t *obs = (outbuf_t *)calloc((size_t)T, sizeof(outbuf_t));
+  uint64_t tot_unmatched = 0, tot_iter = 0;
+  uint32_t firstseed[1024];
+  for (int t = 0; t < T && t < 1024; t++) firstseed[t] = (uint32_t)t * (n / (uint32_t)T);
+#pragma omp parallel num_threads(T) reduction(+ : tot_unmatched, tot_iter)
+  {
+    const int tid = omp_get_thread_num();
+    outbuf_t *ob = &obs[tid];
+    orc_stats lst;
+    memset(&lst, 0, sizeof(lst));
+    cons_t *c = (cons_t *)calloc(1, sizeof(cons_t));
+    uint64_t ref[ORC_WMAX], revref[ORC_WMAX];
+    int done = 0, prev_unmatched = 0, left_search = 0, stop_searching = 0;
+    uint32_t num_reads_thr = 0, num_unmatched_past = 0;
+    int64_t current = firstseed[tid & 1023], prev = 0, first_rid = 0, ref_pos = 0, cur_read_pos = 0;
+    int64_t remainingpos = (int64_t)n - 1;
+    if (n == 0 || !claim(x.taken, (uint32_t)current)) done = 1;
+    else {
+      tot_unmatched++;
+      updaterefcount(read + (size_t)current * W, c, 1, 0, 0, len[current], L, W, &lst);
+      first_rid = prev = current; prev_unmatched = 1;
+    }
+    while (!done) {
+      tot_iter++;
+      if (num_reads_thr % 1000000 == 0) {
+        if ((float)num_unmatched_past > STOP_CRITERIA_REORDER * 1000000) stop_searching = 1;
+        num_unmatched_past = 0;
+      }
+      num_reads_thr++;
+      int flag = 0, fshift = 0, frev = 0;
+      uint32_t k = 0;
+      if (!stop_searching) {
+        memcpy(ref, c->ref, sizeof(uint64_t) * W);
+        memcpy(revref, c->revref, sizeof(uint64_t) * W);
+        for (int shift = 0; shift < x.maxshift && !flag; shift++) {
+          for (int rev = 0; rev < 2 && !flag; rev++) {
+            const uint64_t *r = rev ? revref : ref;
+            for (int l = 0; l < 2 && !flag; l++) {
+              dict_t *d = &x.dict[l];
+              if (!rev) { if (d->end + shift >= c->ref_len) continue; }
+              else { if (d->end >= c->ref_len + shift || d->start <= shift) continue; }
+              int64_t b = dict_lookup(d, read_key(r, W, d));
+              if (b < 0) continue;
+              int live = 0;
+              for (int64_t i = (int64_t)d->startpos[b + 1] - 1; i >= (int64_t)d->startpos[b] && live < MAX_SEARCH_REORDER; i--) {
+                uint32_t rid = d->read_id[i];
+                if (__atomic_load_n(&x.taken[rid], __ATOMIC_RELAXED)) continue;
+                live++;
+                int lo = rev ? shift : 0, m = rev ? c->ref_len + shift : c->ref_len - shift;
+                if ((int)len[rid] < m) m = len[rid];
+                if (hamming_range(r, read + (size_t)rid * W, W, lo, m) <= THRESH_REORDER && claim(x.taken, rid)) {
+                  k = rid; fshift = shift; frev = rev; flag = 1;
+                  break;
+                }
+              }
+            }
+          }
+          shl2(revref, W);
+          shr2(ref, W);
+        }
+      }
+      if (flag) {
+        current = k;
+        int ref_len_old = c->ref_len;
+        updaterefcount(read + (size_t)current * W, c, 0, frev, fshift, len[current], L, W, &lst);
+        char rcch;
+        if (!frev) {
+          if (!left_search) { cur_read_pos = ref_pos + fshift; ref_pos = cur_read_pos; }
+          else { cur_read_pos = ref_pos + ref_len_old - fshift - len[current]; ref_pos = ref_pos + ref_len_old - fshift - c->ref_len; }
+          rcch = left_search ? 'r' : 'd';
+        } else {
+          if (!left_search) { cur_read_pos = ref_pos + ref_len_old + fshift - len[current]; ref_pos = ref_pos + ref_len_old + fshift - c->ref_len; }
+          else { cur_read_pos = ref_pos - fshift; ref_pos = cur_read_pos; }
+          rcch = left_search ? 'd' : 'r';
+        }
+        if (prev_unmatched) ob_push(ob, (uint32_t)prev, 'd', '0', 0, len[prev]);
+        ob_push(ob, (uint32_t)current, rcch, '1', cur_read_pos, len[current]);
+        prev_unmatched = 0;
+      } else {
+        num_unmatched_past++;
+        if (!left_search) {
+          left_search = 1;
+          updaterefcount(read + (size_t)first_rid * W, c, 1, 1, 0, len[first_rid], L, W, &lst);
+          ref_pos = 0; cur_read_pos = 0;
+        } else {
+          left_search = 0;
+          int got = 0;
+          for (int64_t j = remainingpos; j >= 0; j--) {
+            if (!__atomic_load_n(&x.taken[j], __ATOMIC_RELAXED) && claim(x.taken, (uint32_t)j)) {
+              current = j; remainingpos = j - 1; got = 1; tot_unmatched++;
+              break;
+            }
+          }
+          if (prev_unmatched) ob_push_s(ob, (uint32_t)prev);
+          if (!got) done = 1;
+          else {
+            updaterefcount(read + (size_t)current * W, c, 1, 0, 0, len[current], L, W, &lst);
+            ref_pos = 0; cur_read_pos = 0; prev_unmatched = 1; first_rid = current; prev = current;
+          }
+        }
+      }
+    }
+    free(c);
+  }
+  uint64_t nm = 0, ns = 0;
+  for (int t = 0; t < T; t++) {
+    outbuf_t *o = &obs[t];
+    if (out->tid_off) out->tid_off[t] = nm;
+    if (out->tid_off_s) out->tid_off_s[t] = ns;
+    memcpy(out->order + nm, o->order, o->n * sizeof(uint32_t));
+    memcpy(out->rc + nm, o->rc, o->n);
+    memcpy(out->flag + nm, o->flag, o->n);
+    memcpy(out->pos + nm, o->pos, o->n * sizeof(int64_t));
+    memcpy(out->rlen + nm, o->rlen, o->n * sizeof(uint16_t));
+    memcpy(out->order_s + ns, o->order_s, o->ns * sizeof(uint32_t));
+    nm += o->n; ns += o->ns;
+    ob_free(o);
+  }
+  if (out->tid_off) out->tid_off[T] = nm;
+  if (out->tid_off_s) out->tid_off_s[T] = ns;
+  out->n_matched = nm; out->n_single = ns;
+  st->unmatched = tot_unmatched; st->iterations = tot_iter;
+  free(obs); free(x.taken);
+  if (n > 0) for (int l = 0; l < 2; l++) dict_free(&x.dict[l]);
+  return 0;
+}
+#endif /* _OPENMP */

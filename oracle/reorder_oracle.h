@@ -78,6 +78,11 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
 int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
                        uint32_t num_chains, int num_thr, orc_out *out, orc_stats *st);
 
+/* CPU-baseline port: T free-running OpenMP threads like the reference's `-t T`; NOT deterministic
+ * for T > 1 (like the reference).  Outputs laid out per thread (tid_off has T+1 entries). */
+int orc_reorder_omp(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen, int num_threads,
+                    orc_out *out, orc_stats *st);
+
 /* writetofile (reorder.h:643-730): byte stream of temp.dna.<tid> for a slice
  * of the matched stream (rc may be NULL => all 'd', i.e. the singleton file).
  * Returns bytes written into dst (capacity must be >= cnt*(2+ceil(L/4))). */

@@ -209,3 +209,39 @@ def test_1M_150bp_many_chains_vs_rounds_oracle():
     got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=K, num_thr=T))
     _same(got, want, "1M150")
     check_invariants(got, read, ln, L, n)
+
+
+def test_full_size_properties_100M_150bp():
+    """BASELINE config 3 at full size: size-independent properties of the output (the oracle cannot
+    run 100 M reads in test time): permutation of the clean reads, flag/RC/pos/length consistency,
+    per-tid streams made of whole contigs, determinism across two runs."""
+    import ctypes as C
+    import torch
+    sa = _sa()
+    from spring_amd import _lib
+    L_ = _lib.lib()
+    n, L, T = 100_000_000, 150, 8
+    nb = L_.spring_synth_dna_bytes(n, L)
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    assert L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, n * L // 25, 11, 10000) == 0
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):
+        with sa.ReorderStage(sa.ReorderOpts(num_thr=T)) as s:
+            s.load_dna_device(buf.data_ptr(), nb, n, L, True)
+            outs.append(s.run().streams())
+    a, b = outs
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    seen = np.zeros(n, dtype=np.uint8)
+    seen[a["order"]] += 1
+    seen[a["order_s"]] += 1
+    assert len(a["order"]) + len(a["order_s"]) == n and seen.min() == 1 and seen.max() == 1
+    f0 = a["flag"] == ord("0")
+    assert np.all(a["pos"][f0] == 0) and np.all(a["rc"][f0] == ord("d")) and np.all(a["rlen"] == L)
+    toff = [int(x) for x in a["tid_off"]]
+    for lo, hi in zip(toff[:-1], toff[1:]):
+        fl = a["flag"][lo:hi]
+        assert fl[0] == ord("0") and fl[-1] == ord("1")
+        assert not np.any((fl[:-1] == ord("0")) & (fl[1:] == ord("0")))
+    assert a["stats"]["unmatched"] == int(f0.sum()) + len(a["order_s"])

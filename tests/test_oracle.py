@@ -129,3 +129,17 @@ def test_golden_fixtures(name):
         b = po.reorder_rounds(read, ln, L, K, 2)
         for k in KEYS:
             assert np.array_equal(b[k], g["K%d_%s" % (K, k)]), (name, K, k)
+
+
+@pytest.mark.parametrize("name", ["syn5k_150", "var2k", "heavy", "repeat10k"])
+@pytest.mark.parametrize("T", [1, 4])
+def test_openmp_port_invariants(name, T):
+    """CPU-baseline port (free-running threads, non-deterministic for T > 1 like the reference):
+    T = 1 equals the serial restatement; any T yields a valid reordering."""
+    read, ln, n, L = _load(name)
+    r = po.reorder_omp(read, ln, L, T)
+    check_invariants(r, read, ln, L, n)
+    if T == 1:
+        a = po.reorder_serial(read, ln, L)
+        for k in KEYS:
+            assert np.array_equal(a[k], r[k]), (name, k)
