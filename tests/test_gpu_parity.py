@@ -215,20 +215,12 @@ def test_full_size_properties_100M_150bp():
     """BASELINE config 3 at full size: size-independent properties of the output (the oracle cannot
     run 100 M reads in test time): permutation of the clean reads, flag/RC/pos/length consistency,
     per-tid streams made of whole contigs, determinism across two runs."""
-    import ctypes as C
-    import torch
     sa = _sa()
-    from spring_amd import _lib
-    L_ = _lib.lib()
     n, L, T = 100_000_000, 150, 8
-    nb = L_.spring_synth_dna_bytes(n, L)
-    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    assert L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, n * L // 25, 11, 10000) == 0
-    torch.cuda.synchronize()
     outs = []
     for _ in range(2):
         with sa.ReorderStage(sa.ReorderOpts(num_thr=T)) as s:
-            s.load_dna_device(buf.data_ptr(), nb, n, L, True)
+            s.load_synth(n, L, n * L // 25, 11, 10000)  # counter-based generator: same bytes both times
             outs.append(s.run().streams())
     a, b = outs
     for k in KEYS:
