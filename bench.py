@@ -54,22 +54,16 @@ def main():
     from spring_amd import _lib
     L_ = _lib.lib()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+    from spring_amd.lanes import Lanes
+    lanes = Lanes()  # one process per GPU; nccl (= RCCL) when WORLD_SIZE > 1
+    world, rank = lanes.world, lanes.rank
+    if world == 1:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
 
     n, L = a.reads, a.readlen
     G = max(n * L // a.coverage, 2 * L)
-    seed = 11 + 1000 * rank  # every rank (lane) has its own genome and reads
+    seed = lanes.lane_seed(11)  # every rank (lane) has its own genome and reads
     nb = L_.spring_synth_dna_bytes(n, L)
     buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
     rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, seed, a.err_ppm)
@@ -84,24 +78,7 @@ def main():
         s.close()
         return st
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        st = one_pass()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        st = one_pass()
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el, st = lanes.timed_steps(one_pass, a.steps, a.warmup)
     total_reads = n * a.steps * world
     value = total_reads / el / 1e6
 
@@ -187,8 +164,7 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    lanes.close()
 
 
 if __name__ == "__main__":
