@@ -106,6 +106,24 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx);
  * lock-step rounds (search_match reorder.h:246-318, updaterefcount :110-220). */
 int spring_reorder_run_chains(spring_reorder_ctx *ctx);
 
+/* ---- single-pool multi-GPU (one process per GPU).  Every rank loads the same
+ * reads and builds the same dictionaries; rank r owns chains [r*K/world, (r+1)*K/world), K =
+ * total_chains.  Per round: mg_search -> caller all-gathers the proposal words (mg_slice says which
+ * bytes are this rank's) -> mg_apply.  Loop until *alive == 0, then mg_end + finalize/download as
+ * usual (each rank then holds the streams of its own chains; tid of chain c is c % num_thr, so tid t
+ * of the whole job is the concatenation over ranks of every rank's tid-t segment).  The result is
+ * bit-identical to run_chains() with num_chains = total_chains on one GPU, whatever `world` is.
+ * d_prop: device buffer of total_chains*8 bytes owned by the caller (e.g. a torch tensor it can hand
+ * to torch.distributed), or NULL to let the library allocate it. */
+int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains, void *d_prop);
+int spring_reorder_mg_search(spring_reorder_ctx *ctx);
+int spring_reorder_mg_slice(spring_reorder_ctx *ctx, void **d_prop, size_t *slice_off, size_t *slice_bytes,
+                            size_t *total_bytes);
+int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32_t *alive);
+int spring_reorder_mg_end(spring_reorder_ctx *ctx);
+/* all-gather between `world` contexts living in ONE process on one device (tests). */
+int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world);
+
 /* Gathers the per-chain emissions into the per-tid streams (the replay side of
  * writetofile, reorder.h:643-730). */
 int spring_reorder_finalize(spring_reorder_ctx *ctx);

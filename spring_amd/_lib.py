@@ -9,6 +9,8 @@ EXPORTS = [
     "spring_reorder_default_opts", "spring_reorder_last_error", "spring_reorder_trim_pool", "spring_reorder_run", "spring_reorder_create",
     "spring_reorder_destroy", "spring_reorder_load_dna", "spring_reorder_load_dna_device",
     "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
+    "spring_reorder_mg_begin", "spring_reorder_mg_search", "spring_reorder_mg_slice", "spring_reorder_mg_apply",
+    "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
     "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
@@ -64,6 +66,12 @@ def lib():
     L.spring_reorder_build_dict.argtypes = [vp]
     L.spring_reorder_run_chains.argtypes = [vp]
     L.spring_reorder_finalize.argtypes = [vp]
+    L.spring_reorder_mg_begin.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.spring_reorder_mg_search.argtypes = [vp]
+    L.spring_reorder_mg_slice.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.spring_reorder_mg_apply.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint32)]
+    L.spring_reorder_mg_end.argtypes = [vp]
+    L.spring_reorder_mg_exchange_virtual.argtypes = [C.POINTER(vp), C.c_uint32]
     L.spring_reorder_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.spring_reorder_download.argtypes = [vp] + [vp] * 8
     L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]

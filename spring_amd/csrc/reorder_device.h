@@ -17,6 +17,10 @@ constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
 
 enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
 enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2 };
+// per-chain proposal word exchanged between ranks in single-pool multi-GPU mode:
+// kind << 32 | rid, bit 40 = "this seed is the lowest of the round" (moves the cursor)
+enum { PK_NONE = 0, PK_MATCH = 1, PK_SEED = 2, PK_NEED = 3, PK_NOSEED = 4, PK_DONE = 5 };
+constexpr unsigned long long PK_CURSOR_BIT = 1ull << 40;
 
 // Per-chain state (one greedy chain == one reference OpenMP thread, reorder.h:351-431).
 // The 64-byte header is one cache line: a wave loads it once (4 x 16 B, broadcast)
@@ -69,8 +73,10 @@ struct DevParams {
   uint32_t *resv;     // lowest chain id that proposed read r this round (0xffffffff = none)
   uint32_t *needy;    // bitmap over chains waiting for a seed
   Globals *glob;
-  // chains
-  uint32_t K;
+  // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
+  uint32_t K, c0, Ktot;
+  unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
+  uint32_t *alive_round;      // [1] chains not done, recounted from prop every round (multi-GPU mode)
   Chain *chains;
   int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong
   // append-order emission buffers (+ chain, seq for the final scatter)
@@ -96,6 +102,9 @@ void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_
 void launch_init_chains(hipStream_t st, const DevParams &P);
 void launch_search(hipStream_t st, const DevParams &P, bool stats);
 void launch_apply(hipStream_t st, const DevParams &P, bool literal);
+// single-pool multi-GPU round: search (own chains) -> [exchange prop] -> post_exchange -> apply (own) -> mark (all)
+void launch_mg_post_exchange(hipStream_t st, const DevParams &P);
+void launch_mg_mark(hipStream_t st, const DevParams &P);
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s);
 void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz);

@@ -466,31 +466,90 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   __shared__ WaveLds lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t cid = blockIdx.x * 4 + wave;
-  if (cid >= P.K) return;
-  Chain *c = &P.chains[cid];
+  const uint32_t li = blockIdx.x * 4 + wave;
+  if (li >= P.K) return;
+  const uint32_t cid = P.c0 + li;  // global chain id
+  Chain *c = &P.chains[li];
   WaveLds *ws = &lds[wave];
-  const uint32_t step = P.n / P.K;
+  const uint32_t step = P.n / P.Ktot;
   const uint32_t seed = cid * step;
   const bool start = P.n > 0 && (cid == 0 || step > 0);
   ChainHot h;
   memset(&h, 0, sizeof(h));
   if (!start) {
     h.done = 1;
-    if (lane == 0) store_hot(c, h);
+    if (lane == 0) {
+      store_hot(c, h);
+      if (P.prop) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+    }
     return;
   }
   const int n = P.uniform_len ? P.L : (int)P.lens[seed];
-  const int Rn = wave_update_compute<NP, false>(P, cid, ws, nullptr, seed, n, true, false, 0, 0, 0, lane);
+  const int Rn = wave_update_compute<NP, false>(P, li, ws, nullptr, seed, n, true, false, 0, 0, 0, lane);
   pack_consensus(ws, Rn, lane, c);
   if (lane == 0) {
-    atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
     h.prev = seed; h.first_rid = seed; h.prev_unmatched = 1;
-    h.e_slot = cid * CHUNK; h.s_slot = cid * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
+    h.e_slot = li * CHUNK; h.s_slot = li * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
     h.ref_len = Rn; h.cnt_buf = 1;
     store_hot(c, h);
     c->n_unmatched = 1;
+    if (P.prop) P.prop[cid] = (unsigned long long)PK_NONE << 32;
   }
+}
+// every rank marks the initial seeds of ALL chains (taken[] is replicated)
+__global__ void k_init_seeds(DevParams P) {
+  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cid >= P.Ktot) return;
+  const uint32_t step = P.n / P.Ktot;
+  if (!(P.n > 0 && (cid == 0 || step > 0))) return;
+  const uint32_t seed = cid * step;
+  atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
+}
+
+// (rank+1)-th highest untaken read at or below the cursor, rank = number of seed-needing chains
+// with a lower id (reorder.h:576-592 with one global cursor).  Wave-cooperative.  Returns -1 when
+// the pool is exhausted; *is_last = this chain proposes the lowest seed of the round.
+__device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid, int lane, bool *is_last) {
+  int r = 0, tot = 0;
+  const uint32_t nw = (P.Ktot + 31) / 32;
+  for (uint32_t w = lane; w < nw; w += 64) {
+    uint32_t v = P.needy[w];
+    tot += __popc(v);
+    if (w * 32 + 32 <= cid) r += __popc(v);
+    else if (w * 32 <= cid) r += __popc(v & ((1u << (cid - w * 32)) - 1u));
+  }
+  const uint32_t rank = (uint32_t)wave_sum_i(r), nneedy = (uint32_t)wave_sum_i(tot);
+  *is_last = rank + 1 == nneedy;
+  uint32_t need = rank + 1;
+  long long top = P.glob->cursor;
+  long long seed = -1;
+  while (top >= 0) {
+    const long long wtop = top >> 6, w = wtop - lane;
+    uint64_t u = 0;
+    if (w >= 0) {
+      u = ~P.taken[w];
+      if (w == wtop) {
+        int bits = (int)(top & 63) + 1;
+        if (bits < 64) u &= (1ull << bits) - 1;
+      }
+    }
+    int cnt = __popcll(u);
+    int incl = wave_incl_scan_i(cnt, lane);
+    uint32_t total = (uint32_t)__shfl(incl, 63, 64);
+    if (total >= need) {
+      uint64_t m = __ballot((uint32_t)incl >= need);
+      int wl = __ffsll((unsigned long long)m) - 1;
+      int before = __shfl(incl - cnt, wl, 64);
+      uint64_t uu = shfl_u64(u, wl);
+      int kth = (int)need - before;  // kth highest set bit of uu
+      for (int t = 1; t < kth; t++) uu &= ~(1ull << (63 - __clzll(uu)));
+      seed = (wtop - wl) * 64 + (63 - __clzll(uu));
+      break;
+    }
+    need -= total;
+    top = (wtop - 64) * 64 + 63;
+  }
+  return seed;
 }
 
 // ---- one batch of 64 probes of search_match (reorder.h:246-318) by one wavefront.
@@ -596,13 +655,14 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
 // before 1) and the first set bit of the hit ballot is the reference's winner.
 // Chains that need a new contig seed instead pick the (rank+1)-th highest
 // untaken read at or below the global cursor (reorder.h:576-592).
-template <bool STATS>
+template <bool STATS, bool MG>
 __global__ __launch_bounds__(256) void k_search(DevParams P) {
   __shared__ uint64_t s_refs[4][2][LDS_LIMBS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t cid = blockIdx.x * 4 + wave;
-  if (cid >= P.K) return;
-  Chain *c = &P.chains[cid];
+  const uint32_t li = blockIdx.x * 4 + wave;
+  if (li >= P.K) return;
+  const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
+  Chain *c = &P.chains[li];
   ChainHot h;
   load_hot(c, h);
   // stage ref / revref in LDS right away (same dependency level as the header load)
@@ -615,51 +675,18 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   if (h.done) return;
 
   if (h.mode == MODE_NEED_SEED) {
-    // rank among seed-needing chains (by chain id)
-    int r = 0, tot = 0;
-    const uint32_t nw = (P.K + 31) / 32;
-    for (uint32_t w = lane; w < nw; w += 64) {
-      uint32_t v = P.needy[w];
-      tot += __popc(v);
-      if (w * 32 + 32 <= cid) r += __popc(v);
-      else if (w * 32 <= cid) r += __popc(v & ((1u << (cid - w * 32)) - 1u));
+    if (MG) {  // seeds are assigned after the exchange (k_mg_seed), when every rank knows who needs one
+      if (lane == 0) P.prop[cid] = (unsigned long long)PK_NEED << 32;
+      return;
     }
-    const uint32_t rank = (uint32_t)wave_sum_i(r), nneedy = (uint32_t)wave_sum_i(tot);
-    uint32_t need = rank + 1;
-    long long top = P.glob->cursor;
-    long long seed = -1;
-    while (top >= 0) {
-      const long long wtop = top >> 6, w = wtop - lane;
-      uint64_t u = 0;
-      if (w >= 0) {
-        u = ~P.taken[w];
-        if (w == wtop) {
-          int bits = (int)(top & 63) + 1;
-          if (bits < 64) u &= (1ull << bits) - 1;
-        }
-      }
-      int cnt = __popcll(u);
-      int incl = wave_incl_scan_i(cnt, lane);
-      uint32_t total = (uint32_t)__shfl(incl, 63, 64);
-      if (total >= need) {
-        uint64_t m = __ballot((uint32_t)incl >= need);
-        int wl = __ffsll((unsigned long long)m) - 1;
-        int before = __shfl(incl - cnt, wl, 64);
-        uint64_t uu = shfl_u64(u, wl);
-        int kth = (int)need - before;  // kth highest set bit of uu
-        for (int t = 1; t < kth; t++) uu &= ~(1ull << (63 - __clzll(uu)));
-        seed = (wtop - wl) * 64 + (63 - __clzll(uu));
-        break;
-      }
-      need -= total;
-      top = (wtop - 64) * 64 + 63;
-    }
+    bool is_last;
+    const long long seed = find_seed(P, cid, lane, &is_last);
     if (lane == 0) {
       if (seed >= 0) {
         h.prop_kind = PROP_SEED;
         h.prop_rid = (uint32_t)seed;
         // the last-ranked needy chain proposes the lowest seed of the round: it alone moves the cursor
-        h.cursor_writer = rank + 1 == nneedy;
+        h.cursor_writer = is_last;
         atomicMin(&P.resv[seed], cid);
       } else {
         h.prop_kind = PROP_NONE;
@@ -683,6 +710,7 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     if (lane == 0) {
       h.prop_kind = PROP_NONE;
       store_hot(c, h);
+      if (MG) P.prop[cid] = (unsigned long long)PK_NONE << 32;
       if (STATS && new_iter) c->st_iter++;
     }
     return;
@@ -704,9 +732,11 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     if (o.found) {
       h.prop_kind = PROP_MATCH; h.prop_rid = o.rid; h.prop_shift = wb * 16 + (int)(o.win >> 2);
       h.prop_rev = (uint8_t)((o.win >> 1) & 1);
-      atomicMin(&P.resv[o.rid], cid);
+      if (MG) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;  // resolved after the exchange
+      else atomicMin(&P.resv[o.rid], cid);
     } else {
       h.prop_kind = PROP_NONE;
+      if (MG) P.prop[cid] = (unsigned long long)PK_NONE << 32;
     }
     store_hot(c, h);
     if (STATS) {
@@ -746,27 +776,39 @@ __device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uin
   P.s_order[idx] = rid; P.s_chain[idx] = cid; P.s_seq[idx] = h.n_single++;
 }
 
-template <int NP, bool LITERAL>
+template <int NP, bool LITERAL, bool MG>
 __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   __shared__ WaveLds lds[4];
   __shared__ WaveLdsLiteral ldsl[LITERAL ? 4 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t cid = blockIdx.x * 4 + wave;
-  if (cid >= P.K) return;
-  Chain *c = &P.chains[cid];
+  const uint32_t li = blockIdx.x * 4 + wave;  // local chain index (state arrays, emission tags)
+  if (li >= P.K) return;
+  const uint32_t cid = P.c0 + li;             // global chain id (conflict priority)
+  Chain *c = &P.chains[li];
   ChainHot h;
   load_hot(c, h);
   if (h.done) return;
   WaveLds *ws = &lds[wave];
   WaveLdsLiteral *wl = &ldsl[LITERAL ? wave : 0];
-  const int kind = h.prop_kind;
+  int kind = h.prop_kind;
+  if (MG) {  // seed decisions were taken after the exchange and live in prop[]
+    const unsigned long long pv = P.prop[cid];
+    const int pk = (int)(pv >> 32) & 7;
+    if (pk == PK_SEED) { kind = PROP_SEED; h.prop_rid = (uint32_t)pv; }
+    else if (pk == PK_NOSEED) { kind = PROP_NONE; h.finishing = 1; }
+    else if (pk == PK_MATCH) kind = PROP_MATCH;
+    else kind = PROP_NONE;
+  }
 
   if (h.finishing) {  // seed-needing chain found the pool empty
     if (lane == 0) {
-      if (h.prev_unmatched) emit_single(P, h, cid, h.prev);
+      if (h.prev_unmatched) emit_single(P, h, li, h.prev);
       h.done = 1; h.finishing = 0;
-      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
-      atomicSub(&P.glob->alive, 1u);
+      if (MG) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+      else {
+        atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+        atomicSub(&P.glob->alive, 1u);
+      }
       store_hot(c, h);
     }
     return;
@@ -784,9 +826,9 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   const int R_old = h.ref_len;
   if (do_upd) {
     if (!P.uniform_len) n = (int)P.lens[urid];
-    R_new = wave_update_compute<NP, LITERAL>(P, cid, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf, lane);
+    R_new = wave_update_compute<NP, LITERAL>(P, li, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf, lane);
   }
-  if (kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
+  if (!MG && kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
     if (lane == 0) P.glob->cursor = (long long)h.prop_rid - 1;
     h.cursor_writer = 0;
   }
@@ -807,7 +849,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   if (kind == PROP_MATCH) {
     const uint32_t rid = h.prop_rid;
     const int shift = ushift;
-    atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+    if (!MG) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));  // MG: k_mg_mark on every rank
     const bool left = h.left_search;
     long long ref_pos = h.ref_pos, cur_pos;
     char rcch;
@@ -820,14 +862,16 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
       else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
       rcch = left ? 'd' : 'r';
     }
-    if (h.prev_unmatched) emit_rec(P, h, cid, h.prev, 'd', '0', 0);
-    emit_rec(P, h, cid, rid, rcch, '1', cur_pos);
+    if (h.prev_unmatched) emit_rec(P, h, li, h.prev, 'd', '0', 0);
+    emit_rec(P, h, li, rid, rcch, '1', cur_pos);
     h.prev_unmatched = 0; h.ref_pos = ref_pos; h.retrying = 0;
   } else if (kind == PROP_SEED) {  // reorder.h:580-587, :600-613
     const uint32_t rid = h.prop_rid;
-    atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
-    atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
-    if (h.prev_unmatched) emit_single(P, h, cid, h.prev);
+    if (!MG) {
+      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+    }
+    if (h.prev_unmatched) emit_single(P, h, li, h.prev);
     c->n_unmatched++;
     h.prev_unmatched = 1; h.first_rid = rid; h.prev = rid;
     h.ref_pos = 0; h.mode = MODE_SEARCH;
@@ -837,10 +881,64 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
     if (!h.left_search) { h.left_search = 1; h.ref_pos = 0; }
     else {
       h.left_search = 0; h.mode = MODE_NEED_SEED;
-      atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));
+      if (!MG) atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));  // MG: the chain says PK_NEED next round
     }
   }
   store_hot(c, h);
+}
+
+// ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
+// prop[] now holds every rank's proposals.  All ranks run these over ALL chains and therefore keep
+// identical taken[] / resv[] / cursor replicas; only k_apply is restricted to the chains a rank owns.
+
+// needy bitmap + number of chains still running, from the proposal kinds
+__global__ void k_mg_bits(DevParams P) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nw = (P.Ktot + 31) / 32;
+  uint32_t bits = 0, alive = 0;
+  if (w < nw) {
+    for (uint32_t j = 0; j < 32; j++) {
+      const uint32_t cid = w * 32 + j;
+      if (cid >= P.Ktot) break;
+      const int pk = (int)(P.prop[cid] >> 32) & 7;
+      if (pk == PK_NEED) bits |= 1u << j;
+      if (pk != PK_DONE) alive++;
+    }
+    P.needy[w] = bits;
+  }
+  alive = (uint32_t)wave_sum_i((int)alive);
+  if ((threadIdx.x & 63) == 0 && alive) atomicAdd(P.alive_round, alive);
+}
+// seed assignment for every chain that asked for one (one wavefront per chain, all ranks identically)
+__global__ __launch_bounds__(256) void k_mg_seed(DevParams P) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t cid = blockIdx.x * 4 + wave;
+  if (cid >= P.Ktot) return;
+  if (((int)(P.prop[cid] >> 32) & 7) != PK_NEED) return;
+  bool is_last;
+  const long long seed = find_seed(P, cid, lane, &is_last);
+  if (lane == 0)
+    P.prop[cid] = seed >= 0 ? (((unsigned long long)PK_SEED << 32) | (uint32_t)seed | (is_last ? PK_CURSOR_BIT : 0ull))
+                            : ((unsigned long long)PK_NOSEED << 32);
+}
+// lowest chain id wins a contested read
+__global__ void k_mg_resolve(DevParams P) {
+  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cid >= P.Ktot) return;
+  const unsigned long long pv = P.prop[cid];
+  const int pk = (int)(pv >> 32) & 7;
+  if (pk == PK_MATCH || pk == PK_SEED) atomicMin(&P.resv[(uint32_t)pv], cid);
+}
+// winners claim their read on every replica; the lowest seed of the round moves the cursor
+__global__ void k_mg_mark(DevParams P) {
+  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cid >= P.Ktot) return;
+  const unsigned long long pv = P.prop[cid];
+  const int pk = (int)(pv >> 32) & 7;
+  if (pk != PK_MATCH && pk != PK_SEED) return;
+  const uint32_t rid = (uint32_t)pv;
+  if (P.resv[rid] == cid) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+  if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)rid - 1;
 }
 
 // ------------------------------------------------------------ K7 finalize / emit
@@ -962,22 +1060,47 @@ void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_
   } while (0)
 
 void launch_init_chains(hipStream_t st, const DevParams &P) {
+  if (P.Ktot) hipLaunchKernelGGL(k_init_seeds, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
+  if (!P.K) return;
 #define CALL(N) hipLaunchKernelGGL(k_init_chains<N>, dim3((P.K + 3) / 4), dim3(256), 0, st, P)
   NP_DISPATCH(CALL);
 #undef CALL
 }
 void launch_search(hipStream_t st, const DevParams &P, bool stats) {
-  if (stats) hipLaunchKernelGGL(k_search<true>, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(k_search<false>, dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+  if (!P.K) return;
+  const dim3 g((P.K + 3) / 4), b(256);
+  if (P.prop) {
+    if (stats) hipLaunchKernelGGL((k_search<true, true>), g, b, 0, st, P);
+    else hipLaunchKernelGGL((k_search<false, true>), g, b, 0, st, P);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_search<true, false>), g, b, 0, st, P);
+    else hipLaunchKernelGGL((k_search<false, false>), g, b, 0, st, P);
+  }
 }
 void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
-  if (literal) {
-    hipLaunchKernelGGL((k_apply<8, true>), dim3((P.K + 3) / 4), dim3(256), 0, st, P);
+  if (!P.K) return;
+  const dim3 g((P.K + 3) / 4), b(256);
+  if (P.prop) {
+    if (literal) { hipLaunchKernelGGL((k_apply<8, true, true>), g, b, 0, st, P); return; }
+#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, true>), g, b, 0, st, P)
+    NP_DISPATCH(CALL);
+#undef CALL
     return;
   }
-#define CALL(N) hipLaunchKernelGGL((k_apply<N, false>), dim3((P.K + 3) / 4), dim3(256), 0, st, P)
+  if (literal) { hipLaunchKernelGGL((k_apply<8, true, false>), g, b, 0, st, P); return; }
+#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, false>), g, b, 0, st, P)
   NP_DISPATCH(CALL);
 #undef CALL
+}
+void launch_mg_post_exchange(hipStream_t st, const DevParams &P) {
+  const uint32_t nw = (P.Ktot + 31) / 32;
+  hipMemsetAsync(P.alive_round, 0, 4, st);
+  hipLaunchKernelGGL(k_mg_bits, GRID1(nw, 256), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_mg_seed, dim3((P.Ktot + 3) / 4), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
+}
+void launch_mg_mark(hipStream_t st, const DevParams &P) {
+  hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 }
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s) {

@@ -131,6 +131,7 @@ struct spring_reorder_ctx {
   DevParams P;
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
+  bool mg = false;
   std::vector<uint64_t> tid_off, tid_off_s;
   spring_reorder_stats stats;
   hipEvent_t ev[8];
@@ -584,7 +585,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   DMALLOC(P.e_order, cap * 4); DMALLOC(P.e_rc, cap); DMALLOC(P.e_flag, cap); DMALLOC(P.e_pos, cap * 8);
   DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
   DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
-  P.K = K;
+  P.K = K; P.c0 = 0; P.Ktot = K; P.prop = nullptr; P.alive_round = nullptr;
 
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   launch_init_taken(st, P.taken, nwords, n);
@@ -649,6 +650,133 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   return 0;
 }
 
+// ------------------------------------------------- single-pool multi-GPU
+// Every rank holds the full read pool and both dictionaries; rank r owns chains
+// [r*K/world, (r+1)*K/world).  One round = mg_search (own chains) -> all-gather of the
+// per-chain proposal words (done by the caller: torch.distributed over RCCL, or
+// spring_reorder_mg_exchange_virtual between contexts of one process) -> mg_apply.
+// Output is bit-identical to run_chains() with num_chains = total_chains on one GPU.
+int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains,
+                            void *d_prop) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_begin: build_dict first");
+  if (world == 0 || rank >= world || total_chains == 0 || total_chains % world)
+    return fail(SPRING_REORDER_E_ARG, "mg_begin: total_chains (%u) must be a positive multiple of world (%u)", total_chains, world);
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  const uint32_t n = ctx->n, Ktot = total_chains, K = Ktot / world;
+  ctx->K = K;
+  DevParams &P = ctx->P;
+  P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
+  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2;
+  P.uniform_len = ctx->uniform ? 1 : 0;
+  for (int l = 0; l < 2; l++) {
+    P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
+    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bmask[l] = ctx->dict[l].bmask;
+    P.ids[l] = ctx->dict[l].ids;
+  }
+  const uint64_t nwords = ((uint64_t)n + 63) / 64;
+  const size_t nn = std::max<uint32_t>(n, 1);
+  DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
+  DMALLOC(P.resv, nn * 4);
+  DMALLOC(P.needy, ((size_t)Ktot + 31) / 32 * 4);
+  DMALLOC(P.glob, sizeof(Globals));
+  DMALLOC(P.alive_round, 16);
+  DMALLOC(P.chains, (size_t)K * sizeof(Chain));
+  DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
+  if (d_prop) P.prop = (unsigned long long *)d_prop;
+  else DMALLOC(P.prop, (size_t)Ktot * 8);
+  const size_t cap = (size_t)n + (size_t)K * CHUNK;
+  if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
+  ctx->cap = cap;
+  DMALLOC(P.e_order, cap * 4); DMALLOC(P.e_rc, cap); DMALLOC(P.e_flag, cap); DMALLOC(P.e_pos, cap * 8);
+  DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
+  DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
+  P.K = K; P.c0 = rank * K; P.Ktot = Ktot;
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  launch_init_taken(st, P.taken, nwords, n);
+  launch_fill_u32(st, P.resv, n, 0xffffffffu);
+  HIPCHK(hipMemsetAsync(P.needy, 0, ((size_t)Ktot + 31) / 32 * 4, st));
+  HIPCHK(hipMemsetAsync(P.chains, 0, (size_t)K * sizeof(Chain), st));
+  Globals g;
+  memset(&g, 0, sizeof(g));
+  g.cursor = (long long)n - 1;
+  g.e_alloc = g.s_alloc = K * CHUNK;
+  HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
+  launch_fill_u32(st, P.e_chain, cap, 0xffffffffu);
+  launch_fill_u32(st, P.s_chain, cap, 0xffffffffu);
+  launch_init_chains(st, P);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  ctx->mg = true;
+  ctx->stats.rounds = 0;
+  return 0;
+}
+
+int spring_reorder_mg_search(spring_reorder_ctx *ctx) {
+  if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_search: mg_begin first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  launch_search(ctx->st, ctx->P, ctx->o.collect_stats != 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->st));  // the caller's exchange reads this rank's slice next
+  return 0;
+}
+
+int spring_reorder_mg_slice(spring_reorder_ctx *ctx, void **d_prop, size_t *slice_off, size_t *slice_bytes,
+                            size_t *total_bytes) {
+  if (!ctx || !ctx->mg) return fail(SPRING_REORDER_E_STATE, "mg_slice: mg_begin first");
+  if (d_prop) *d_prop = ctx->P.prop;
+  if (slice_off) *slice_off = (size_t)ctx->P.c0 * 8;
+  if (slice_bytes) *slice_bytes = (size_t)ctx->P.K * 8;
+  if (total_bytes) *total_bytes = (size_t)ctx->P.Ktot * 8;
+  return 0;
+}
+
+int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32_t *alive) {
+  if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_apply: mg_begin first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  launch_mg_post_exchange(st, ctx->P);
+  launch_apply(st, ctx->P, ctx->o.force_literal_update != 0);
+  launch_mg_mark(st, ctx->P);
+  HIPCHK(hipGetLastError());
+  ctx->stats.rounds++;
+  if (check_alive) {
+    uint32_t a = 0;
+    HIPCHK(hipMemcpyAsync(&a, ctx->P.alive_round, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (alive) *alive = a;
+  }
+  return 0;
+}
+
+int spring_reorder_mg_end(spring_reorder_ctx *ctx) {
+  if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_end: mg_begin first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  HIPCHK(hipEventRecord(ctx->ev[5], ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->stage = ST_CHAINS;
+  return 0;
+}
+
+// in-process all-gather between `world` contexts of one device (tests of G-independence on one GPU)
+int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world) {
+  if (!ctxs || !world) return fail(SPRING_REORDER_E_ARG, "bad arguments");
+  for (uint32_t d = 0; d < world; d++) {
+    spring_reorder_ctx *dc = ctxs[d];
+    if (!dc || !dc->mg) return fail(SPRING_REORDER_E_STATE, "exchange_virtual: mg_begin first");
+    HIPCHK(hipSetDevice(dc->dev));
+    for (uint32_t s2 = 0; s2 < world; s2++) {
+      if (s2 == d) continue;
+      spring_reorder_ctx *sc = ctxs[s2];
+      if (sc->P.prop == dc->P.prop) continue;  // shared buffer
+      HIPCHK(hipMemcpyAsync(dc->P.prop + sc->P.c0, sc->P.prop + sc->P.c0, (size_t)sc->P.K * 8, hipMemcpyDeviceToDevice, dc->st));
+    }
+  }
+  for (uint32_t d = 0; d < world; d++) HIPCHK(hipStreamSynchronize(ctxs[d]->st));
+  return 0;
+}
+
 int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage != ST_CHAINS) return fail(SPRING_REORDER_E_STATE, "finalize: run_chains first");
@@ -674,7 +802,8 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   for (int t = 0; t < T; t++) {
     ctx->tid_off[t] = am;
     ctx->tid_off_s[t] = as;
-    for (uint32_t i = (uint32_t)t; i < K; i += (uint32_t)T) {
+    for (uint32_t i = 0; i < K; i++) {
+      if ((P.c0 + i) % (uint32_t)T != (uint32_t)t) continue;  // chain id -> tid id % num_thr
       off_m[i] = am; off_s[i] = as;
       am += hc[i].h.n_emit; as += hc[i].h.n_single;
     }
@@ -685,7 +814,8 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
     s.unmatched += hc[i].n_unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
     s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost; s.hits += hc[i].st_hits;
   }
-  if (am + as != ctx->n || g.e_alloc > ctx->cap + CHUNK || g.s_alloc > ctx->cap + CHUNK)
+  // a rank of a multi-GPU pool only holds the records of the chains it owns
+  if ((!ctx->mg && am + as != ctx->n) || am + as > ctx->n || g.e_alloc > ctx->cap + CHUNK || g.s_alloc > ctx->cap + CHUNK)
     return fail(SPRING_REORDER_E_STATE, "internal: emission counts do not add up (%llu+%llu vs n=%u, alloc %u/%u cap %llu)",
                 (unsigned long long)am, (unsigned long long)as, ctx->n, g.e_alloc, g.s_alloc,
                 (unsigned long long)ctx->cap);

@@ -237,3 +237,43 @@ def test_full_size_properties_100M_150bp():
         assert fl[0] == ord("0") and fl[-1] == ord("1")
         assert not np.any((fl[:-1] == ord("0")) & (fl[1:] == ord("0")))
     assert a["stats"]["unmatched"] == int(f0.sum()) + len(a["order_s"])
+
+
+@pytest.mark.parametrize("name,K", [("syn5k_150", 64), ("var2k", 24), ("heavy", 48), ("repeat10k", 96), ("test_1+2", 8)])
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_single_pool_is_independent_of_gpu_count(name, K, G):
+    """sharding the chains of ONE read pool over G ranks (all-gather of proposals per
+    round) must give exactly the single-GPU K-chain output.  G virtual ranks on one device."""
+    from spring_amd.pool import VirtualPool
+    sa = _sa()
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    T = 3
+    want = po.reorder_rounds(read, ln, L, K, T)
+    single = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=K, num_thr=T))
+    vp = VirtualPool(G, K, T)
+    try:
+        got = vp.run(lambda s: s.load_dna(dna, n, L))
+    finally:
+        vp.close()
+    for k in KEYS:
+        assert np.array_equal(got[k], want[k]), (name, G, k)
+        assert np.array_equal(got[k], single[k]), (name, G, k)
+    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+
+
+def test_single_pool_1M_4_virtual_ranks():
+    from spring_amd.pool import VirtualPool
+    sa = _sa()
+    n, L, K, T, G = 1_000_000, 150, 4096, 8, 4
+    single = None
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T)) as s:
+        s.load_synth(n, L, n * L // 25, 5, 10000)
+        single = s.run().streams()
+    vp = VirtualPool(G, K, T)
+    try:
+        got = vp.run(lambda s: s.load_synth(n, L, n * L // 25, 5, 10000))
+    finally:
+        vp.close()
+    for k in KEYS:
+        assert np.array_equal(got[k], single[k]), k
