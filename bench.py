@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(64, cpus))")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-pool", choices=["auto", "on", "off"], default="auto",
+                    help="after the main JSON line, also time the single-pool mode (one shared read pool, chains "
+                         "sharded over the GPUs, all-gather of proposals per round); auto = only when --gpus > 1")
+    ap.add_argument("--pool-reads-per-gpu", type=int, default=50_000_000)
     return ap.parse_args()
 
 
@@ -164,6 +168,44 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # ---- experimental: single shared read pool across the GPUs.  Runs AFTER the main
+    # line is printed, under a watchdog, and reports on stderr, so it can never invalidate the main result.
+    want_pool = a.single_pool == "on" or (a.single_pool == "auto" and world > 1)
+    if want_pool:
+        import signal
+        signal.signal(signal.SIGALRM, lambda *_: os._exit(0))
+        signal.alarm(240)
+        try:
+            del buf
+            torch.cuda.empty_cache()
+            L_.spring_reorder_trim_pool()
+            from spring_amd.pool import DistPool
+            dist = lanes.dist
+            if dist is None:  # world == 1: a 1-rank process group still exercises the RCCL all-gather path
+                import torch.distributed as dist
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+            npool = a.pool_reads_per_gpu * world
+            Ktot = 65536 * world
+            res = None
+            for it in range(2):  # first pass warms the allocator pool
+                dp = DistPool(dist, torch.device("cuda", dev), Ktot, num_thr=a.num_thr)
+                lanes.barrier()
+                t0 = time.perf_counter()
+                stp = dp.run(lambda s: s.load_synth(npool, L, max(npool * L // a.coverage, 2 * L), 13, a.err_ppm))
+                lanes.barrier()
+                elp = lanes.max_over_ranks(time.perf_counter() - t0)
+                res = {"mode": "single-pool", "n_gpus": world, "pool_reads": npool, "chains": Ktot, "seconds": round(elp, 4),
+                       "Mreads_per_s_incl_synth": round(npool / elp / 1e6, 3), "rounds": dp.rounds,
+                       "stage_ms": {k: round(stp[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")}}
+                dp.close()
+            if rank == 0:
+                print("#single-pool " + json.dumps(res), file=sys.stderr, flush=True)
+        except Exception as e:  # never fail the bench because of the experimental leg
+            if rank == 0:
+                print("#single-pool failed: %r" % (e,), file=sys.stderr, flush=True)
+        signal.alarm(0)
     lanes.close()
 
 

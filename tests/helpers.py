@@ -47,6 +47,15 @@ def named_set(name):
     if name == "syn2k_251":  # W = 8 limbs
         a = rs.np_reads(105, 2000 * 251 // 25, 2000, 251, 0.005)
         return rs.pack_fixed(a), 2000, 251
+    if name == "syn1k_511":  # MAX_READ_LEN: W = 16 limbs, 8 positions per lane in the consensus update
+        a = rs.np_reads(113, 1000 * 511 // 25, 1000, 511, 0.004)
+        return rs.pack_fixed(a), 1000, 511
+    if name == "syn2k_20":  # very short reads: 6-base dictionary windows, maxshift 10
+        a = rs.np_reads(114, 2000 * 20 // 40, 2000, 20, 0.0)
+        return rs.pack_fixed(a), 2000, 20
+    if name == "var_long":  # variable length up to 400: reverse sub-cases with W = 13
+        reads = rs.var_length_reads(115, 30000, 1500, 120, 400, 0.005)
+        return rs.pack_var(reads), len(reads), max(len(r) for r in reads)
     if name == "var2k":  # variable length 50..150: the three reverse sub-cases + len<=dict.end exclusion
         reads = rs.var_length_reads(106, 12000, 2000, 50, 150, 0.01)
         return rs.pack_var(reads), len(reads), max(len(r) for r in reads)
@@ -75,7 +84,8 @@ def named_set(name):
     raise KeyError(name)
 
 
-SMALL_SETS = ["test_1", "test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k", "var_short",
+SMALL_SETS = ["test_1", "test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "syn1k_511", "syn2k_20",
+              "var_long", "var2k", "var_short",
               "heavy", "repeat10k", "dups", "one", "two_same", "empty"]
 
 

@@ -75,8 +75,8 @@ def test_k1_bit_exact_vs_serial_oracle(name):
         assert got["stats"][k] == want["stats"][k], (name, k, got["stats"][k], want["stats"][k])
 
 
-@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k", "var_short", "heavy",
-                                  "repeat10k", "dups", "test_1+2"])
+@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "syn1k_511", "syn2k_20", "var_long",
+                                  "var2k", "var_short", "heavy", "repeat10k", "dups", "test_1+2"])
 @pytest.mark.parametrize("K,T", [(2, 1), (5, 2), (64, 8), (1000, 3)])
 def test_chains_bit_exact_vs_rounds_oracle(name, K, T):
     dna, n, L = named_set(name)
@@ -90,7 +90,7 @@ def test_chains_bit_exact_vs_rounds_oracle(name, K, T):
     check_invariants(got, read, ln, L, n)
 
 
-@pytest.mark.parametrize("name", ["syn2k_100", "var2k", "var_short", "syn2k_251"])
+@pytest.mark.parametrize("name", ["syn2k_100", "var2k", "var_short", "syn2k_251", "syn1k_511", "var_long"])
 def test_literal_and_parallel_consensus_paths_agree(name):
     a = _gpu(name, 8, 2)
     b = _gpu(name, 8, 2, force_literal_update=True)

@@ -16,8 +16,8 @@ ref = po.ref_lib()
 pytestmark = pytest.mark.skipif(ref is None, reason="oracle/_ref not built (needs /root/reference)")
 
 
-@pytest.mark.parametrize("name", ["test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k",
-                                  "var_short", "heavy", "dups"])
+@pytest.mark.parametrize("name", ["test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "syn1k_511", "syn2k_20",
+                                  "var_long", "var2k", "var_short", "heavy", "dups"])
 @pytest.mark.parametrize("num_thr", [1, 3])
 def test_constructdictionary_matches_reference(name, num_thr):
     dna, n, L = named_set(name)
