@@ -623,13 +623,20 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
       const ulonglong2 rec = urec[pay];
       if (rec.x != key) continue;  // fingerprint collision
       const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
-      int live = 0;
-      for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
+      int live = 0, top_live = -1, j = (int)count - 1;
+      for (; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
         const uint32_t r = ids[start + j];
         if (is_taken(P.taken, r)) continue;
+        if (top_live < 0) top_live = j;
         live++; keyok = true; ncand++;
         if (within_thresh(r)) { hit = true; rid = r; break; }
       }
+      // Lazy trim of the dead tail: chains consume bins from the tail, so on deep bins (PhiX-like
+      // coverage) every later probe would re-skip the same taken reads.  Entries above the first
+      // live one are taken for good, so shrinking the count never changes a result; the reference
+      // gets the same effect from bbhashdict::remove (bitset_util.cpp:37-63).  Racing trims are benign.
+      const int keep = top_live >= 0 ? top_live + 1 : (j < 0 ? 0 : (int)count);
+      if (keep < (int)count) atomicMin(reinterpret_cast<unsigned int *>(const_cast<ulonglong2 *>(&urec[pay])) + 3, (unsigned int)keep);
       break;
     }
   }

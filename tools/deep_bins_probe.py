@@ -1,0 +1,13 @@
+"""PhiX-like stress: n reads over a tiny genome -> every dictionary bin holds hundreds to thousands of reads."""
+import sys, time
+sys.path.insert(0, "/root/repo")
+import spring_amd
+for a in sys.argv[1:]:
+    n, L, G, K = [int(x) for x in a.split(",")]
+    t0 = time.perf_counter()
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8)) as s:
+        s.load_synth(n, L, G, 21, 10000)
+        s.run()
+        st = s.stats()
+    print("n=%d L=%d G=%d K=%d wall=%.3fs dict=%.1f chains=%.1f ms rounds=%d unmatched=%d single=%d numkeys=%s" % (
+        n, L, G, K, time.perf_counter() - t0, st["ms_dict"], st["ms_chains"], st["rounds"], st["unmatched"], st["n_single"], st["numkeys"]), flush=True)
