@@ -153,6 +153,23 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
 int spring_reorder_download_reads(spring_reorder_ctx *ctx, uint64_t *limbs /* n*W */, uint16_t *len);
 
 /* ---------------------------------------------------------------------------
+ * consumers of read_order.bin that are pure permutation / prefix-sum work.
+ * Host arrays in and out; *kernel_ms (may be NULL) = device time of the kernels alone.
+ *   spring_order_invert_se : generate_order_se (reorder_compress_quality_id.cpp:117-125)
+ *                            order_array[order[i]] = i, i < n
+ *   spring_order_invert_pe : generate_order_pe (reorder_compress_quality_id.cpp:101-115)
+ *                            for i < n: if (order[i] < n/2) order_array[order[i]] = pos++   (n/2 outputs)
+ *   spring_order_correct   : correct_order (encoder.cpp:177-222): every index into the clean-read array
+ *                            (m entries: the per-tid order streams and the singleton order) is shifted by the
+ *                            number of N reads that precede that clean read in the original file;
+ *                            order_N = original positions of the nN reads with N, n_clean = clean reads.
+ */
+int spring_order_invert_se(const uint32_t *order, uint32_t n, uint32_t *order_array, double *kernel_ms);
+int spring_order_invert_pe(const uint32_t *order, uint32_t n, uint32_t *order_array, double *kernel_ms);
+int spring_order_correct(uint32_t *order, uint64_t m, const uint32_t *order_N, uint32_t nN, uint32_t n_clean,
+                         double *kernel_ms);
+
+/* ---------------------------------------------------------------------------
  * Synthetic input for bench.py / tests: uniform random
  * genome of G bases, n reads of length L at uniform positions, i.i.d.
  * substitutions at rate err_ppm/1e6, 50 % reverse complemented, no N.  A

@@ -199,3 +199,26 @@ def build_dict(read, ln, L, which):
     nk = lib().orc_build_dict(read.ctypes.data, ln.ctypes.data, n, L, which, keys.ctypes.data,
                               sp.ctypes.data, ids.ctypes.data, C.byref(dn))
     return keys[:nk].copy(), sp[:nk + 1].copy(), ids[:dn.value].copy()
+
+
+def generate_order_se(order):
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    out = np.zeros(max(len(order), 1), np.uint32)
+    lib().orc_generate_order_se(C.c_void_p(order.ctypes.data), C.c_uint32(len(order)), C.c_void_p(out.ctypes.data))
+    return out[:len(order)]
+
+
+def generate_order_pe(order):
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    out = np.zeros(max(len(order) // 2, 1), np.uint32)
+    lib().orc_generate_order_pe(C.c_void_p(order.ctypes.data), C.c_uint32(len(order)), C.c_void_p(out.ctypes.data))
+    return out[:len(order) // 2]
+
+
+def correct_order(order, order_N, n_clean):
+    order = np.array(order, dtype=np.uint32, copy=True)
+    order_N = np.ascontiguousarray(order_N, dtype=np.uint32)
+    lib().orc_correct_order(C.c_void_p(order.ctypes.data), C.c_uint64(len(order)),
+                            C.c_void_p(order_N.ctypes.data if len(order_N) else 0), C.c_uint32(len(order_N)),
+                            C.c_uint32(n_clean))
+    return order

@@ -1169,3 +1169,29 @@ int orc_reorder_omp(const uint64_t *read, const uint16_t *len, uint32_t n, int L
   return 0;
 }
 #endif /* _OPENMP */
+
+/* ------------------------------------------------ SURVEY 8(f3) restatements (literal loops) */
+/* generate_order_se (reorder_compress_quality_id.cpp:117-125) */
+void orc_generate_order_se(const uint32_t *order, uint32_t numreads, uint32_t *order_array) {
+  for (uint32_t i = 0; i < numreads; i++) order_array[order[i]] = i;
+}
+/* generate_order_pe (reorder_compress_quality_id.cpp:101-115) */
+void orc_generate_order_pe(const uint32_t *order, uint32_t numreads, uint32_t *order_array) {
+  uint32_t pos_after_reordering = 0, numreads_by_2 = numreads / 2;
+  for (uint32_t i = 0; i < numreads; i++)
+    if (order[i] < numreads_by_2) order_array[order[i]] = pos_after_reordering++;
+}
+/* correct_order (encoder.cpp:177-222) on an in-memory index array */
+void orc_correct_order(uint32_t *order, uint64_t m, const uint32_t *order_N, uint32_t numreads_N, uint32_t n_clean) {
+  uint32_t numreads_total = n_clean + numreads_N;
+  uint8_t *read_flag_N = (uint8_t *)calloc(numreads_total ? numreads_total : 1, 1);
+  for (uint32_t i = 0; i < numreads_N; i++) read_flag_N[order_N[i]] = 1;
+  uint32_t *cumulative_N_reads = (uint32_t *)malloc(sizeof(uint32_t) * (n_clean ? n_clean : 1));
+  uint32_t pos_in_clean = 0, num_N_reads_till_now = 0;
+  for (uint32_t i = 0; i < numreads_total; i++) {
+    if (read_flag_N[i]) num_N_reads_till_now++;
+    else cumulative_N_reads[pos_in_clean++] = num_N_reads_till_now;
+  }
+  for (uint64_t i = 0; i < m; i++) order[i] += cumulative_N_reads[order[i]];
+  free(read_flag_N); free(cumulative_N_reads);
+}

@@ -13,6 +13,7 @@ EXPORTS = [
     "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
+    "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct",
     "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
 ]
 
@@ -77,6 +78,9 @@ def lib():
     L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.spring_reorder_dict_lookup.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, vp, C.c_size_t]
     L.spring_reorder_download_reads.argtypes = [vp, vp, vp]
+    L.spring_order_invert_se.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
+    L.spring_order_invert_pe.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
+    L.spring_order_correct.argtypes = [vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.spring_synth_dna_bytes.restype = C.c_size_t
     L.spring_synth_dna_bytes.argtypes = [C.c_uint32, C.c_uint32]
     L.spring_synth_dna_host.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
