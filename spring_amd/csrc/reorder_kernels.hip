@@ -5,6 +5,7 @@
 // reorder.h + bitset_util.{h,cpp}; each kernel names the loop it replaces.
 // No MFMA here: everything is 64-bit integer / bit work bounded by random HBM
 // access.
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -1076,6 +1077,12 @@ void launch_init_chains(hipStream_t st, const DevParams &P) {
 void launch_search(hipStream_t st, const DevParams &P, bool stats) {
   if (!P.K) return;
   const dim3 g((P.K + 3) / 4), b(256);
+  // occupancy experiment: SPRING_DBG_SEARCH_LDS=<bytes> adds dummy dynamic LDS per block
+  static const int dbg_lds = getenv("SPRING_DBG_SEARCH_LDS") ? atoi(getenv("SPRING_DBG_SEARCH_LDS")) : 0;
+  if (dbg_lds && !P.prop && !stats) {
+    hipLaunchKernelGGL((k_search<false, false>), g, b, (size_t)dbg_lds, st, P);
+    return;
+  }
   if (P.prop) {
     if (stats) hipLaunchKernelGGL((k_search<true, true>), g, b, 0, st, P);
     else hipLaunchKernelGGL((k_search<false, true>), g, b, 0, st, P);
