@@ -106,6 +106,24 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx);
  * lock-step rounds (search_match reorder.h:246-318, updaterefcount :110-220). */
 int spring_reorder_run_chains(spring_reorder_ctx *ctx);
 
+/* ---- FASTQ front end.  The sequence side of preprocess() (src/preprocess.cpp:186-214,:293-304;
+ * read_fastq_block src/util.cpp:31-54; write_dna_in_bits / write_dnaN_in_bits src/util.cpp:269-294,:322-348) on
+ * the GPU: uncompressed 4-line FASTQ text in host memory -> reads without N packed 2 bits/base straight into the
+ * record stream the reorder stage consumes (what the reference writes to input_clean_{1,2}.dna; file-2 reads
+ * follow file-1 reads), reads with N packed 4 bits/base (input_N.dna[.2]) with their position in their file
+ * (read_order_N.bin[.2]).  Errors mirror the reference's exceptions ("Invalid FASTQ(A) file. Number of lines not
+ * multiple of 4(2)", "Too long read length ...", "Number of reads in paired files do not match.").
+ * After it the context is loaded (build_dict next); spring_reorder_download_dna returns the clean stream. */
+typedef struct {
+  uint32_t num_reads[2], num_reads_clean[2], num_reads_N[2];
+  uint32_t max_readlen; /* over all reads, with or without N (preprocess.cpp:312-315) */
+} spring_fastq_info;
+int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, size_t nbytes_1, const uint8_t *fastq_2,
+                              size_t nbytes_2 /* fastq_2 = NULL: single end */, spring_fastq_info *info);
+/* N reads of input file `which` (0/1): 4-bit packed records + positions; any pointer may be NULL. */
+int spring_reorder_fastq_N(spring_reorder_ctx *ctx, int32_t which, uint8_t *n_dna, size_t cap, size_t *nbytes,
+                           uint32_t *order_N, uint32_t *count);
+
 /* ---- single-pool multi-GPU (one process per GPU).  Every rank loads the same
  * reads and builds the same dictionaries; rank r owns chains [r*K/world, (r+1)*K/world), K =
  * total_chains.  Per round: mg_search -> caller all-gathers the proposal words (mg_slice says which

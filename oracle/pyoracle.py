@@ -222,3 +222,24 @@ def correct_order(order, order_N, n_clean):
                             C.c_void_p(order_N.ctypes.data if len(order_N) else 0), C.c_uint32(len(order_N)),
                             C.c_uint32(n_clean))
     return order
+
+
+def preprocess_fastq(text: bytes):
+    """Sequence side of preprocess() for one FASTQ file -> dict(clean, ndna, order_N, num_reads, num_clean, num_N, max_readlen).
+    Raises ValueError with the reference's message on malformed input."""
+    buf = np.frombuffer(text, dtype=np.uint8)
+    clean = np.zeros(len(buf) + 16, np.uint8)
+    ndna = np.zeros(len(buf) + 16, np.uint8)
+    order_N = np.zeros(len(buf) // 4 + 4, np.uint32)
+    counts = np.zeros(4, np.uint32)
+    cb, nb = C.c_size_t(), C.c_size_t()
+    f = lib().orc_preprocess_fastq
+    f.restype = C.c_int
+    rc = f(C.c_void_p(buf.ctypes.data if len(buf) else 0), C.c_size_t(len(buf)), C.c_void_p(clean.ctypes.data), C.byref(cb),
+           C.c_void_p(ndna.ctypes.data), C.byref(nb), C.c_void_p(order_N.ctypes.data), C.c_void_p(counts.ctypes.data))
+    if rc == -1:
+        raise ValueError("Invalid FASTQ(A) file. Number of lines not multiple of 4(2)")
+    if rc == -2:
+        raise ValueError("Too long read length (please try --long/-l flag).")
+    return dict(clean=clean[:cb.value].tobytes(), ndna=ndna[:nb.value].tobytes(), order_N=order_N[:counts[2]].copy(),
+                num_reads=int(counts[0]), num_clean=int(counts[1]), num_N=int(counts[2]), max_readlen=int(counts[3]))

@@ -1195,3 +1195,55 @@ void orc_correct_order(uint32_t *order, uint64_t m, const uint32_t *order_N, uin
   for (uint64_t i = 0; i < m; i++) order[i] += cumulative_N_reads[order[i]];
   free(read_flag_N); free(cumulative_N_reads);
 }
+
+/* ------------------------------------------------ sequence side of preprocess()
+ * read_fastq_block (util.cpp:31-54) + N split / packing (preprocess.cpp:186-214, :293-304) +
+ * write_dnaN_in_bits (util.cpp:322-348), for one uncompressed FASTQ file held in memory.
+ * counts[0..3] = num_reads, num_reads_clean, num_reads_N, max_readlen.
+ * Returns 0, -1 = "Invalid FASTQ(A) file. Number of lines not multiple of 4(2)", -2 = "Too long read length". */
+static int fq_getline(const uint8_t *t, size_t n, size_t *p, size_t *s, size_t *e) {
+  if (*p >= n) return 0; /* std::getline fails at EOF with nothing extracted */
+  *s = *p;
+  while (*p < n && t[*p] != '\n') (*p)++;
+  *e = *p;
+  if (*p < n) (*p)++; /* consume the delimiter */
+  return 1;
+}
+int orc_preprocess_fastq(const uint8_t *txt, size_t nbytes, uint8_t *clean, size_t *clean_bytes, uint8_t *ndna,
+                         size_t *n_bytes, uint32_t *order_N, uint32_t *counts) {
+  size_t p = 0, cb = 0, nb = 0;
+  uint32_t num_reads = 0, num_clean = 0, num_N = 0, maxlen = 0;
+  for (;;) {
+    size_t s, e, rs, re;
+    if (!fq_getline(txt, nbytes, &p, &s, &e)) break;           /* id */
+    if (!fq_getline(txt, nbytes, &p, &rs, &re)) return -1;      /* read */
+    if (re > rs && txt[re - 1] == '\r') re--;                   /* remove_CR_from_end */
+    if (!fq_getline(txt, nbytes, &p, &s, &e)) return -1;        /* comment */
+    if (!fq_getline(txt, nbytes, &p, &s, &e)) return -1;        /* quality */
+    size_t len = re - rs;
+    if (len > ORC_MAX_READ_LEN) return -2;
+    if (len > maxlen) maxlen = (uint32_t)len;
+    int hasN = 0;
+    for (size_t i = rs; i < re; i++) hasN |= txt[i] == 'N';
+    if (!hasN) {
+      cb += orc_pack_read((const char *)txt + rs, (int)len, clean + cb);
+      num_clean++;
+    } else {
+      order_N[num_N++] = num_reads;
+      uint16_t l16 = (uint16_t)len;
+      memcpy(ndna + nb, &l16, 2);
+      size_t nbts = (len + 1) / 2;
+      for (size_t i = 0; i < nbts; i++) ndna[nb + 2 + i] = 0;
+      for (size_t i = 0; i < len; i++) {
+        uint8_t c = txt[rs + i];
+        uint8_t v = c == 'A' ? 0 : c == 'C' ? 2 : c == 'G' ? 1 : c == 'T' ? 3 : 4;
+        ndna[nb + 2 + i / 2] |= (uint8_t)(v << (4 * (i % 2)));
+      }
+      nb += 2 + nbts;
+    }
+    num_reads++;
+  }
+  *clean_bytes = cb; *n_bytes = nb;
+  counts[0] = num_reads; counts[1] = num_clean; counts[2] = num_N; counts[3] = maxlen;
+  return 0;
+}

@@ -13,6 +13,7 @@ EXPORTS = [
     "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
+    "spring_reorder_load_fastq", "spring_reorder_fastq_N",
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct",
     "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
 ]
@@ -22,6 +23,11 @@ class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_chains", C.c_uint32), ("num_thr", C.c_int32),
                 ("collect_stats", C.c_int32), ("time_search", C.c_int32), ("force_literal_update", C.c_int32),
                 ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32)]
+
+
+class FastqInfo(C.Structure):
+    _fields_ = [("num_reads", C.c_uint32 * 2), ("num_reads_clean", C.c_uint32 * 2), ("num_reads_N", C.c_uint32 * 2),
+                ("max_readlen", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -78,6 +84,8 @@ def lib():
     L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.spring_reorder_dict_lookup.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, vp, C.c_size_t]
     L.spring_reorder_download_reads.argtypes = [vp, vp, vp]
+    L.spring_reorder_load_fastq.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(FastqInfo)]
+    L.spring_reorder_fastq_N.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_uint32)]
     L.spring_order_invert_se.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
     L.spring_order_invert_pe.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
     L.spring_order_correct.argtypes = [vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspring_reorder_hip.so")
-SOURCES = ["reorder_kernels.hip", "reorder_pipeline.cpp", "reorder_files.cpp", "order_ops.hip"]
+SOURCES = ["reorder_kernels.hip", "reorder_pipeline.cpp", "reorder_files.cpp", "order_ops.hip", "fastq_kernels.hip"]
 HEADERS = ["reorder_device.h", "synth_common.h", "call_reorder.h"]
 
 

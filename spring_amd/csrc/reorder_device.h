@@ -112,6 +112,19 @@ void launch_emit_dna(hipStream_t st, const uint64_t *reads, const uint16_t *lens
                      const char *rc, uint64_t cnt, const uint64_t *off, uint32_t rec_fixed, uint8_t *dst);
 void launch_synth(hipStream_t st, uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t thr24);
 
+// FASTQ front end (fastq_kernels.hip)
+constexpr int NL_CHUNK_BYTES = 4096;
+void launch_nl_count(hipStream_t st, const uint8_t *t, uint64_t nbytes, uint32_t *blk_cnt, uint64_t nblk);
+void launch_nl_fill(hipStream_t st, const uint8_t *t, uint64_t nbytes, const uint64_t *blk_off, uint64_t *line_end,
+                    uint64_t nblk);
+void launch_read_info(hipStream_t st, const uint8_t *t, const uint64_t *line_end, uint64_t nreads, uint32_t *len,
+                      uint32_t *fclean, uint32_t *szc, uint32_t *fN, uint32_t *szN, uint32_t *err);
+void launch_pack_reads(hipStream_t st, const uint8_t *t, const uint64_t *line_end, uint64_t nreads, const uint32_t *len,
+                       const uint32_t *fclean, const uint32_t *cidx, const uint64_t *coff, const uint32_t *nidx,
+                       const uint64_t *noff, uint32_t cidx_base, uint64_t coff_base, uint32_t file_read_base,
+                       uint8_t *out_clean, uint64_t *out_off, uint8_t *out_N, uint32_t *out_orderN);
+hipError_t reduce_max_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n);
+
 hipError_t sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
                       const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit);
 hipError_t rle(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *in, size_t n, uint64_t *uniq,

@@ -132,6 +132,11 @@ struct spring_reorder_ctx {
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
   bool mg = false;
+  // FASTQ front end (f1): reads with N, per input file
+  uint8_t *d_N[2] = {nullptr, nullptr};
+  uint32_t *d_orderN[2] = {nullptr, nullptr};
+  uint64_t N_bytes[2] = {0, 0};
+  spring_fastq_info fq;
   std::vector<uint64_t> tid_off, tid_off_s;
   spring_reorder_stats stats;
   hipEvent_t ev[8];
@@ -318,6 +323,171 @@ int spring_reorder_load_dna_device(spring_reorder_ctx *ctx, const void *d_dna, s
   std::vector<uint8_t> h(nbytes);
   if (nbytes) HIPCHK(hipMemcpy(h.data(), d_dna, nbytes, hipMemcpyDeviceToHost));
   return spring_reorder_load_dna(ctx, h.data(), nbytes, n, max_readlen);
+}
+
+// ------------------------------------------------------------------ f1: FASTQ front end
+// read_fastq_block + the N-split / packing loop of preprocess() (reference src/util.cpp:31-54,
+// src/preprocess.cpp:186-214,:293-304) for the sequence lines, on the GPU: the clean reads land in the
+// .dna record stream the unpack kernel reads (no input_clean_*.dna round trip through the file system).
+namespace {
+struct FqFile {
+  uint8_t *d_txt = nullptr;
+  uint64_t nbytes = 0, nlines = 0, nreads = 0;
+  uint64_t *line_end = nullptr;
+  uint32_t *len = nullptr, *fclean = nullptr, *szc = nullptr, *fN = nullptr, *szN = nullptr, *cidx = nullptr, *nidx = nullptr;
+  uint64_t *coff = nullptr, *noff = nullptr;
+  uint32_t n_clean = 0, n_N = 0, maxlen = 0;
+  uint64_t clean_bytes = 0, N_bytes = 0;
+};
+}  // namespace
+
+static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbytes, FqFile &f, uint32_t *d_err) {
+  hipStream_t st = ctx->st;
+  f.nbytes = nbytes;
+  if (!nbytes) return 0;
+  DMALLOC(f.d_txt, nbytes + 16);
+  HIPCHK(hipMemcpyAsync(f.d_txt, txt, nbytes, hipMemcpyHostToDevice, st));
+  const uint64_t nblk = (nbytes + NL_CHUNK_BYTES - 1) / NL_CHUNK_BYTES;
+  uint32_t *blk_cnt = nullptr;
+  uint64_t *blk_off = nullptr;
+  void *tmp = nullptr;
+  size_t tb = 0;
+  DMALLOC(blk_cnt, nblk * 4);
+  DMALLOC(blk_off, nblk * 8);
+  launch_nl_count(st, f.d_txt, nbytes, blk_cnt, nblk);
+  HIPCHK(excl_scan_u32_to_u64(st, nullptr, tb, blk_cnt, blk_off, nblk));
+  DMALLOC(tmp, tb);
+  HIPCHK(excl_scan_u32_to_u64(st, tmp, tb, blk_cnt, blk_off, nblk));
+  uint64_t last_off = 0;
+  uint32_t last_cnt = 0;
+  HIPCHK(hipMemcpyAsync(&last_off, blk_off + (nblk - 1), 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&last_cnt, blk_cnt + (nblk - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const uint64_t nl = last_off + last_cnt;
+  const bool unterminated = txt[nbytes - 1] != '\n';  // std::getline still returns the last line
+  f.nlines = nl + (unterminated ? 1 : 0);
+  if (f.nlines % 4) return fail(SPRING_REORDER_E_ARG, "Invalid FASTQ(A) file. Number of lines not multiple of 4(2)");
+  f.nreads = f.nlines / 4;
+  if (f.nreads > 4294967290ull) return fail(SPRING_REORDER_E_ARG, "Too many reads.");
+  DMALLOC(f.line_end, (f.nlines + 1) * 8);
+  launch_nl_fill(st, f.d_txt, nbytes, blk_off, f.line_end, nblk);
+  if (unterminated) {
+    const uint64_t e = nbytes;
+    HIPCHK(hipMemcpyAsync(f.line_end + nl, &e, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  const size_t nr = f.nreads;
+  if (!nr) { ctx->dfree(blk_cnt); ctx->dfree(blk_off); ctx->dfree(tmp); return 0; }
+  DMALLOC(f.len, nr * 4); DMALLOC(f.fclean, nr * 4); DMALLOC(f.szc, nr * 4); DMALLOC(f.fN, nr * 4); DMALLOC(f.szN, nr * 4);
+  DMALLOC(f.cidx, nr * 4); DMALLOC(f.nidx, nr * 4); DMALLOC(f.coff, nr * 8); DMALLOC(f.noff, nr * 8);
+  launch_read_info(st, f.d_txt, f.line_end, nr, f.len, f.fclean, f.szc, f.fN, f.szN, d_err);
+  HIPCHK(hipGetLastError());
+  ctx->dfree(tmp); tmp = nullptr;
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  HIPCHK(excl_scan_u32(st, nullptr, t1, f.fclean, f.cidx, nr));
+  HIPCHK(excl_scan_u32_to_u64(st, nullptr, t2, f.szc, f.coff, nr));
+  uint32_t *d_max = nullptr;
+  DMALLOC(d_max, 16);
+  HIPCHK(reduce_max_u32(st, nullptr, t3, f.len, d_max, nr));
+  tb = std::max(t1, std::max(t2, t3));
+  DMALLOC(tmp, tb);
+  HIPCHK(excl_scan_u32(st, tmp, tb, f.fclean, f.cidx, nr));
+  HIPCHK(excl_scan_u32(st, tmp, tb, f.fN, f.nidx, nr));
+  HIPCHK(excl_scan_u32_to_u64(st, tmp, tb, f.szc, f.coff, nr));
+  HIPCHK(excl_scan_u32_to_u64(st, tmp, tb, f.szN, f.noff, nr));
+  HIPCHK(reduce_max_u32(st, tmp, tb, f.len, d_max, nr));
+  uint32_t lc = 0, lf = 0, ln = 0, lfn = 0, lsz = 0, lszn = 0;
+  uint64_t lco = 0, lno = 0;
+  HIPCHK(hipMemcpyAsync(&lc, f.cidx + (nr - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&lf, f.fclean + (nr - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&ln, f.nidx + (nr - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&lfn, f.fN + (nr - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&lco, f.coff + (nr - 1), 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&lsz, f.szc + (nr - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&lno, f.noff + (nr - 1), 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&lszn, f.szN + (nr - 1), 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f.maxlen, d_max, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  f.n_clean = lc + lf; f.n_N = ln + lfn; f.clean_bytes = lco + lsz; f.N_bytes = lno + lszn;
+  ctx->dfree(blk_cnt); ctx->dfree(blk_off); ctx->dfree(tmp); ctx->dfree(d_max);
+  return 0;
+}
+
+int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, size_t nbytes_1, const uint8_t *fastq_2,
+                              size_t nbytes_2, spring_fastq_info *info) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_fastq: context already loaded");
+  if ((nbytes_1 && !fastq_1) || (nbytes_2 && !fastq_2)) return fail(SPRING_REORDER_E_ARG, "NULL FASTQ buffer");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  const bool paired = fastq_2 != nullptr;
+  uint32_t *d_err = nullptr;
+  DMALLOC(d_err, 16);
+  HIPCHK(hipMemsetAsync(d_err, 0, 4, st));
+  FqFile f[2];
+  int r = fq_scan_file(ctx, fastq_1, nbytes_1, f[0], d_err);
+  if (r) return r;
+  if (paired && (r = fq_scan_file(ctx, fastq_2, nbytes_2, f[1], d_err))) return r;
+  uint32_t err = 0;
+  HIPCHK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+  if (err) return fail(SPRING_REORDER_E_ARG, "Too long read length (please try --long/-l flag).");
+  if (paired && f[0].nreads != f[1].nreads) return fail(SPRING_REORDER_E_ARG, "Number of reads in paired files do not match.");
+  if (f[0].nreads + f[1].nreads > 4294967290ull) return fail(SPRING_REORDER_E_ARG, "Too many reads.");
+  const uint32_t n_clean = f[0].n_clean + f[1].n_clean;
+  const uint64_t clean_bytes = f[0].clean_bytes + f[1].clean_bytes;
+  const uint32_t maxlen = std::max(f[0].maxlen, f[1].maxlen);
+  memset(&ctx->fq, 0, sizeof(ctx->fq));
+  for (int j = 0; j < 2; j++) {
+    ctx->fq.num_reads[j] = (uint32_t)f[j].nreads; ctx->fq.num_reads_clean[j] = f[j].n_clean; ctx->fq.num_reads_N[j] = f[j].n_N;
+  }
+  ctx->fq.max_readlen = maxlen;
+  if (info) *info = ctx->fq;
+  r = setup_geometry(ctx, n_clean, maxlen ? maxlen : 1);
+  if (r) return r;
+  ctx->dna_bytes = clean_bytes;
+  DMALLOC(ctx->d_dna, clean_bytes + 16);
+  DMALLOC(ctx->d_off, (size_t)std::max<uint32_t>(n_clean, 1) * 8);
+  uint32_t cbase = 0, rbase = 0;
+  uint64_t obase = 0;
+  for (int j = 0; j < 2; j++) {
+    if (!f[j].nreads) continue;
+    DMALLOC(ctx->d_N[j], f[j].N_bytes + 16);
+    DMALLOC(ctx->d_orderN[j], (size_t)std::max<uint32_t>(f[j].n_N, 1) * 4);
+    ctx->N_bytes[j] = f[j].N_bytes;
+    // pos_N counts from the start of its own file (preprocess.cpp:299: num_reads[j] + i)
+    launch_pack_reads(st, f[j].d_txt, f[j].line_end, f[j].nreads, f[j].len, f[j].fclean, f[j].cidx, f[j].coff, f[j].nidx,
+                      f[j].noff, cbase, obase, 0u, ctx->d_dna, ctx->d_off, ctx->d_N[j], ctx->d_orderN[j]);
+    HIPCHK(hipGetLastError());
+    cbase += f[j].n_clean; obase += f[j].clean_bytes; rbase += (uint32_t)f[j].nreads;
+  }
+  (void)rbase;
+  ctx->uniform = false;  // lengths are read from the lens array (a min-length reduction could enable the fast path)
+  r = unpack_on_device(ctx);
+  if (r) return r;
+  HIPCHK(hipStreamSynchronize(st));
+  for (int j = 0; j < 2; j++) {
+    ctx->dfree(f[j].d_txt); ctx->dfree(f[j].line_end); ctx->dfree(f[j].len); ctx->dfree(f[j].fclean); ctx->dfree(f[j].szc);
+    ctx->dfree(f[j].fN); ctx->dfree(f[j].szN); ctx->dfree(f[j].cidx); ctx->dfree(f[j].nidx); ctx->dfree(f[j].coff);
+    ctx->dfree(f[j].noff);
+  }
+  ctx->dfree(d_err);
+  return 0;
+}
+
+int spring_reorder_fastq_N(spring_reorder_ctx *ctx, int32_t which, uint8_t *n_dna, size_t cap, size_t *nbytes,
+                           uint32_t *order_N, uint32_t *count) {
+  if (!ctx || ctx->stage < ST_LOADED) return fail(SPRING_REORDER_E_STATE, "fastq_N: load_fastq first");
+  if (which < 0 || which > 1) return fail(SPRING_REORDER_E_ARG, "which must be 0 or 1");
+  HIPCHK(hipSetDevice(ctx->dev));
+  const uint32_t nN = ctx->fq.num_reads_N[which];
+  if (nbytes) *nbytes = ctx->N_bytes[which];
+  if (count) *count = nN;
+  if (n_dna && ctx->N_bytes[which]) {
+    if (cap < ctx->N_bytes[which]) return fail(SPRING_REORDER_E_ARG, "fastq_N: buffer too small");
+    HIPCHK(hipMemcpy(n_dna, ctx->d_N[which], ctx->N_bytes[which], hipMemcpyDeviceToHost));
+  }
+  if (order_N && nN) HIPCHK(hipMemcpy(order_N, ctx->d_orderN[which], (size_t)nN * 4, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 size_t spring_synth_dna_bytes(uint32_t n, uint32_t L) { return (size_t)n * (2u + (L + 3u) / 4u); }

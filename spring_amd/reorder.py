@@ -88,6 +88,31 @@ class ReorderStage:
         _chk(self._L.spring_reorder_load_synth(self._h, n, L, G, seed, err_ppm))
         self.n, self.max_readlen = n, L
 
+    def load_fastq(self, fastq_1: bytes, fastq_2: bytes = None):
+        """FASTQ text -> N split -> packed reads on the device (preprocess.cpp:186-214,:293-304).
+        Returns the counts the reference stores in compression_params (num_reads, num_reads_clean, max_readlen)."""
+        a = np.frombuffer(fastq_1, dtype=np.uint8)
+        b = np.frombuffer(fastq_2, dtype=np.uint8) if fastq_2 is not None else None
+        info = _lib.FastqInfo()
+        _chk(self._L.spring_reorder_load_fastq(
+            self._h, a.ctypes.data if len(a) else None, len(a),
+            (b.ctypes.data if len(b) else C.c_void_p(1)) if b is not None else None, len(b) if b is not None else 0,
+            C.byref(info)))
+        self.n = info.num_reads_clean[0] + info.num_reads_clean[1]
+        self.max_readlen = max(int(info.max_readlen), 1)
+        return dict(num_reads=list(info.num_reads), num_reads_clean=list(info.num_reads_clean),
+                    num_reads_N=list(info.num_reads_N), max_readlen=int(info.max_readlen))
+
+    def fastq_N(self, which=0):
+        """(input_N.dna bytes, read_order_N.bin array) of input file `which`."""
+        nb, cnt = C.c_size_t(), C.c_uint32()
+        _chk(self._L.spring_reorder_fastq_N(self._h, which, None, 0, C.byref(nb), None, C.byref(cnt)))
+        buf = np.zeros(max(nb.value, 1), np.uint8)
+        order = np.zeros(max(cnt.value, 1), np.uint32)
+        _chk(self._L.spring_reorder_fastq_N(self._h, which, buf.ctypes.data, nb.value, C.byref(nb), order.ctypes.data,
+                                            C.byref(cnt)))
+        return buf[:nb.value].tobytes(), order[:cnt.value]
+
     def build_dict(self):  # constructdictionary (bitset_util.h:74-221)
         _chk(self._L.spring_reorder_build_dict(self._h))
 
@@ -151,10 +176,13 @@ class ReorderStage:
         return limbs[:self.n], ln[:self.n]
 
     def download_dna(self) -> bytes:
-        nb = self._L.spring_synth_dna_bytes(self.n, self.max_readlen)
+        nb = self._L.spring_synth_dna_bytes(self.n, self.max_readlen)  # upper bound (fixed-length records)
         buf = np.zeros(max(nb, 1), np.uint8)
         _chk(self._L.spring_reorder_download_dna(self._h, buf.ctypes.data, nb))
-        return buf[:nb].tobytes()
+        p = 0
+        for _ in range(self.n):  # walk the records to find the end of the stream
+            p += 2 + ((int(buf[p]) | (int(buf[p + 1]) << 8)) + 3) // 4
+        return buf[:p].tobytes()
 
 
 def reorder_dna(dna: bytes, n: int, max_readlen: int, opts: ReorderOpts = None):

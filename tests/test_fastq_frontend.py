@@ -1,0 +1,109 @@
+"""FASTQ -> N split -> packed reads on the GPU vs the restatement of the sequence side of
+preprocess() (read_fastq_block util.cpp:31-54, preprocess.cpp:186-214,:293-304, write_dna[N]_in_bits).
+Uses the reference's own fixtures util/test_{1,2}.fastq (62 of 100 reads of test_1 contain N)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from oracle import pyoracle as po
+
+
+def _fixture(name):
+    return open(os.path.join(GOLDEN, name), "rb").read()
+
+
+def _synth_fastq(seed, n, lmin, lmax, pn=0.1, crlf=False, final_newline=True):
+    rng = np.random.default_rng(seed)
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lmin, lmax + 1))
+        r = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        if rng.random() < pn and L:
+            r[rng.integers(0, L, max(1, L // 20))] = ord("N")
+        out += [b"@r%d" % i, r.tobytes(), b"+", b"I" * L]
+    t = eol.join(out)
+    return t + eol if final_newline else t
+
+
+def test_oracle_preprocess_on_reference_fixture():
+    t = _fixture("test_1.fastq")
+    r = po.preprocess_fastq(t)
+    assert (r["num_reads"], r["num_clean"], r["num_N"], r["max_readlen"]) == (100, 38, 62, 100)
+    # the clean stream is what the reorder tests load (helpers.named_set packs the same reads independently)
+    from helpers import named_set
+    dna, n, L = named_set("test_1")
+    assert r["clean"] == dna and n == 38
+    # N reads: 4 bits per base, decodes back to the text
+    lines = t.split(b"\n")
+    p = 0
+    for k, idx in enumerate(r["order_N"].tolist()):
+        read = lines[4 * idx + 1]
+        ln = r["ndna"][p] | (r["ndna"][p + 1] << 8)
+        assert ln == len(read)
+        body = r["ndna"][p + 2:p + 2 + (ln + 1) // 2]
+        dec = bytes(b"AGCTN"[(body[i // 2] >> (4 * (i % 2))) & 15] for i in range(ln))
+        assert dec == read
+        p += 2 + (ln + 1) // 2
+    assert p == len(r["ndna"])
+
+
+def test_oracle_preprocess_errors_and_line_endings():
+    with pytest.raises(ValueError, match="multiple of 4"):
+        po.preprocess_fastq(b"@a\nACGT\n+\n")
+    with pytest.raises(ValueError, match="Too long"):
+        po.preprocess_fastq(b"@a\n" + b"A" * 600 + b"\n+\n" + b"I" * 600 + b"\n")
+    a = po.preprocess_fastq(_synth_fastq(1, 50, 30, 80))
+    b = po.preprocess_fastq(_synth_fastq(1, 50, 30, 80, crlf=True))
+    c = po.preprocess_fastq(_synth_fastq(1, 50, 30, 80, final_newline=False))
+    assert a["clean"] == b["clean"] == c["clean"] and a["ndna"] == b["ndna"] == c["ndna"]
+    assert po.preprocess_fastq(b"")["num_reads"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["test_1", "test_2", "pe_fixture", "syn_var", "syn_crlf", "syn_nonl", "syn_big", "empty"])
+def test_fastq_frontend_bit_exact(case):
+    import spring_amd
+    f2 = None
+    if case == "test_1": f1 = _fixture("test_1.fastq")
+    elif case == "test_2": f1 = _fixture("test_2.fastq")
+    elif case == "pe_fixture": f1, f2 = _fixture("test_1.fastq"), _fixture("test_2.fastq")
+    elif case == "syn_var": f1 = _synth_fastq(2, 3000, 0, 300, 0.2)
+    elif case == "syn_crlf": f1 = _synth_fastq(3, 2000, 20, 150, 0.1, crlf=True)
+    elif case == "syn_nonl": f1 = _synth_fastq(4, 2000, 20, 150, 0.1, final_newline=False)
+    elif case == "syn_big": f1 = _synth_fastq(5, 200_000, 100, 100, 0.05)
+    else: f1 = b""
+    want = [po.preprocess_fastq(f1)] + ([po.preprocess_fastq(f2)] if f2 is not None else [])
+    with spring_amd.ReorderStage() as s:
+        info = s.load_fastq(f1, f2)
+        for j, w in enumerate(want):
+            assert info["num_reads"][j] == w["num_reads"] and info["num_reads_clean"][j] == w["num_clean"]
+            assert info["num_reads_N"][j] == w["num_N"]
+            nd, on = s.fastq_N(j)
+            assert nd == w["ndna"] and np.array_equal(on, w["order_N"])
+        assert info["max_readlen"] == max(w["max_readlen"] for w in want)
+        assert s.download_dna() == b"".join(w["clean"] for w in want)
+        # and the stage runs on it exactly as on the .dna stream the reference would have written
+        n, L = s.n, s.max_readlen
+        if n:
+            got = s.run().streams()
+            read, ln = po.load_dna(b"".join(w["clean"] for w in want), n, L)
+            ref = po.reorder_rounds(read, ln, L, max(1, min(65536, n >> 10)), 1)
+            for k in ("order", "rc", "flag", "pos", "rlen", "order_s"):
+                assert np.array_equal(got[k], ref[k]), (case, k)
+
+
+@pytest.mark.gpu
+def test_fastq_frontend_errors():
+    import spring_amd
+    with spring_amd.ReorderStage() as s:
+        with pytest.raises(spring_amd.ReorderError, match="multiple of 4"):
+            s.load_fastq(b"@a\nACGT\n+\n")
+    with spring_amd.ReorderStage() as s:
+        with pytest.raises(spring_amd.ReorderError, match="Too long read length"):
+            s.load_fastq(b"@a\n" + b"A" * 600 + b"\n+\n" + b"I" * 600 + b"\n")
+    with spring_amd.ReorderStage() as s:
+        with pytest.raises(spring_amd.ReorderError, match="paired files do not match"):
+            s.load_fastq(_synth_fastq(6, 10, 50, 50), _synth_fastq(7, 11, 50, 50))
