@@ -117,6 +117,8 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx);
 typedef struct {
   uint32_t num_reads[2], num_reads_clean[2], num_reads_N[2];
   uint32_t max_readlen; /* over all reads, with or without N (preprocess.cpp:312-315) */
+  uint32_t pad;
+  double ms_device;     /* device time from the first parse kernel to the end of packing + unpack (HIP events) */
 } spring_fastq_info;
 int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, size_t nbytes_1, const uint8_t *fastq_2,
                               size_t nbytes_2 /* fastq_2 = NULL: single end */, spring_fastq_info *info);

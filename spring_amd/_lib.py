@@ -27,7 +27,7 @@ class Opts(C.Structure):
 
 class FastqInfo(C.Structure):
     _fields_ = [("num_reads", C.c_uint32 * 2), ("num_reads_clean", C.c_uint32 * 2), ("num_reads_N", C.c_uint32 * 2),
-                ("max_readlen", C.c_uint32)]
+                ("max_readlen", C.c_uint32), ("pad", C.c_uint32), ("ms_device", C.c_double)]
 
 
 class Stats(C.Structure):

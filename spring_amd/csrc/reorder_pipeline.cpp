@@ -137,6 +137,7 @@ struct spring_reorder_ctx {
   uint32_t *d_orderN[2] = {nullptr, nullptr};
   uint64_t N_bytes[2] = {0, 0};
   spring_fastq_info fq;
+  double fq_ms = 0;
   std::vector<uint64_t> tid_off, tid_off_s;
   spring_reorder_stats stats;
   hipEvent_t ev[8];
@@ -347,6 +348,7 @@ static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbyt
   if (!nbytes) return 0;
   DMALLOC(f.d_txt, nbytes + 16);
   HIPCHK(hipMemcpyAsync(f.d_txt, txt, nbytes, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(ctx->ev[6], st));  // device time of the parse kernels (after the H2D copy)
   const uint64_t nblk = (nbytes + NL_CHUNK_BYTES - 1) / NL_CHUNK_BYTES;
   uint32_t *blk_cnt = nullptr;
   uint64_t *blk_off = nullptr;
@@ -409,6 +411,9 @@ static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbyt
   HIPCHK(hipMemcpyAsync(&f.maxlen, d_max, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   f.n_clean = lc + lf; f.n_N = ln + lfn; f.clean_bytes = lco + lsz; f.N_bytes = lno + lszn;
+  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  HIPCHK(hipEventSynchronize(ctx->ev[7]));
+  { float ms = 0; if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->fq_ms += ms; }
   ctx->dfree(blk_cnt); ctx->dfree(blk_off); ctx->dfree(tmp); ctx->dfree(d_max);
   return 0;
 }
@@ -425,6 +430,7 @@ int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, s
   DMALLOC(d_err, 16);
   HIPCHK(hipMemsetAsync(d_err, 0, 4, st));
   FqFile f[2];
+  double ms_dev = 0;
   int r = fq_scan_file(ctx, fastq_1, nbytes_1, f[0], d_err);
   if (r) return r;
   if (paired && (r = fq_scan_file(ctx, fastq_2, nbytes_2, f[1], d_err))) return r;
@@ -449,6 +455,7 @@ int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, s
   DMALLOC(ctx->d_off, (size_t)std::max<uint32_t>(n_clean, 1) * 8);
   uint32_t cbase = 0, rbase = 0;
   uint64_t obase = 0;
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
   for (int j = 0; j < 2; j++) {
     if (!f[j].nreads) continue;
     DMALLOC(ctx->d_N[j], f[j].N_bytes + 16);
@@ -464,7 +471,12 @@ int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, s
   ctx->uniform = false;  // lengths are read from the lens array (a min-length reduction could enable the fast path)
   r = unpack_on_device(ctx);
   if (r) return r;
+  HIPCHK(hipEventRecord(ctx->ev[7], st));
   HIPCHK(hipStreamSynchronize(st));
+  { float ms = 0; if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->fq_ms += ms; }
+  ms_dev = ctx->fq_ms;
+  ctx->fq.ms_device = ms_dev;
+  if (info) info->ms_device = ms_dev;
   for (int j = 0; j < 2; j++) {
     ctx->dfree(f[j].d_txt); ctx->dfree(f[j].line_end); ctx->dfree(f[j].len); ctx->dfree(f[j].fclean); ctx->dfree(f[j].szc);
     ctx->dfree(f[j].fN); ctx->dfree(f[j].szN); ctx->dfree(f[j].cidx); ctx->dfree(f[j].nidx); ctx->dfree(f[j].coff);

@@ -101,7 +101,8 @@ class ReorderStage:
         self.n = info.num_reads_clean[0] + info.num_reads_clean[1]
         self.max_readlen = max(int(info.max_readlen), 1)
         return dict(num_reads=list(info.num_reads), num_reads_clean=list(info.num_reads_clean),
-                    num_reads_N=list(info.num_reads_N), max_readlen=int(info.max_readlen))
+                    num_reads_N=list(info.num_reads_N), max_readlen=int(info.max_readlen),
+                    ms_device=float(info.ms_device))
 
     def fastq_N(self, which=0):
         """(input_N.dna bytes, read_order_N.bin array) of input file `which`."""
