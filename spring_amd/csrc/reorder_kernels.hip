@@ -1102,7 +1102,8 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
     return;
   }
   if (literal) { hipLaunchKernelGGL((k_apply<8, true, false>), g, b, 0, st, P); return; }
-#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, false>), g, b, 0, st, P)
+  static const int dbg_lds = getenv("SPRING_DBG_APPLY_LDS") ? atoi(getenv("SPRING_DBG_APPLY_LDS")) : 0;  // occupancy experiment
+#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, false>), g, b, (size_t)dbg_lds, st, P)
   NP_DISPATCH(CALL);
 #undef CALL
 }
