@@ -11,6 +11,7 @@ namespace sr {
 constexpr int MAX_READ_LEN = 511;   // params.h:22
 constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
 constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
+constexpr uint32_t DEEP_BIN = 16;   // bins with at least this many reads are tail-trimmed between rounds
 constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
 constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in LDS
 constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
@@ -93,7 +94,10 @@ void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int d
 void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
                  int S, int dstart, int dend, uint64_t *keys, uint32_t *vals);
 void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask);
+                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask,
+                       uint32_t *deep, uint32_t *ndeep);
+void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
+                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken);
 void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count);

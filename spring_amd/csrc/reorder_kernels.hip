@@ -167,11 +167,13 @@ __global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__res
 // one thread per unique key: writes its {key,start,count} record and claims a bucket slot.
 __global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
                              const uint32_t *__restrict__ ucount, const uint32_t *__restrict__ ids,
-                             uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, uint64_t bmask) {
+                             uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, uint64_t bmask,
+                             uint32_t *__restrict__ deep, uint32_t *__restrict__ ndeep) {
   uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= numkeys) return;
   const uint64_t key = ukeys[u];
   const uint32_t st = ustart[u], cn = ucount[u];
+  if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
   urec[u] = make_ulonglong2(key, (uint64_t)st | ((uint64_t)cn << 32));
   const uint64_t h = mix64(key);
   const bool single = cn == 1;
@@ -188,6 +190,25 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t 
     }
     b = (b + 1) & bmask;
   }
+}
+
+// Dead-tail trim of deep bins.  Chains consume a bin from its tail (highest read ids first), so on very
+// deep bins (PhiX-like coverage) every probe would re-skip an ever growing run of taken reads.  Entries above
+// the first live one are taken for good, so shrinking the bin's count never changes a result; the reference
+// gets the same effect from bbhashdict::remove (bitset_util.cpp:37-63).  Runs between rounds, over the list
+// of deep bins only (collected by k_tab_insert), so the hot search kernel carries no extra state.
+__global__ void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *__restrict__ ndeep,
+                            ulonglong2 *__restrict__ urec, const uint32_t *__restrict__ ids,
+                            const uint64_t *__restrict__ taken) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *ndeep) return;
+  const uint32_t u = deep[i];
+  const ulonglong2 rec = urec[u];
+  const uint32_t start = (uint32_t)rec.y;
+  int j = (int)(uint32_t)(rec.y >> 32) - 1;
+  const int j0 = j;
+  while (j >= 0 && is_taken(taken, ids[start + j])) j--;
+  if (j != j0) urec[u].y = (uint64_t)start | ((uint64_t)(uint32_t)(j + 1) << 32);
 }
 
 // test hook: start/count of the bin of each key; single-read bins report count = 1 | 0x80000000
@@ -624,20 +645,13 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
       const ulonglong2 rec = urec[pay];
       if (rec.x != key) continue;  // fingerprint collision
       const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
-      int live = 0, top_live = -1, j = (int)count - 1;
-      for (; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
+      int live = 0;
+      for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
         const uint32_t r = ids[start + j];
         if (is_taken(P.taken, r)) continue;
-        if (top_live < 0) top_live = j;
         live++; keyok = true; ncand++;
         if (within_thresh(r)) { hit = true; rid = r; break; }
       }
-      // Lazy trim of the dead tail: chains consume bins from the tail, so on deep bins (PhiX-like
-      // coverage) every later probe would re-skip the same taken reads.  Entries above the first
-      // live one are taken for good, so shrinking the count never changes a result; the reference
-      // gets the same effect from bbhashdict::remove (bitset_util.cpp:37-63).  Racing trims are benign.
-      const int keep = top_live >= 0 ? top_live + 1 : (j < 0 ? 0 : (int)count);
-      if (keep < (int)count) atomicMin(reinterpret_cast<unsigned int *>(const_cast<ulonglong2 *>(&urec[pay])) + 3, (unsigned int)keep);
       break;
     }
   }
@@ -724,6 +738,13 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
     return;
   }
 
+  // the bookkeeping fields changed above go back now; the 64-byte header is not kept in registers across
+  // the probe loop (the kernel is latency-bound at 8 waves/SIMD, i.e. 64 VGPRs, so every register counts)
+  const int ref_len = h.ref_len;
+  if (lane == 0 && new_iter) {
+    c->h.num_reads_thr = h.num_reads_thr;
+    c->h.num_unmatched_past = h.num_unmatched_past;
+  }
   const uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
   wave_sync();
   // batches of 16 shifts in priority order; most chains match in batch 0
@@ -732,21 +753,22 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   uint64_t st_p = 0, st_k = 0, st_c = 0;
   int wb = 0;
   for (int b = 0; b < nbatch; b++) {
-    probe_batch<STATS>(P, sref, srev, b, lane, h.ref_len, o);
+    probe_batch<STATS>(P, sref, srev, b, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     if (o.found) { wb = b; break; }
   }
   if (lane == 0) {
     if (o.found) {
-      h.prop_kind = PROP_MATCH; h.prop_rid = o.rid; h.prop_shift = wb * 16 + (int)(o.win >> 2);
-      h.prop_rev = (uint8_t)((o.win >> 1) & 1);
+      c->h.prop_rid = o.rid;
+      c->h.prop_shift = wb * 16 + (int)(o.win >> 2);
+      c->h.prop_rev = (uint8_t)((o.win >> 1) & 1);
+      c->h.prop_kind = PROP_MATCH;
       if (MG) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;  // resolved after the exchange
       else atomicMin(&P.resv[o.rid], cid);
     } else {
-      h.prop_kind = PROP_NONE;
+      c->h.prop_kind = PROP_NONE;
       if (MG) P.prop[cid] = (unsigned long long)PK_NONE << 32;
     }
-    store_hot(c, h);
     if (STATS) {
       c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c;
       if (o.found) c->st_hits++;
@@ -1040,10 +1062,16 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
   hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
 }
 void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask) {
+                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask,
+                       uint32_t *deep, uint32_t *ndeep) {
   if (!numkeys) return;
   hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
-                     reinterpret_cast<uint32_t *>(fpt), urec, bmask);
+                     reinterpret_cast<uint32_t *>(fpt), urec, bmask, deep, ndeep);
+}
+void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
+                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken) {
+  if (!ndeep_host) return;
+  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 256), dim3(256), 0, st, deep, ndeep, urec, ids, taken);
 }
 void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,

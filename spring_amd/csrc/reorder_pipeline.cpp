@@ -108,6 +108,8 @@ struct DictDev {
   uint4 *fpt = nullptr;
   ulonglong2 *urec = nullptr;
   uint32_t *ids = nullptr;
+  uint32_t *deep = nullptr, *d_ndeep = nullptr;  // bins with >= DEEP_BIN reads (k_trim_bins)
+  uint32_t ndeep = 0;
 };
 
 struct spring_reorder_ctx {
@@ -675,8 +677,13 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     DBG_T("alloc tab");
     HIPCHK(hipMemsetAsync(d.fpt, 0, nb * 32, st));
     DBG_T("memset tab");
-    launch_tab_insert(st, k_in, ustart, cnt, d.ids, numkeys, d.fpt, d.urec, d.bmask);
+    // deep-bin list: at most one entry per DEEP_BIN reads of the dictionary
+    DMALLOC(d.deep, ((size_t)m / DEEP_BIN + 1) * 4);
+    DMALLOC(d.d_ndeep, 16);
+    HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 4, st));
+    launch_tab_insert(st, k_in, ustart, cnt, d.ids, numkeys, d.fpt, d.urec, d.bmask, d.deep, d.d_ndeep);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&d.ndeep, d.d_ndeep, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     DBG_T("insert");
     ctx->dfree(d_tmp); ctx->dfree(k_in); ctx->dfree(k_out); ctx->dfree(v_in); ctx->dfree(cnt);
@@ -809,6 +816,8 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
       launch_apply(st, P, literal);
     }
     rounds += R;
+    for (int l = 0; l < 2; l++)  // shrink deep bins whose tail has been consumed (exact; see k_trim_bins)
+      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
     HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -923,6 +932,9 @@ int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32
   launch_mg_mark(st, ctx->P);
   HIPCHK(hipGetLastError());
   ctx->stats.rounds++;
+  if (ctx->stats.rounds % 16 == 0)
+    for (int l = 0; l < 2; l++)
+      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, ctx->P.taken);
   if (check_alive) {
     uint32_t a = 0;
     HIPCHK(hipMemcpyAsync(&a, ctx->P.alive_round, 4, hipMemcpyDeviceToHost, st));
