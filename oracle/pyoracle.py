@@ -172,6 +172,13 @@ def reorder_omp(read, ln, L, num_threads):
     return _finish(o, arrs, st)
 
 
+def last_omp_phases():
+    """(dictionary seconds, chain seconds) of the last reorder_omp call."""
+    out = (C.c_double * 2)()
+    lib().orc_last_omp_phases(out)
+    return float(out[0]), float(out[1])
+
+
 def write_dna_stream(read, ln, L, order, rc=None):
     """writetofile(): bytes of temp.dna.<tid> (rc given) or temp.dna.singleton (rc None)."""
     read = np.ascontiguousarray(read, dtype=np.uint64)

@@ -8,6 +8,7 @@
  */
 #include "reorder_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -963,6 +964,9 @@ void orc_updaterefcount(const uint64_t *cur, int32_t *cnt, uint64_t *ref, uint64
 #ifdef _OPENMP
 #include <omp.h>
 
+static double g_omp_phase[2]; /* seconds: dictionaries, chains of the last orc_reorder_omp call */
+void orc_last_omp_phases(double *out) { out[0] = g_omp_phase[0]; out[1] = g_omp_phase[1]; }
+
 typedef struct { uint64_t k; uint32_t v; } kv_t;
 
 static void par_radix_sort(kv_t *a, kv_t *tmp, size_t n, int nbits, int T) {
@@ -999,7 +1003,10 @@ static void dict_build_par(dict_t *d, const uint64_t *read, const uint16_t *len,
     if ((int)len[i] > d->end) { a[m].v = i; m++; }
 #pragma omp parallel for num_threads(T) schedule(static)
   for (uint32_t j = 0; j < m; j++) a[j].k = read_key(read + (size_t)a[j].v * W, W, d);
+  double tt = omp_get_wtime();
   par_radix_sort(a, tmp, m, 2 * (d->end - d->start + 1), T);
+  if (getenv("ORC_TIMING")) fprintf(stderr, "[orc_omp]   radix sort %.2f s\n", omp_get_wtime() - tt);
+  tt = omp_get_wtime();
   d->dict_numreads = m;
   d->keys = (uint64_t *)malloc(sizeof(uint64_t) * (m ? m : 1));
   d->startpos = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)m + 1));
@@ -1015,12 +1022,19 @@ static void dict_build_par(dict_t *d, const uint64_t *read, const uint16_t *len,
   uint64_t cap = 2;
   while (cap < 2ull * nk) cap <<= 1;
   d->hmask = cap - 1;
+  if (getenv("ORC_TIMING")) fprintf(stderr, "[orc_omp]   unique/fill %.2f s\n", omp_get_wtime() - tt);
+  tt = omp_get_wtime();
   d->htab = (uint32_t *)calloc(cap, sizeof(uint32_t));
-  for (uint32_t i = 0; i < nk; i++) {
+#pragma omp parallel for num_threads(T) schedule(static)
+  for (uint32_t i = 0; i < nk; i++) { /* keys are distinct: claim the first free slot with a CAS */
     uint64_t h = mix64(d->keys[i]) & d->hmask;
-    while (d->htab[h]) h = (h + 1) & d->hmask;
-    d->htab[h] = i + 1;
+    for (;;) {
+      uint32_t z = 0;
+      if (__atomic_compare_exchange_n(&d->htab[h], &z, i + 1, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+      h = (h + 1) & d->hmask;
+    }
   }
+  if (getenv("ORC_TIMING")) fprintf(stderr, "[orc_omp]   hash insert %.2f s\n", omp_get_wtime() - tt);
   free(a); free(tmp);
 }
 
@@ -1040,7 +1054,12 @@ int orc_reorder_omp(const uint64_t *read, const uint16_t *len, uint32_t n, int L
   int s[2], e[2];
   orc_dict_windows(L, s, e);
   for (int l = 0; l < 2; l++) { x.dict[l].start = s[l]; x.dict[l].end = e[l]; }
+  const int timing = getenv("ORC_TIMING") != NULL;
+  double t0 = omp_get_wtime();
   if (n > 0) for (int l = 0; l < 2; l++) dict_build_par(&x.dict[l], read, len, n, W, T);
+  g_omp_phase[0] = omp_get_wtime() - t0;
+  if (timing) fprintf(stderr, "[orc_omp] dict build %.2f s\n", g_omp_phase[0]);
+  t0 = omp_get_wtime();
   x.taken = (uint8_t *)calloc(n ? n : 1, 1);
   outbuf_t *obs = (outbuf_t *)calloc((size_t)T, sizeof(outbuf_t));
   uint64_t tot_unmatched = 0, tot_iter = 0;
@@ -1146,6 +1165,8 @@ int orc_reorder_omp(const uint64_t *read, const uint16_t *len, uint32_t n, int L
     }
     free(c);
   }
+  g_omp_phase[1] = omp_get_wtime() - t0;
+  if (timing) fprintf(stderr, "[orc_omp] chains %.2f s\n", g_omp_phase[1]);
   uint64_t nm = 0, ns = 0;
   for (int t = 0; t < T; t++) {
     outbuf_t *o = &obs[t];
