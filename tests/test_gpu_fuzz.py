@@ -1,0 +1,86 @@
+"""Randomised differential test: the HIP path vs the oracle on many small random read sets with random
+geometry (read length, fixed/variable, error rate, duplicates, coverage) and random schedule parameters
+(chains K, output sets T).  Bit-exact or fail; the seed of a failing case is in the assertion message."""
+import os
+
+import numpy as np
+import pytest
+
+import readsets as rs
+from helpers import KEYS, check_invariants
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 5)
+    L = int(rng.choice([20, 33, 50, 64, 75, 100, 101, 127, 128, 150, 151, 200, 250, 300, 400, 511]))
+    n = int(rng.integers(1, 2500))
+    err = float(rng.choice([0.0, 0.002, 0.01, 0.03, 0.08]))
+    cov = int(rng.choice([2, 8, 25, 60, 400]))
+    G = max(n * L // cov, L + 5)
+    if kind == 0:  # fixed length
+        dna = rs.pack_fixed(rs.np_reads(seed, G, n, L, err)); maxlen = L
+    elif kind == 1:  # variable length
+        lmin = int(rng.integers(1, L + 1))
+        reads = rs.var_length_reads(seed, max(G, L + 5), n, lmin, L, err)
+        dna = rs.pack_var(reads); maxlen = max(len(r) for r in reads)
+    elif kind == 2:  # heavy duplicates
+        base = rs.np_reads(seed, max(G // 20, L + 5), max(n // 20, 1), L, 0.0)
+        a = np.repeat(base, 20, axis=0)[:n]
+        flip = rng.random(a.shape) < err
+        a = np.where(flip, np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, a.shape)], a).astype(np.uint8)
+        rng.shuffle(a, axis=0)
+        n = a.shape[0]; dna = rs.pack_fixed(a); maxlen = L
+    elif kind == 3:  # repeat-rich genome
+        dna = rs.pack_fixed(rs.np_reads_repeat(seed, max(G, 16 * L), n, L, err)); maxlen = L
+    else:  # mostly short reads + a few at max length (many reads outside one or both dictionaries)
+        reads = rs.var_length_reads(seed, max(G, L + 5), n, 1, max(L // 2, 1), err)
+        reads += rs.var_length_reads(seed + 1, max(G, L + 5), max(n // 10, 1), L, L, err)
+        n = len(reads); dna = rs.pack_var(reads); maxlen = L
+    K = int(rng.choice([1, 2, 3, 7, 16, 63, 256, 1000, 4096]))
+    T = int(rng.choice([1, 2, 3, 8]))
+    return dna, n, maxlen, K, T
+
+
+_BLOCKS = int(os.environ.get("SPRING_FUZZ_BLOCKS", "8"))  # 25 cases per block; raise for a long one-off sweep
+
+
+@pytest.mark.parametrize("block", range(_BLOCKS))
+def test_fuzz_gpu_equals_oracle(block):
+    import spring_amd
+    for seed in range(1000 + 25 * block, 1000 + 25 * (block + 1)):
+        dna, n, L, K, T = _random_case(seed)
+        read, ln = po.load_dna(dna, n, L)
+        want = po.reorder_rounds(read, ln, L, K, T)
+        got = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, collect_stats=True))
+        for k in KEYS:
+            assert np.array_equal(got[k], want[k]), ("seed", seed, "n", n, "L", L, "K", K, "T", T, k)
+        assert np.array_equal(got["tid_off"], want["tid_off"]), ("seed", seed)
+        for k in ("probes", "keyok", "cands", "hits", "iterations", "lost", "unmatched"):
+            assert got["stats"][k] == want["stats"][k], ("seed", seed, k, got["stats"][k], want["stats"][k])
+        check_invariants(got, read, ln, L, n)
+        if K == 1:
+            ser = po.reorder_serial(read, ln, L)
+            for k in KEYS:
+                assert np.array_equal(got[k], ser[k]), ("seed", seed, "serial", k)
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_fuzz_single_pool_virtual_ranks(block):
+    from spring_amd.pool import VirtualPool
+    for seed in range(5000 + 6 * block, 5000 + 6 * (block + 1)):
+        dna, n, L, K, T = _random_case(seed)
+        G = int(np.random.default_rng(seed).choice([2, 3, 4]))
+        K = max(G, (K // G) * G)
+        read, ln = po.load_dna(dna, n, L)
+        want = po.reorder_rounds(read, ln, L, K, T)
+        vp = VirtualPool(G, K, T)
+        try:
+            got = vp.run(lambda s: s.load_dna(dna, n, L))
+        finally:
+            vp.close()
+        for k in KEYS:
+            assert np.array_equal(got[k], want[k]), ("seed", seed, "G", G, "K", K, k)
