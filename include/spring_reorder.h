@@ -196,6 +196,8 @@ int spring_order_correct(uint32_t *order, uint64_t m, const uint32_t *order_N, u
  * counter-based generator (splitmix64 of the index), so the host and the
  * device version produce identical bytes.  Output = .dna record stream.
  */
+#define SPRING_SYNTH_REPEATS 0x80000000u /* OR into err_ppm: genome whose eighths 0,2,4,6 are exact copies
+                                            (the repeat-rich "hard" distribution of SURVEY.md 8(d)) */
 size_t spring_synth_dna_bytes(uint32_t n, uint32_t L);
 int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
 /* generates into a device buffer the caller owns (e.g. a torch uint8 tensor); stream = 0. */

@@ -16,6 +16,8 @@
 #define SYN_HD static inline
 #endif
 
+#define SYN_REPEAT_FLAG 0x80000000u  // top bit of err_ppm / err_thr24: genome with 4 exact copies of one unit
+
 SYN_HD uint64_t syn_sm64(uint64_t x) {  // splitmix64 finalizer
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -41,7 +43,13 @@ SYN_HD uint64_t syn_mulhi64(uint64_t a, uint64_t b) {
 SYN_HD uint32_t syn_read_base(uint64_t seed, uint64_t G, uint32_t L, uint32_t err_thr24, uint64_t i,
                               uint32_t j, uint64_t pos, uint32_t rc) {
   uint32_t jj = rc ? (L - 1 - j) : j;  // position on the forward strand
-  uint32_t b = syn_genome_base(seed, pos + jj);
+  uint64_t gp = pos + jj;
+  if (err_thr24 & SYN_REPEAT_FLAG) {  // "hard" genome: eighths 0,2,4,6 are exact copies of eighth 0
+    const uint64_t seg = G / 8, k = seg ? gp / seg : 0;
+    if (seg && k < 8 && (k & 1) == 0) gp %= seg;
+  }
+  err_thr24 &= ~SYN_REPEAT_FLAG;
+  uint32_t b = syn_genome_base(seed, gp);
   uint64_t e = syn_sm64((seed * 0x2545F4914F6CDD1Dull) ^ (i * 512ull + (jj >> 1)) ^ 0x5EEDull);
   uint32_t h = (uint32_t)(e >> (32 * (jj & 1)));
   if ((h & 0xFFFFFFu) < err_thr24) b = (b + 1u + ((h >> 24) % 3u)) & 3u;
@@ -57,6 +65,8 @@ SYN_HD void syn_read_params(uint64_t seed, uint64_t G, uint32_t L, uint64_t i, u
 // natural code (A0 C1 G2 T3) -> SPRING 2-bit code (A0 G1 C2 T3, util.cpp:270-274)
 SYN_HD uint32_t syn_nat_to_spring(uint32_t b) { return (b == 1u) ? 2u : (b == 2u) ? 1u : b; }
 
-SYN_HD uint32_t syn_err_thr24(uint32_t err_ppm) { return (uint32_t)(((uint64_t)err_ppm << 24) / 1000000ull); }
+SYN_HD uint32_t syn_err_thr24(uint32_t err_ppm) {
+  return (uint32_t)(((uint64_t)(err_ppm & ~SYN_REPEAT_FLAG) << 24) / 1000000ull) | (err_ppm & SYN_REPEAT_FLAG);
+}
 
 #endif

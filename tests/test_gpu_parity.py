@@ -184,6 +184,11 @@ def test_synth_host_equals_device():
         s.load_synth(n, L, G, 11, 10000)
         dev = s.download_dna()
     assert dev == sa.synth_dna_host(n, L, G, 11, 10000)
+    rep = 20000 | 0x80000000  # SPRING_SYNTH_REPEATS: genome with four exact copies of one unit
+    with sa.ReorderStage() as s:
+        s.load_synth(n, L, G, 12, rep)
+        dev2 = s.download_dna()
+    assert dev2 == sa.synth_dna_host(n, L, G, 12, rep) and dev2 != dev
 
 
 def test_config2_1M_100bp_k1_bit_exact():

@@ -4,11 +4,11 @@ import torch, numpy as np
 import spring_amd
 from spring_amd import _lib
 L_ = _lib.lib()
-def run(n, L, K, stats=False, timed=False, rps=0):
+def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False):
     G = n * L // 25
     nb = L_.spring_synth_dna_bytes(n, L)
     buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 11, 10000); assert rc == 0
+    rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 11, err | (0x80000000 if repeats else 0)); assert rc == 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     s = spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8, collect_stats=stats, time_search=timed, rounds_per_sync=rps))
@@ -21,5 +21,6 @@ def run(n, L, K, stats=False, timed=False, rps=0):
         n, L, K, t1-t0, st["ms_unpack"], st["ms_dict"], st["ms_chains"], st["ms_finalize"], st["rounds"], st["unmatched"], st["n_single"], n/(t1-t0)/1e6, st["ms_search_kernel"], st["search_launches"], st["lost"], st["device_bytes"]/1e9), flush=True)
     return st
 for a in sys.argv[1:]:
-    n, L, K = [int(x) for x in a.split(",")[:3]]
-    run(n, L, K)
+    f = a.split(",")
+    n, L, K = [int(x) for x in f[:3]]
+    run(n, L, K, err=int(f[3]) if len(f) > 3 else 10000, repeats=len(f) > 4 and f[4] == "rep")
