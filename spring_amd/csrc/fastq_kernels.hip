@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void k_nl_fill(const uint8_t *__restrict__ t, 
 __global__ __launch_bounds__(256) void k_read_info(const uint8_t *__restrict__ t, const uint64_t *__restrict__ line_end,
                                                    uint64_t nreads, uint32_t *__restrict__ len, uint32_t *__restrict__ fclean,
                                                    uint32_t *__restrict__ szc, uint32_t *__restrict__ fN,
-                                                   uint32_t *__restrict__ szN, uint32_t *__restrict__ err) {
+                                                   uint32_t *__restrict__ szN, uint32_t *__restrict__ lenc,
+                                                   uint32_t *__restrict__ err) {
   const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int l16 = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
   uint64_t s = 0, e = 0;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_read_info(const uint8_t *__restrict__ t
     fN[i] = anyN ? 1u : 0u;
     szc[i] = anyN ? 0u : 2u + (L32 + 3u) / 4u;
     szN[i] = anyN ? 2u + (L32 + 1u) / 2u : 0u;
+    lenc[i] = anyN ? 0xffffffffu : L32;  // for the minimum clean length (equal-length fast path)
   }
 }
 
@@ -160,8 +162,8 @@ void launch_nl_fill(hipStream_t st, const uint8_t *t, uint64_t nbytes, const uin
   if (nblk) hipLaunchKernelGGL(k_nl_fill, dim3((unsigned)nblk), dim3(256), 0, st, t, nbytes, blk_off, line_end);
 }
 void launch_read_info(hipStream_t st, const uint8_t *t, const uint64_t *line_end, uint64_t nreads, uint32_t *len,
-                      uint32_t *fclean, uint32_t *szc, uint32_t *fN, uint32_t *szN, uint32_t *err) {
-  if (nreads) hipLaunchKernelGGL(k_read_info, GRIDN(nreads, 16), dim3(256), 0, st, t, line_end, nreads, len, fclean, szc, fN, szN, err);
+                      uint32_t *fclean, uint32_t *szc, uint32_t *fN, uint32_t *szN, uint32_t *lenc, uint32_t *err) {
+  if (nreads) hipLaunchKernelGGL(k_read_info, GRIDN(nreads, 16), dim3(256), 0, st, t, line_end, nreads, len, fclean, szc, fN, szN, lenc, err);
 }
 void launch_pack_reads(hipStream_t st, const uint8_t *t, const uint64_t *line_end, uint64_t nreads, const uint32_t *len,
                        const uint32_t *fclean, const uint32_t *cidx, const uint64_t *coff, const uint32_t *nidx,
@@ -173,6 +175,9 @@ void launch_pack_reads(hipStream_t st, const uint8_t *t, const uint64_t *line_en
 }
 hipError_t reduce_max_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n) {
   return rocprim::reduce(tmp, tmp_bytes, in, out, 0u, n, rocprim::maximum<uint32_t>(), st);
+}
+hipError_t reduce_min_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n) {
+  return rocprim::reduce(tmp, tmp_bytes, in, out, 0xffffffffu, n, rocprim::minimum<uint32_t>(), st);
 }
 
 }  // namespace sr

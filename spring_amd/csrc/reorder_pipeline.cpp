@@ -339,7 +339,7 @@ struct FqFile {
   uint64_t *line_end = nullptr;
   uint32_t *len = nullptr, *fclean = nullptr, *szc = nullptr, *fN = nullptr, *szN = nullptr, *cidx = nullptr, *nidx = nullptr;
   uint64_t *coff = nullptr, *noff = nullptr;
-  uint32_t n_clean = 0, n_N = 0, maxlen = 0;
+  uint32_t n_clean = 0, n_N = 0, maxlen = 0, min_clean = 0xffffffffu;
   uint64_t clean_bytes = 0, N_bytes = 0;
 };
 }  // namespace
@@ -384,7 +384,9 @@ static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbyt
   if (!nr) { ctx->dfree(blk_cnt); ctx->dfree(blk_off); ctx->dfree(tmp); return 0; }
   DMALLOC(f.len, nr * 4); DMALLOC(f.fclean, nr * 4); DMALLOC(f.szc, nr * 4); DMALLOC(f.fN, nr * 4); DMALLOC(f.szN, nr * 4);
   DMALLOC(f.cidx, nr * 4); DMALLOC(f.nidx, nr * 4); DMALLOC(f.coff, nr * 8); DMALLOC(f.noff, nr * 8);
-  launch_read_info(st, f.d_txt, f.line_end, nr, f.len, f.fclean, f.szc, f.fN, f.szN, d_err);
+  uint32_t *lenc = nullptr;
+  DMALLOC(lenc, nr * 4);
+  launch_read_info(st, f.d_txt, f.line_end, nr, f.len, f.fclean, f.szc, f.fN, f.szN, lenc, d_err);
   HIPCHK(hipGetLastError());
   ctx->dfree(tmp); tmp = nullptr;
   size_t t1 = 0, t2 = 0, t3 = 0;
@@ -400,6 +402,7 @@ static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbyt
   HIPCHK(excl_scan_u32_to_u64(st, tmp, tb, f.szc, f.coff, nr));
   HIPCHK(excl_scan_u32_to_u64(st, tmp, tb, f.szN, f.noff, nr));
   HIPCHK(reduce_max_u32(st, tmp, tb, f.len, d_max, nr));
+  HIPCHK(reduce_min_u32(st, tmp, tb, lenc, d_max + 1, nr));
   uint32_t lc = 0, lf = 0, ln = 0, lfn = 0, lsz = 0, lszn = 0;
   uint64_t lco = 0, lno = 0;
   HIPCHK(hipMemcpyAsync(&lc, f.cidx + (nr - 1), 4, hipMemcpyDeviceToHost, st));
@@ -411,12 +414,13 @@ static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbyt
   HIPCHK(hipMemcpyAsync(&lno, f.noff + (nr - 1), 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&lszn, f.szN + (nr - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&f.maxlen, d_max, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&f.min_clean, d_max + 1, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   f.n_clean = lc + lf; f.n_N = ln + lfn; f.clean_bytes = lco + lsz; f.N_bytes = lno + lszn;
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   HIPCHK(hipEventSynchronize(ctx->ev[7]));
   { float ms = 0; if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->fq_ms += ms; }
-  ctx->dfree(blk_cnt); ctx->dfree(blk_off); ctx->dfree(tmp); ctx->dfree(d_max);
+  ctx->dfree(blk_cnt); ctx->dfree(blk_off); ctx->dfree(tmp); ctx->dfree(d_max); ctx->dfree(lenc);
   return 0;
 }
 
@@ -470,7 +474,9 @@ int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, s
     cbase += f[j].n_clean; obase += f[j].clean_bytes; rbase += (uint32_t)f[j].nreads;
   }
   (void)rbase;
-  ctx->uniform = false;  // lengths are read from the lens array (a min-length reduction could enable the fast path)
+  // every clean read as long as max_readlen => fixed-size records, and the search skips the length loads
+  ctx->uniform = n_clean > 0 && std::min(f[0].min_clean, f[1].min_clean) == maxlen;
+  if (ctx->uniform) { ctx->dfree(ctx->d_off); ctx->d_off = nullptr; }
   r = unpack_on_device(ctx);
   if (r) return r;
   HIPCHK(hipEventRecord(ctx->ev[7], st));
