@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "reorder_device.h"
@@ -48,9 +51,6 @@ using namespace sr;
 // the stage itself.  Blocks released by a context are cached per device and handed to
 // the next context (sizes rounded to 2 MiB so repeated runs hit exactly).
 // spring_reorder_trim_pool() gives the memory back to the driver.
-#include <map>
-#include <mutex>
-#include <unordered_map>
 namespace {
 struct DevPool {
   std::mutex mu;

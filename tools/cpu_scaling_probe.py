@@ -1,6 +1,6 @@
 """CPU baseline port scaling on this host: orc_reorder_omp at several thread counts (same 8 M-read sample)."""
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import spring_amd
 from oracle import pyoracle as po
 n, L = 8_000_000, 150

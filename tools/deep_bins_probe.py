@@ -1,6 +1,6 @@
 """PhiX-like stress: n reads over a tiny genome -> every dictionary bin holds hundreds to thousands of reads."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import spring_amd
 for a in sys.argv[1:]:
     n, L, G, K = [int(x) for x in a.split(",")]

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import spring_amd
 n, L, G, K = 10000000, 100, 5400, 8192
 with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8, collect_stats=True)) as s:

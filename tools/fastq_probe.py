@@ -1,6 +1,6 @@
 """f1 measurement: FASTQ text (fixed-width records built with numpy) -> load_fastq; reports device time and GB/s of text."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 import spring_amd
 n, L = int(sys.argv[1]), int(sys.argv[2])

@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from spring_amd import order_ops as oo
 n, nN = 100_000_000, 3_000_000

@@ -1,5 +1,5 @@
 import sys, time, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch, numpy as np
 import spring_amd
 from spring_amd import _lib
