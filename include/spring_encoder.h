@@ -1,0 +1,76 @@
+/*
+ * include/spring_encoder.h -- C ABI of the MI355X (gfx950) encoder stage, the consumer of the
+ * reorder stage's streams.
+ *
+ * Replaces, in memory, what spring::call_encoder -> encoder_main<N>() -> encode<N>() computes
+ * (reference src/call_template_functions.cpp:65-142, src/encoder.h:124-494,:572-633,
+ * src/encoder.cpp:32-109,:177-222): per contig the majority consensus (buildcontig), the
+ * alignment of singleton and N reads to the consensus through two 21-base dictionaries with
+ * Hamming threshold 24 (encode), the noise / position streams (writecontig), the corrected read
+ * order (correct_order), the unaligned reads, and the 2-bit packing of pack_compress_seq
+ * (encoder.cpp:111-156) -- everything up to, not including, the BSC calls.
+ *
+ * Result == the reference at `-t 1` byte for byte for the same input streams; per-tid inputs are
+ * consumed tid 0, 1, ... (one legal interleaving of the reference at `-t T`).  The alignment is
+ * computed by a fixed-point iteration over "first probe that takes the read" keys, which
+ * reproduces the serial take order including the MAX_SEARCH_ENCODER = 1000 window of bins that
+ * shrink while the scan advances.
+ *
+ * Return value: 0 on success, negative SPRING_REORDER_E_* on error; text in spring_reorder_last_error().
+ */
+#ifndef SPRING_ENCODER_H_
+#define SPRING_ENCODER_H_
+
+#include <stdint.h>
+
+#include "spring_reorder.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spring_encoder_ctx spring_encoder_ctx;
+
+typedef struct {
+  uint64_t n_aligned;       /* stream records + aligned singletons: entries of pos / rc / noise lines */
+  uint64_t n_total;         /* + unaligned reads: entries of order / readlength                       */
+  uint64_t seq_len;         /* consensus bases over all contigs                                       */
+  uint64_t noise_bytes;     /* read_noise.txt                                                         */
+  uint64_t n_noisepos;      /* u16 entries of read_noisepos.bin                                       */
+  uint64_t unaligned_bytes; /* read_unaligned.txt                                                     */
+  uint64_t len_unaligned;   /* read_unaligned.txt.count                                               */
+  uint64_t num_contigs;
+  uint32_t matched_s, matched_N;   /* "singleton reads were aligned", "reads with N were aligned"      */
+  uint32_t align_passes;    /* fixed-point passes of the alignment (1 when no bin exceeds 1000 reads) */
+  uint32_t max_bin;         /* deepest singleton-dictionary bin                                       */
+  double ms_device;         /* HIP-event time of the device work of the call                          */
+  double ms_phase[8];       /* contigs, sort, consensus, pool+dictionaries, align, merge, noise, tail */
+} spring_encoder_info;
+
+int spring_encoder_create(int device, spring_encoder_ctx **out);
+void spring_encoder_destroy(spring_encoder_ctx *ctx);
+
+/* Encode straight from a finalized reorder context: reads and streams never leave HBM.
+ * dnaN / order_N: image of input_N.dna (util.cpp:322-348 records) and read_order_N.bin
+ * (preprocess.cpp:186-214), host pointers, may be NULL/0. */
+int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *reorder, const uint8_t *dnaN,
+                                  uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t numreads_N,
+                                  spring_encoder_info *info);
+
+/* Copy the streams to host buffers sized from spring_encoder_info (any pointer may be NULL):
+ *   seq          seq_len chars (read_seq.bin.<tid> texts, tid-major); seq_len_tid[num_thr]
+ *   pos          n_aligned u64 (read_pos.bin, absolute)
+ *   noise        noise_bytes; noisepos n_noisepos u16
+ *   order        n_total u32 (read_order.bin); rlen n_total u16 (read_lengths.bin); rc n_aligned
+ *   unaligned    unaligned_bytes (read_unaligned.txt) */
+int spring_encoder_download(spring_encoder_ctx *ctx, char *seq, uint64_t *seq_len_tid, uint64_t *pos, char *noise,
+                            uint16_t *noisepos, uint32_t *order, uint16_t *rlen, char *rc, uint8_t *unaligned);
+
+/* pack_compress_seq without BSC: per tid floor(len/4) bytes (A0 C1 G2 T3, first base in the low
+ * bits) concatenated tid-major into packed, and the len%4 tail characters into tail[4*tid..]. */
+int spring_encoder_download_seq_packed(spring_encoder_ctx *ctx, uint8_t *packed, char *tail);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

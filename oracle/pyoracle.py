@@ -250,3 +250,90 @@ def preprocess_fastq(text: bytes):
         raise ValueError("Too long read length (please try --long/-l flag).")
     return dict(clean=clean[:cb.value].tobytes(), ndna=ndna[:nb.value].tobytes(), order_N=order_N[:counts[2]].copy(),
                 num_reads=int(counts[0]), num_clean=int(counts[1]), num_N=int(counts[2]), max_readlen=int(counts[3]))
+
+
+# --------------------------------------------------------------- encoder stage
+
+class OrcEncIn(C.Structure):
+    _fields_ = [("max_readlen", C.c_int), ("num_thr", C.c_int), ("read", C.c_void_p), ("len", C.c_void_p),
+                ("n_clean", C.c_uint32), ("tid_off", C.c_void_p), ("order", C.c_void_p), ("rc", C.c_void_p),
+                ("flag", C.c_void_p), ("pos", C.c_void_p), ("rlen", C.c_void_p), ("order_s", C.c_void_p),
+                ("numreads_s", C.c_uint32), ("dnaN", C.c_void_p), ("order_N", C.c_void_p),
+                ("numreads_N", C.c_uint32)]
+
+
+class OrcEncOut(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("seq_len", C.c_uint64), ("seq_len_tid", C.c_void_p), ("pos", C.c_void_p),
+                ("noise", C.c_void_p), ("noise_len", C.c_uint64), ("noisepos", C.c_void_p),
+                ("n_noisepos", C.c_uint64), ("order", C.c_void_p), ("rlen", C.c_void_p), ("rc", C.c_void_p),
+                ("n_aligned", C.c_uint64), ("n_total", C.c_uint64), ("unaligned", C.c_void_p),
+                ("unaligned_bytes", C.c_uint64), ("len_unaligned", C.c_uint64), ("matched_s", C.c_uint32),
+                ("matched_N", C.c_uint32), ("num_contigs", C.c_uint64), ("num_probes", C.c_uint64),
+                ("num_hits", C.c_uint64)]
+
+
+def _np_from(ptr, count, dtype):
+    if not ptr or count == 0:
+        return np.zeros(0, dtype)
+    nbytes = int(count) * np.dtype(dtype).itemsize
+    return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=dtype).copy()
+
+
+def pack_dnaN(strings):
+    """write_dnaN_in_bits (util.cpp:322-348) for a list of read strings -> bytes of input_N.dna."""
+    code = {"A": 0, "G": 1, "C": 2, "T": 3, "N": 4}
+    out = bytearray()
+    for s in strings:
+        out += int(len(s)).to_bytes(2, "little")
+        b = bytearray((len(s) + 1) // 2)
+        for i, ch in enumerate(s):
+            b[i // 2] |= code[ch] << (4 * (i & 1))
+        out += b
+    return bytes(out)
+
+
+def encode(read, ln, L, streams, num_thr=None, dnaN=b"", order_N=None):
+    """encoder_main<N>() at -t 1 on in-memory inputs.  `streams` is a reorder result dict
+    (order, rc, flag, pos, rlen, order_s, tid_off).  Returns a dict of the output streams."""
+    Lb = lib()
+    Lb.orc_encode.argtypes = [C.POINTER(OrcEncIn), C.POINTER(OrcEncOut)]
+    Lb.orc_encode_free.argtypes = [C.POINTER(OrcEncOut)]
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    tid_off = np.ascontiguousarray(streams["tid_off"], dtype=np.uint64)
+    T = len(tid_off) - 1 if num_thr is None else num_thr
+    keep = dict(order=np.ascontiguousarray(streams["order"], np.uint32),
+                rc=np.ascontiguousarray(streams["rc"], np.uint8),
+                flag=np.ascontiguousarray(streams["flag"], np.uint8),
+                pos=np.ascontiguousarray(streams["pos"], np.int64),
+                rlen=np.ascontiguousarray(streams["rlen"], np.uint16),
+                order_s=np.ascontiguousarray(streams["order_s"], np.uint32),
+                order_N=np.ascontiguousarray(order_N if order_N is not None else [], np.uint32),
+                dnaN=np.frombuffer(dnaN, dtype=np.uint8))
+    i = OrcEncIn()
+    i.max_readlen, i.num_thr = L, T
+    i.read, i.len, i.n_clean = read.ctypes.data, ln.ctypes.data, len(ln)
+    i.tid_off = tid_off.ctypes.data
+    for k in ("order", "rc", "flag", "pos", "rlen", "order_s"):
+        setattr(i, k, keep[k].ctypes.data)
+    i.numreads_s = len(keep["order_s"])
+    i.dnaN = keep["dnaN"].ctypes.data if len(keep["dnaN"]) else None
+    i.order_N = keep["order_N"].ctypes.data
+    i.numreads_N = len(keep["order_N"])
+    o = OrcEncOut()
+    rc = Lb.orc_encode(C.byref(i), C.byref(o))
+    if rc != 0:
+        raise ValueError("orc_encode failed: %d" % rc)
+    res = dict(seq=_np_from(o.seq, o.seq_len, np.uint8).tobytes(),
+               seq_len_tid=_np_from(o.seq_len_tid, T, np.uint64),
+               pos=_np_from(o.pos, o.n_aligned, np.uint64),
+               noise=_np_from(o.noise, o.noise_len, np.uint8).tobytes(),
+               noisepos=_np_from(o.noisepos, o.n_noisepos, np.uint16),
+               order=_np_from(o.order, o.n_total, np.uint32),
+               rlen=_np_from(o.rlen, o.n_total, np.uint16),
+               rc=_np_from(o.rc, o.n_aligned, np.uint8),
+               unaligned=_np_from(o.unaligned, o.unaligned_bytes, np.uint8).tobytes(),
+               len_unaligned=int(o.len_unaligned), matched_s=int(o.matched_s), matched_N=int(o.matched_N),
+               num_contigs=int(o.num_contigs), num_probes=int(o.num_probes), num_hits=int(o.num_hits))
+    Lb.orc_encode_free(C.byref(o))
+    return res

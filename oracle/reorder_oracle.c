@@ -126,16 +126,7 @@ void orc_dict_windows(int L, int start[2], int end[2]) { /* reorder.h:751-759 */
 
 /* ------------------------------------------------------------ dictionary */
 
-typedef struct {
-  int start, end;
-  uint32_t numkeys, dict_numreads;
-  uint64_t *keys;     /* sorted unique (stand-in for the MPHF domain)        */
-  uint32_t *startpos; /* numkeys+1 */
-  uint32_t *read_id;  /* dict_numreads */
-  uint8_t *empty_bin; /* numkeys */
-  uint32_t *htab;     /* exact key -> bin index+1 (replaces boomphf lookup,  */
-  uint64_t hmask;     /*  BooPHF.h:851; any exact map gives the same output) */
-} dict_t;
+#include "orc_internal.h" /* dict_t (shared with encoder_oracle.c) */
 
 static inline uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -161,8 +152,9 @@ static inline int64_t dict_lookup(const dict_t *d, uint64_t key) {
 }
 
 static inline uint64_t read_key(const uint64_t *r, int W, const dict_t *d) {
-  /* (read & mask1) >> 2*start  (bitset_util.h:64-72,:94-95) */
-  return window64(r, W, 2 * d->start, 2 * (d->end - d->start + 1));
+  /* (read & mask1) >> bpb*start  (bitset_util.h:64-72,:94-95); bpb = 2 (reorder) or 3 (encoder) */
+  int bpb = d->bpb ? d->bpb : 2;
+  return window64(r, W, bpb * d->start, bpb * (d->end - d->start + 1));
 }
 
 /* constructdictionary (bitset_util.h:74-221) */
@@ -1268,3 +1260,11 @@ int orc_preprocess_fastq(const uint8_t *txt, size_t nbytes, uint8_t *clean, size
   counts[0] = num_reads; counts[1] = num_clean; counts[2] = num_N; counts[3] = maxlen;
   return 0;
 }
+
+/* ------------------------------------------------ bridge for encoder_oracle.c */
+uint64_t orc__window64(const uint64_t *b, int W, int bitpos, int nbits) { return window64(b, W, bitpos, nbits); }
+void orc__dict_build(dict_t *d, const uint64_t *read, const uint16_t *len, uint32_t n, int W) { dict_build(d, read, len, n, W); }
+void orc__dict_free(dict_t *d) { dict_free(d); }
+int64_t orc__dict_lookup(const dict_t *d, uint64_t key) { return dict_lookup(d, key); }
+void orc__findpos(const dict_t *d, int64_t *dictidx, uint64_t startposidx) { findpos(d, dictidx, startposidx); }
+void orc__bin_remove(dict_t *d, int64_t *dictidx, uint64_t startposidx, int64_t current) { bin_remove(d, dictidx, startposidx, current); }

@@ -16,6 +16,8 @@ EXPORTS = [
     "spring_reorder_load_fastq", "spring_reorder_fastq_N",
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct",
     "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
+    "spring_encoder_create", "spring_encoder_destroy", "spring_encoder_encode_reorder", "spring_encoder_download",
+    "spring_encoder_download_seq_packed",
 ]
 
 
@@ -28,6 +30,20 @@ class Opts(C.Structure):
 class FastqInfo(C.Structure):
     _fields_ = [("num_reads", C.c_uint32 * 2), ("num_reads_clean", C.c_uint32 * 2), ("num_reads_N", C.c_uint32 * 2),
                 ("max_readlen", C.c_uint32), ("pad", C.c_uint32), ("ms_device", C.c_double)]
+
+
+class EncoderInfo(C.Structure):
+    _fields_ = ([(k, C.c_uint64) for k in ("n_aligned", "n_total", "seq_len", "noise_bytes", "n_noisepos",
+                                           "unaligned_bytes", "len_unaligned", "num_contigs")]
+                + [(k, C.c_uint32) for k in ("matched_s", "matched_N", "align_passes", "max_bin")]
+                + [("ms_device", C.c_double), ("ms_phase", C.c_double * 8)])
+
+    def asdict(self):
+        d = {}
+        for k, _ in self._fields_:
+            v = getattr(self, k)
+            d[k] = list(v) if hasattr(v, "__len__") else v
+        return d
 
 
 class Stats(C.Structure):
@@ -95,9 +111,15 @@ def lib():
     L.spring_synth_dna_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_reorder_load_synth.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_reorder_download_dna.argtypes = [vp, u8p, C.c_size_t]
+    L.spring_encoder_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    L.spring_encoder_destroy.argtypes = [vp]
+    L.spring_encoder_destroy.restype = None
+    L.spring_encoder_encode_reorder.argtypes = [vp, vp, u8p, C.c_uint64, vp, C.c_uint32, C.POINTER(EncoderInfo)]
+    L.spring_encoder_download.argtypes = [vp] + [vp] * 9
+    L.spring_encoder_download_seq_packed.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         if name not in ("spring_reorder_last_error", "spring_reorder_destroy", "spring_synth_dna_bytes",
-                        "spring_reorder_default_opts", "spring_reorder_trim_pool"):
+                        "spring_reorder_default_opts", "spring_reorder_trim_pool", "spring_encoder_destroy"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

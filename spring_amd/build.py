@@ -8,15 +8,17 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspring_reorder_hip.so")
-SOURCES = ["reorder_kernels.hip", "reorder_pipeline.cpp", "reorder_files.cpp", "order_ops.hip", "fastq_kernels.hip"]
-HEADERS = ["reorder_device.h", "synth_common.h", "call_reorder.h"]
+SOURCES = ["reorder_kernels.hip", "reorder_pipeline.cpp", "reorder_files.cpp", "order_ops.hip", "fastq_kernels.hip",
+           "encoder.hip"]
+HEADERS = ["reorder_device.h", "reorder_internal.h", "synth_common.h", "call_reorder.h"]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "spring_reorder.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "spring_reorder.h"),
+                                                            os.path.join(ROOT, "include", "spring_encoder.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

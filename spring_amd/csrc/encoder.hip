@@ -1,0 +1,1121 @@
+// spring_amd/csrc/encoder.hip -- SURVEY 8(f2): the encoder stage on the GPU.
+//
+// What encoder_main<N>() computes from the reorder stage's streams (reference src/encoder.h:124-494,
+// :572-633; src/encoder.cpp:32-109,:177-222), re-designed as data-parallel passes over HBM-resident
+// arrays:
+//   contigs     heads from the flag stream + the 10 000 001-read cut (encoder.h:215), two scans
+//   sort        one stable radix sort by (contig, pos - min pos)            (list::sort, encoder.h:222)
+//   consensus   one thread per consensus base votes over the reads covering it   (buildcontig)
+//   pool        singleton + N reads as 2-bit limbs + N mask, forward and reverse complement;
+//               two exact hash dictionaries on their 21-base windows        (constructdictionary, bpb 3)
+//   align       one thread per consensus position probes 4 windows; every hit proposes
+//               atomicMin(T[read], probe key): the first probe in the reference's serial order wins.
+//               Bins deeper than MAX_SEARCH_ENCODER are handled by iterating to the fixed point
+//               with "live at probe P" = T_prev[read] >= P                  (encode, encoder.h:243-343)
+//   merge       aligned singletons appended in take order, second stable sort   (encoder.h:351)
+//   noise       count / scan / write of substitutions against the consensus     (writecontig)
+//   tail        unaligned reads, corrected order                     (encoder.h:425-452, correct_order)
+// The 3-bit bitsets of the reference are represented as 2-bit SPRING codes (code3 = 2 * code2) plus
+// an N bit per base: Hamming(3-bit) = popcount(2-bit xor) + #N, keys with an N never match a
+// consensus window.  No CPU fallback: every pass is a kernel or a rocPRIM primitive.
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "reorder_device.h"
+#include "reorder_internal.h"
+#include "spring_encoder.h"
+
+using sr::fail;
+
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(SPRING_REORDER_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+namespace {
+
+constexpr uint32_t LIST_LIMIT = 10000001u;  // a contig is cut after this many reads (encoder.h:215)
+constexpr int MAX_SEARCH_E = 1000;          // params.h:33
+constexpr int THRESH_E = 24;                // params.h:34
+constexpr unsigned long long INF = ~0ull;
+
+// ------------------------------------------------------------------ bit helpers
+__device__ __forceinline__ uint64_t lowmask(int nbits) {
+  return nbits >= 64 ? ~0ull : nbits <= 0 ? 0ull : ((1ull << nbits) - 1);
+}
+// 64 bits of a long bit stream starting at bit (stream padded with >= 2 zero words)
+__device__ __forceinline__ uint64_t win64(const uint64_t *__restrict__ b, uint64_t bit) {
+  const uint64_t w = bit >> 6;
+  const int off = (int)(bit & 63);
+  uint64_t lo = b[w] >> off;
+  if (off) lo |= b[w + 1] << (64 - off);
+  return lo;
+}
+// same on a read of nl limbs (zero beyond)
+__device__ __forceinline__ uint64_t win64b(const uint64_t *__restrict__ b, int nl, int bit) {
+  const int w = bit >> 6, off = bit & 63;
+  uint64_t lo = w < nl ? b[w] >> off : 0ull;
+  if (off && w + 1 < nl) lo |= b[w + 1] << (64 - off);
+  return lo;
+}
+__device__ __forceinline__ uint64_t rev2(uint64_t x) {  // reverse the order of the 32 2-bit groups
+  const uint64_t y = __brevll(x);
+  return ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+}
+__device__ __forceinline__ uint64_t spread32(uint32_t x) {  // bit i -> bit 2i
+  uint64_t v = x;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v;
+}
+// limb t (bases 32t..32t+31) of the reverse complement of a 2-bit read (complement = 3 - code)
+__device__ __forceinline__ uint64_t rc_limb(const uint64_t *__restrict__ r, int nl, int len, int t) {
+  const int rem = len - 32 * t;
+  if (rem <= 0) return 0;
+  const int s0 = len - 32 * (t + 1);
+  const uint64_t w = s0 >= 0 ? win64b(r, nl, 2 * s0) : (win64b(r, nl, 0) << (2 * (-s0)));
+  return (~rev2(w)) & lowmask(2 * rem);
+}
+// limb t (bases 64t..64t+63) of a reversed 1-bit-per-base mask
+__device__ __forceinline__ uint64_t rcn_limb(const uint64_t *__restrict__ nm, int nl, int len, int t) {
+  const int rem = len - 64 * t;
+  if (rem <= 0) return 0;
+  const int s0 = len - 64 * (t + 1);
+  const uint64_t w = s0 >= 0 ? win64b(nm, nl, s0) : (win64b(nm, nl, 0) << (-s0));
+  return __brevll(w) & lowmask(rem);
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+// largest c with ref_off[c] <= g (ref_off has C+1 entries, ref_off[C] = seq_len > g)
+__device__ __forceinline__ uint32_t find_contig(const uint64_t *__restrict__ ref_off, uint32_t C, uint64_t g) {
+  uint32_t lo = 0, hi = C;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (ref_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------ contigs
+__global__ void k_heads(const char *__restrict__ flag, uint32_t M, uint32_t *__restrict__ fs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) fs[i] = flag[i] == '0' ? i : 0u;
+}
+__global__ void k_tid_heads(const uint64_t *__restrict__ tid_off, int T, uint32_t M, uint32_t *__restrict__ fs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T && tid_off[t] < M) fs[tid_off[t]] = (uint32_t)tid_off[t];
+}
+__global__ void k_head2(const uint32_t *__restrict__ fstart, uint32_t M, uint32_t *__restrict__ h2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) h2[i] = ((i - fstart[i]) % LIST_LIMIT == 0) ? 1u : 0u;
+}
+__global__ void k_cstart(const uint32_t *__restrict__ h2, const uint32_t *__restrict__ cid1, uint32_t M,
+                         uint32_t *__restrict__ cstart) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M && h2[i]) cstart[cid1[i] - 1] = i;
+}
+__global__ void k_fill_ll(long long *p, uint32_t n, long long v) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_u64(unsigned long long *p, uint64_t n, unsigned long long v) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_iota(uint32_t *p, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+// per-contig min(pos), max(pos+len): one atomic per wave when the wave sits inside one contig
+__global__ void k_minmax(const long long *__restrict__ pos, const uint16_t *__restrict__ rlen,
+                         const uint32_t *__restrict__ cid1, uint32_t M, long long *__restrict__ cmin,
+                         long long *__restrict__ cmax) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = i < M;
+  const uint32_t c = ok ? cid1[i] - 1 : 0xffffffffu;
+  long long lo = ok ? pos[i] : LLONG_MAX, hi = ok ? pos[i] + rlen[i] : LLONG_MIN;
+  const uint32_t c0 = __shfl(c, 0);
+  const bool uniform = __all(c == c0) && c0 != 0xffffffffu;
+  if (uniform) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      const long long l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&cmin[c0], lo); atomicMax(&cmax[c0], hi); }
+  } else if (ok) {
+    atomicMin(&cmin[c], lo);
+    atomicMax(&cmax[c], hi);
+  }
+}
+__global__ void k_reflen(const long long *__restrict__ cmin, const long long *__restrict__ cmax, uint32_t C,
+                         uint32_t *__restrict__ R, unsigned long long *__restrict__ maxR) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  if (c == C) { R[c] = 0; return; }
+  const unsigned long long r = (unsigned long long)(cmax[c] - cmin[c]);
+  R[c] = r > 0xffffffffull ? 0xffffffffu : (uint32_t)r;
+  atomicMax(maxR, r);
+}
+__global__ void k_keys1(const long long *__restrict__ pos, const uint32_t *__restrict__ cid1,
+                        const long long *__restrict__ cmin, uint32_t M, int pb, uint64_t *__restrict__ keys,
+                        uint32_t *__restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const uint32_t c = cid1[i] - 1;
+  keys[i] = ((uint64_t)c << pb) | (uint64_t)(pos[i] - cmin[c]);
+  vals[i] = i;
+}
+// sorted record: x = pos relative to the contig, y = read id | len << 32 | rc << 48 | singleton << 49
+__global__ void k_srec(const uint64_t *__restrict__ kout, const uint32_t *__restrict__ vout,
+                       const uint32_t *__restrict__ order, const char *__restrict__ rc,
+                       const uint16_t *__restrict__ rlen, uint32_t M, int pb, ulonglong2 *__restrict__ srec) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= M) return;
+  const uint32_t i = vout[k];
+  ulonglong2 r;
+  r.x = kout[k] & lowmask(pb);
+  r.y = (uint64_t)order[i] | ((uint64_t)rlen[i] << 32) | ((uint64_t)(rc[i] == 'r') << 48);
+  srec[k] = r;
+}
+
+// ------------------------------------------------------------------ consensus (buildcontig, encoder.cpp:32-74)
+__global__ __launch_bounds__(256) void k_consensus(const ulonglong2 *__restrict__ srec,
+                                                   const uint32_t *__restrict__ cstart,
+                                                   const uint64_t *__restrict__ ref_off, uint32_t C, uint64_t seq_len,
+                                                   const uint64_t *__restrict__ reads, int S, int Lmax,
+                                                   uint8_t *__restrict__ refc) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= seq_len) return;
+  const uint32_t c = find_contig(ref_off, C, g);
+  const uint64_t p = g - ref_off[c];
+  const uint32_t lo0 = cstart[c], hi0 = cstart[c + 1];
+  // a = first record with relpos + Lmax > p, b = first record with relpos > p
+  uint32_t a = lo0, b = hi0;
+  {
+    uint32_t lo = lo0, hi = hi0;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (srec[mid].x + (uint64_t)Lmax > p) hi = mid; else lo = mid + 1; }
+    a = lo;
+    hi = hi0;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (srec[mid].x > p) hi = mid; else lo = mid + 1; }
+    b = lo;
+  }
+  int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;  // A, C, G, T (chartolong, encoder.cpp:36-45)
+  for (uint32_t k = a; k < b; k++) {
+    const ulonglong2 r = srec[k];
+    const int len = (int)((r.y >> 32) & 0xffff);
+    const uint64_t j64 = p - r.x;
+    if (j64 >= (uint64_t)len) continue;
+    const int j = (int)j64;
+    const bool rc = (r.y >> 48) & 1;
+    const int jj = rc ? len - 1 - j : j;
+    int code = (int)((reads[(size_t)(uint32_t)r.y * S + (jj >> 5)] >> (2 * (jj & 31))) & 3);
+    if (rc) code = 3 - code;
+    // SPRING code A0 G1 C2 T3
+    cnt0 += code == 0; cnt2 += code == 1; cnt1 += code == 2; cnt3 += code == 3;
+  }
+  int mx = 0, ind = 0;  // strict >, order A C G T; nothing covering the base -> 'A' (encoder.cpp:62-72)
+  if (cnt0 > mx) { mx = cnt0; ind = 0; }
+  if (cnt1 > mx) { mx = cnt1; ind = 1; }
+  if (cnt2 > mx) { mx = cnt2; ind = 2; }
+  if (cnt3 > mx) { mx = cnt3; ind = 3; }
+  refc[g] = (uint8_t)(ind == 1 ? 2 : ind == 2 ? 1 : ind);  // back to the SPRING code
+}
+__global__ void k_pack_ref(const uint8_t *__restrict__ refc, uint64_t seq_len, uint64_t *__restrict__ refbits,
+                           uint64_t nwords) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint64_t v = 0;
+  const uint64_t g0 = w * 32;
+  if (g0 + 32 <= seq_len) {
+    const uint64_t *q = (const uint64_t *)(refc + g0);  // g0 is a multiple of 32
+    for (int h = 0; h < 4; h++) {
+      const uint64_t x = q[h];
+      for (int k = 0; k < 8; k++) v |= ((x >> (8 * k)) & 3ull) << (2 * (8 * h + k));
+    }
+  } else {
+    for (int k = 0; k < 32 && g0 + k < seq_len; k++) v |= (uint64_t)(refc[g0 + k] & 3) << (2 * k);
+  }
+  refbits[w] = v;
+}
+
+// ------------------------------------------------------------------ singleton pool (readsingletons, encoder.h:541-570)
+__global__ void k_pool_clean(const uint64_t *__restrict__ reads, const uint16_t *__restrict__ lens, int S,
+                             const uint32_t *__restrict__ order_s, uint32_t ns, uint64_t *__restrict__ sread,
+                             uint16_t *__restrict__ slen, uint16_t *__restrict__ ncnt) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q = (uint32_t)(t / S);
+  if (q >= ns) return;
+  const int k = (int)(t % S);
+  const uint32_t id = order_s[q];
+  sread[(size_t)q * S + k] = reads[(size_t)id * S + k];
+  if (k == 0) { slen[q] = lens[id]; ncnt[q] = 0; }
+}
+// input_N.dna records (write_dnaN_in_bits, util.cpp:322-348): u16 len, then 4 bits per base A0 G1 C2 T3 N4
+__global__ void k_pool_N(const uint8_t *__restrict__ dnaN, const uint64_t *__restrict__ offN, uint32_t nN,
+                         uint32_t ns, int S, int SM, uint64_t *__restrict__ sread, uint64_t *__restrict__ nmask,
+                         uint16_t *__restrict__ slen, uint16_t *__restrict__ ncnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nN) return;
+  const uint8_t *p = dnaN + offN[i];
+  const int len = p[0] | (p[1] << 8);
+  p += 2;
+  const uint32_t q = ns + i;
+  uint64_t *rd = sread + (size_t)q * S, *nm = nmask + (size_t)q * SM;
+  int nc = 0;
+  uint64_t acc = 0, accn = 0;
+  for (int j = 0; j < len; j++) {
+    const unsigned v = (p[j >> 1] >> (4 * (j & 1))) & 15u;
+    const bool isN = v >= 4;
+    acc |= (uint64_t)(isN ? 0u : v) << (2 * (j & 31));
+    accn |= (uint64_t)isN << (j & 63);
+    nc += isN;
+    if ((j & 31) == 31) { rd[j >> 5] = acc; acc = 0; }
+    if ((j & 63) == 63) { nm[j >> 6] = accn; accn = 0; }
+  }
+  if (len & 31) rd[len >> 5] = acc;
+  if (len & 63) nm[len >> 6] = accn;
+  slen[q] = (uint16_t)len;
+  ncnt[q] = (uint16_t)nc;
+}
+__global__ void k_pool_rev(const uint64_t *__restrict__ sread, const uint64_t *__restrict__ nmask,
+                           const uint16_t *__restrict__ slen, int S, int SM, uint32_t np,
+                           uint64_t *__restrict__ srev, uint64_t *__restrict__ nmask_r) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q = (uint32_t)(t / S);
+  if (q >= np) return;
+  const int k = (int)(t % S);
+  const int len = slen[q];
+  // an N keeps code 0 forward and gets code 3 here: xor with the window then equals the xor of the
+  // complemented window with 0, which is what the reference's reverse bitset sees
+  srev[(size_t)q * S + k] = rc_limb(sread + (size_t)q * S, S, len, k);
+  if (k < SM) nmask_r[(size_t)q * SM + k] = rcn_limb(nmask + (size_t)q * SM, SM, len, k);
+}
+// read q enters dictionary l iff len > end (bitset_util.h:83-105); a key with an N can never equal a
+// consensus window, so such reads are left out (unobservable)
+__global__ void k_pool_flag(const uint16_t *__restrict__ slen, const uint64_t *__restrict__ nmask, int SM,
+                            uint32_t np, int start, int end, uint32_t *__restrict__ flag) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= np) return;
+  bool ok = (int)slen[q] > end;
+  if (ok) ok = (win64b(nmask + (size_t)q * SM, SM, start) & lowmask(end - start + 1)) == 0;
+  flag[q] = ok ? 1u : 0u;
+}
+__global__ void k_pool_keys(const uint64_t *__restrict__ sread, int S, const uint32_t *__restrict__ flag,
+                            const uint32_t *__restrict__ slot, uint32_t np, int start, int klen,
+                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= np || !flag[q]) return;
+  keys[slot[q]] = win64b(sread + (size_t)q * S, S, 2 * start) & lowmask(2 * klen);
+  vals[slot[q]] = q;
+}
+// open addressing, 16-byte slots {key | 1<<63, start | count << 32}
+__global__ void k_etab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
+                              const uint32_t *__restrict__ ucount, uint32_t numkeys,
+                              unsigned long long *__restrict__ tab, uint64_t tmask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numkeys) return;
+  const unsigned long long tag = ukeys[i] | (1ull << 63);
+  uint64_t h = mix64(ukeys[i]) & tmask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&tab[2 * h], 0ull, tag);
+    if (old == 0ull) { tab[2 * h + 1] = (unsigned long long)ustart[i] | ((unsigned long long)ucount[i] << 32); break; }
+    h = (h + 1) & tmask;
+  }
+}
+
+// ------------------------------------------------------------------ alignment (encode, encoder.h:243-343)
+struct AlignP {
+  const uint64_t *refbits, *ref_off;
+  uint32_t C;
+  uint64_t seq_len;
+  int Lmax, S;
+  int dstart[2], dend[2];
+  const unsigned long long *tab[2];
+  uint64_t tmask[2];
+  const uint32_t *ids[2];
+  const uint64_t *sread, *srev;
+  const uint16_t *slen, *ncnt;
+  const unsigned long long *Tprev;
+  unsigned long long *Tnew;
+};
+
+template <bool LIVE>
+__global__ __launch_bounds__(256) void k_align(AlignP A) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A.seq_len) return;
+  const uint32_t c = find_contig(A.ref_off, A.C, g);
+  const uint64_t off = A.ref_off[c], R = A.ref_off[c + 1] - off, p = g - off;
+  const uint64_t Lmax = (uint64_t)A.Lmax;
+  if (R < Lmax || p > R - Lmax) return;  // encoder.h:232, :243
+#pragma unroll 1
+  for (int pr = 0; pr < 4; pr++) {
+    const int rev = pr >> 1, l = pr & 1;
+    if (!A.tab[l]) continue;
+    const int start = A.dstart[l], end = A.dend[l], klen = end - start + 1;
+    uint64_t key;
+    if (!rev) {
+      key = win64(A.refbits, 2 * (g + start)) & lowmask(2 * klen);
+    } else {  // bases [start, end] of the reverse complement of the window
+      const uint64_t x = win64(A.refbits, 2 * (g + Lmax - 1 - end)) & lowmask(2 * klen);
+      key = (~(rev2(x) >> (64 - 2 * klen))) & lowmask(2 * klen);
+    }
+    const unsigned long long tag = key | (1ull << 63);
+    uint64_t h = mix64(key) & A.tmask[l];
+    unsigned long long sx;
+    for (;;) {
+      sx = A.tab[l][2 * h];
+      if (sx == 0ull || sx == tag) break;
+      h = (h + 1) & A.tmask[l];
+    }
+    if (sx == 0ull) continue;
+    const unsigned long long sy = A.tab[l][2 * h + 1];
+    const uint32_t bstart = (uint32_t)sy, bcount = (uint32_t)(sy >> 32);
+    const unsigned long long Pkey = (g << 2) | (unsigned long long)pr;
+    int seen = 0;
+    for (long long k = (long long)bstart + bcount - 1; k >= (long long)bstart; k--) {
+      const uint32_t rid = A.ids[l][k];
+      if (LIVE && A.Tprev[rid] < Pkey) continue;  // taken before this probe: not in the bin any more
+      if (++seen > MAX_SEARCH_E) break;
+      const int nc = A.ncnt[rid];
+      if (nc > THRESH_E) continue;
+      const int len = A.slen[rid];
+      const uint64_t bo = rev ? g + Lmax - len : g;
+      const uint64_t *rd = (rev ? A.srev : A.sread) + (size_t)rid * A.S;
+      int hd = nc;
+      const int nl = (len + 31) >> 5;
+      for (int t = 0; t < nl; t++) {
+        const uint64_t x = (win64(A.refbits, 2 * bo + 64ull * t) ^ rd[t]) & lowmask(2 * (len - 32 * t));
+        hd += __popcll(x);
+        if (hd > THRESH_E) break;
+      }
+      if (hd <= THRESH_E) atomicMin(&A.Tnew[rid], Pkey);
+    }
+  }
+}
+__global__ void k_differs(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
+                          uint32_t n, uint32_t *__restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && a[i] != b[i]) *flag = 1u;
+}
+
+// aligned singletons, listed by descending pool index so that the stable sort by probe key leaves
+// reads taken by one probe in bin order from the tail (encoder.h:286-287)
+__global__ void k_flag_aligned_rev(const unsigned long long *__restrict__ T, uint32_t np, uint32_t *__restrict__ f) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < np) f[j] = T[np - 1 - j] != INF ? 1u : 0u;
+}
+__global__ void k_gather_aligned(const unsigned long long *__restrict__ T, const uint32_t *__restrict__ f,
+                                 const uint32_t *__restrict__ slot, uint32_t np, uint64_t *__restrict__ Pk,
+                                 uint32_t *__restrict__ qv) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= np || !f[j]) return;
+  const uint32_t q = np - 1 - j;
+  Pk[slot[j]] = T[q];
+  qv[slot[j]] = q;
+}
+__global__ void k_single_rec(const uint64_t *__restrict__ Pk, const uint32_t *__restrict__ qv, uint32_t A,
+                             const uint64_t *__restrict__ ref_off, uint32_t C, int Lmax,
+                             const uint16_t *__restrict__ slen, int pb, uint64_t *__restrict__ keys,
+                             ulonglong2 *__restrict__ frec) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A) return;
+  const uint64_t P = Pk[j], g = P >> 2;
+  const int rev = (int)((P >> 1) & 1);
+  const uint32_t q = qv[j], c = find_contig(ref_off, C, g);
+  const uint64_t p = g - ref_off[c];
+  const int len = slen[q];
+  const uint64_t relpos = rev ? p + Lmax - len : p;  // encoder.h:309-311
+  keys[j] = ((uint64_t)c << pb) | relpos;
+  ulonglong2 r;
+  r.x = relpos;
+  r.y = (uint64_t)q | ((uint64_t)len << 32) | ((uint64_t)rev << 48) | (1ull << 49);
+  frec[j] = r;
+}
+
+// ------------------------------------------------------------------ noise streams (writecontig, encoder.cpp:76-109)
+struct NoiseP {
+  const uint64_t *kfin;
+  const uint32_t *vfin;
+  const ulonglong2 *frec;
+  uint64_t F;
+  int pb;
+  const uint64_t *ref_off, *refbits;
+  const uint64_t *reads;
+  int S, SM;
+  const uint64_t *sread, *srev, *nmask, *nmask_r;
+  const uint32_t *cumN;      // may be null (no N reads)
+  const uint32_t *order_sc;  // corrected order of the pool reads
+  uint32_t *nm;              // mismatches per record
+  const uint64_t *noff;      // exclusive scan of nm
+  char *noise;
+  uint16_t *noisepos;
+  uint64_t *out_pos;
+  uint32_t *out_order;
+  uint16_t *out_rlen;
+  char *out_rc;
+};
+// enc_noise (encoder.h:522-541) indexed by SPRING codes: [ref A G C T][read A G C T N]
+__constant__ char c_enc_noise[4][5] = {{0, '1', '0', '2', '3'}, {'1', 0, '2', '0', '3'}, {'0', '1', 0, '2', '3'},
+                                       {'2', '0', '1', 0, '3'}};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_noise(NoiseP N) {
+  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= N.F) return;
+  const uint64_t key = N.kfin[f];
+  const ulonglong2 rec = N.frec[N.vfin[f]];
+  const uint32_t c = (uint32_t)(key >> N.pb);
+  const uint64_t gpos = N.ref_off[c] + rec.x;
+  const uint32_t id = (uint32_t)rec.y;
+  const int len = (int)((rec.y >> 32) & 0xffff);
+  const bool rc = (rec.y >> 48) & 1, single = (rec.y >> 49) & 1;
+  const uint64_t *rd = single ? (rc ? N.srev : N.sread) + (size_t)id * N.S : N.reads + (size_t)id * N.S;
+  const uint64_t *nmk = single ? (rc ? N.nmask_r : N.nmask) + (size_t)id * N.SM : nullptr;
+  const int nl = (len + 31) >> 5;
+  uint32_t cnt = 0;
+  uint64_t o = 0;
+  int prevj = 0;
+  if (WRITE) o = N.noff[f];
+  for (int t = 0; t < nl; t++) {
+    const uint64_t r = (single || !rc) ? rd[t] : rc_limb(rd, N.S, len, t);
+    const uint32_t nh = nmk ? (uint32_t)(nmk[t >> 1] >> (32 * (t & 1))) : 0u;
+    const uint64_t w = win64(N.refbits, 2 * gpos + 64ull * t);
+    const uint64_t x = w ^ r;
+    uint64_t m = (((x | (x >> 1)) & 0x5555555555555555ull) | spread32(nh)) & lowmask(2 * (len - 32 * t));
+    if (!WRITE) {
+      cnt += __popcll(m);
+    } else {
+      while (m) {
+        const int jj = __builtin_ctzll(m) >> 1;
+        m &= m - 1;
+        const int j = 32 * t + jj;
+        const int rcode = (int)((w >> (2 * jj)) & 3);
+        const int dcode = ((nh >> jj) & 1) ? 4 : (int)((r >> (2 * jj)) & 3);
+        N.noise[o + f + cnt] = c_enc_noise[rcode][dcode];
+        N.noisepos[o + cnt] = (uint16_t)(j - prevj);
+        prevj = j;
+        cnt++;
+      }
+    }
+  }
+  if (!WRITE) {
+    N.nm[f] = cnt;
+  } else {
+    N.noise[o + f + cnt] = '\n';
+    N.out_pos[f] = gpos;
+    N.out_rlen[f] = (uint16_t)len;
+    N.out_rc[f] = rc ? 'r' : 'd';
+    N.out_order[f] = single ? N.order_sc[id] : id + (N.cumN ? N.cumN[id] : 0u);
+  }
+}
+
+// ------------------------------------------------------------------ order correction (correct_order, encoder.cpp:177-222)
+__global__ void k_mark_N(const uint32_t *__restrict__ order_N, uint32_t nN, uint32_t *__restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nN) flag[order_N[i]] = 1u;
+}
+__global__ void k_cumulative(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ nbefore, uint32_t total,
+                             uint32_t *__restrict__ cum) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total && !flag[i]) cum[i - nbefore[i]] = nbefore[i];
+}
+__global__ void k_pool_order(const uint32_t *__restrict__ order_s, const uint32_t *__restrict__ order_N, uint32_t ns,
+                             uint32_t np, const uint32_t *__restrict__ cumN, uint32_t *__restrict__ order_sc) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= np) return;
+  order_sc[q] = q < ns ? order_s[q] + (cumN ? cumN[order_s[q]] : 0u) : order_N[q - ns];
+}
+
+// ------------------------------------------------------------------ unaligned reads (encoder.h:425-452)
+__global__ void k_flag_rem(const unsigned long long *__restrict__ T, const uint16_t *__restrict__ slen, uint32_t np,
+                           uint32_t *__restrict__ fr, uint32_t *__restrict__ usz, uint32_t *__restrict__ ulen) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q > np) return;
+  const bool rem = q < np && T[q] == INF;
+  fr[q] = rem ? 1u : 0u;
+  usz[q] = rem ? 2u + (slen[q] + 1u) / 2u : 0u;
+  ulen[q] = rem ? slen[q] : 0u;
+}
+__global__ void k_unaligned(const uint32_t *__restrict__ fr, const uint32_t *__restrict__ uslot,
+                            const uint64_t *__restrict__ uoff, uint32_t np, const uint64_t *__restrict__ sread,
+                            const uint64_t *__restrict__ nmask, const uint16_t *__restrict__ slen, int S, int SM,
+                            const uint32_t *__restrict__ order_sc, uint64_t n_aligned, uint32_t *__restrict__ out_order,
+                            uint16_t *__restrict__ out_rlen, uint8_t *__restrict__ un) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= np || !fr[q]) return;
+  const int len = slen[q];
+  out_order[n_aligned + uslot[q]] = order_sc[q];
+  out_rlen[n_aligned + uslot[q]] = (uint16_t)len;
+  uint8_t *p = un + uoff[q];
+  p[0] = (uint8_t)(len & 0xff);
+  p[1] = (uint8_t)(len >> 8);
+  const uint64_t *rd = sread + (size_t)q * S, *nm = nmask + (size_t)q * SM;
+  for (int b = 0; b < (len + 1) / 2; b++) {  // write_dnaN_in_bits (util.cpp:322-348)
+    unsigned v = 0;
+    for (int h = 0; h < 2; h++) {
+      const int j = 2 * b + h;
+      if (j >= len) break;
+      const unsigned isN = (unsigned)((nm[j >> 6] >> (j & 63)) & 1);
+      const unsigned code = isN ? 4u : (unsigned)((rd[j >> 5] >> (2 * (j & 31))) & 3);
+      v |= code << (4 * h);
+    }
+    p[2 + b] = (uint8_t)v;
+  }
+}
+
+// ------------------------------------------------------------------ seq outputs
+__global__ void k_tid_seq(const uint64_t *__restrict__ tid_off, int T, uint32_t M, const uint32_t *__restrict__ cid1,
+                          const uint64_t *__restrict__ ref_off, uint64_t seq_len, uint64_t *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > T) return;
+  out[t] = (t < T && tid_off[t] < M) ? ref_off[cid1[tid_off[t]] - 1] : seq_len;
+}
+__global__ void k_seq_ascii(const uint8_t *__restrict__ refc, uint64_t n, char *__restrict__ out) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) out[g] = "AGCT"[refc[g] & 3];
+}
+// pack_compress_seq (encoder.cpp:111-156): natural code A0 C1 G2 T3, 4 bases per byte, low bits first
+__global__ void k_seq_pack(const uint8_t *__restrict__ refc, uint64_t base0, uint64_t nbytes, uint8_t *__restrict__ out) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbytes) return;
+  unsigned v = 0;
+  for (int k = 0; k < 4; k++) {
+    const unsigned s = refc[base0 + 4 * b + k] & 3u;
+    const unsigned nat = s == 1 ? 2u : s == 2 ? 1u : s;
+    v |= nat << (2 * k);
+  }
+  out[b] = (uint8_t)v;
+}
+
+inline dim3 grid(uint64_t n) { return dim3((unsigned)((n + 255) / 256 ? (n + 255) / 256 : 1)); }
+inline int bits_for(uint64_t v) {  // bits needed to hold values 0..v
+  int b = 1;
+  while (b < 64 && (v >> b)) b++;
+  return b;
+}
+
+// device buffer from the library's pool
+struct DBuf {
+  int dev = 0;
+  void *p = nullptr;
+  DBuf() = default;
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  ~DBuf() { release(); }
+  void release() { if (p) { sr::dev_free(dev, p); p = nullptr; } }
+  hipError_t alloc(int d, size_t bytes) { release(); dev = d; return sr::dev_alloc(d, bytes, &p); }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct spring_encoder_ctx {
+  int dev = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  int T = 0;
+  spring_encoder_info info;
+  bool have = false;
+  // results (device)
+  DBuf refc, pos, noise, noisepos, order, rlen, rc, unaligned;
+  std::vector<uint64_t> tid_seq;  // T + 1 offsets into refc
+};
+
+#define DALLOC(buf, bytes) HIPCHK((buf).alloc(dev, (bytes)))
+
+extern "C" {
+
+int spring_encoder_create(int device, spring_encoder_ctx **out) {
+  if (!out) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(SPRING_REORDER_E_HIP, "no HIP device available (the encoder stage has no CPU fallback)");
+  if (device < 0) device = 0;
+  if (device >= ndev) return fail(SPRING_REORDER_E_ARG, "device %d out of range", device);
+  spring_encoder_ctx *c = new spring_encoder_ctx();
+  c->dev = device;
+  memset(&c->info, 0, sizeof(c->info));
+  *out = c;
+  return 0;
+}
+
+void spring_encoder_destroy(spring_encoder_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->dev);
+  (void)hipDeviceSynchronize();
+  delete ctx;
+}
+
+int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *reorder, const uint8_t *dnaN,
+                                  uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t nN,
+                                  spring_encoder_info *info_out) {
+  if (!ctx || !reorder) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  if (nN && (!dnaN || !order_N)) return fail(SPRING_REORDER_E_ARG, "numreads_N > 0 but dnaN / order_N is NULL");
+  sr::ReorderView V;
+  int rcv = sr::reorder_view(reorder, &V);
+  if (rcv) return rcv;
+  if (V.dev != ctx->dev) return fail(SPRING_REORDER_E_ARG, "encoder and reorder contexts live on different devices");
+  const int dev = ctx->dev;
+  HIPCHK(hipSetDevice(dev));
+  hipStream_t st = V.st;
+  ctx->st = st;
+  ctx->have = false;
+  const int T = V.num_thr, Lmax = V.L, S = V.S;
+  ctx->T = T;
+  const uint64_t M64 = V.nrec;
+  const uint32_t ns = (uint32_t)V.nsing;
+  if ((uint64_t)ns + nN > 4294967290ull || (uint64_t)V.n + nN > 4294967290ull)
+    return fail(SPRING_REORDER_E_ARG, "too many reads");
+  const uint32_t M = (uint32_t)M64, np = ns + nN;
+  int SM = 1;
+  while (SM * 64 < Lmax) SM <<= 1;
+  spring_encoder_info &I = ctx->info;
+  memset(&I, 0, sizeof(I));
+
+  hipEvent_t ev[10];
+  for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+  struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 10; i++) (void)hipEventDestroy(e[i]); } } evg{ev};
+  HIPCHK(hipEventRecord(ev[0], st));
+
+  // host-side scan of the N records (u16 length prefixes; a sequential dependency of nN steps)
+  std::vector<uint64_t> offN(nN ? nN : 1);
+  {
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < nN; i++) {
+      if (o + 2 > dnaN_bytes) return fail(SPRING_REORDER_E_ARG, "input_N.dna image is truncated");
+      const uint32_t len = dnaN[o] | (dnaN[o + 1] << 8);
+      if ((int)len > Lmax) return fail(SPRING_REORDER_E_ARG, "N read longer than max_readlen");
+      offN[i] = o;
+      o += 2 + (len + 1) / 2;
+    }
+    if (o > dnaN_bytes) return fail(SPRING_REORDER_E_ARG, "input_N.dna image is truncated");
+  }
+
+  // scratch for the rocPRIM primitives (sized for the largest call below)
+  const uint64_t FMAX = (uint64_t)M + np;
+  size_t tb = 0, t2 = 0;
+  HIPCHK(sr::sort_pairs(st, nullptr, t2, nullptr, nullptr, nullptr, nullptr, FMAX ? FMAX : 1, 64)); tb = std::max(tb, t2);
+  HIPCHK(sr::excl_scan_u32_to_u64(st, nullptr, t2, nullptr, nullptr, FMAX + 2)); tb = std::max(tb, t2);
+  HIPCHK(sr::excl_scan_u32(st, nullptr, t2, nullptr, nullptr, (size_t)V.n + nN + 2)); tb = std::max(tb, t2);
+  HIPCHK(sr::rle(st, nullptr, t2, nullptr, np ? np : 1, nullptr, nullptr, nullptr)); tb = std::max(tb, t2);
+  HIPCHK(sr::reduce_max_u32(st, nullptr, t2, nullptr, nullptr, np ? np : 1)); tb = std::max(tb, t2);
+  {
+    size_t t3 = 0;
+    HIPCHK(rocprim::inclusive_scan(nullptr, t3, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)(M ? M : 1),
+                                   rocprim::maximum<uint32_t>(), st));
+    tb = std::max(tb, t3);
+  }
+  DBuf tmp;
+  DALLOC(tmp, tb + 256);
+
+  // ------------------------------------------------ order correction tables
+  DBuf cumN, order_sc, dN, dorderN, doffN;
+  if (nN) {
+    const uint32_t total = V.n + nN;
+    DBuf flagN, nb;
+    DALLOC(flagN, (size_t)total * 4); DALLOC(nb, (size_t)total * 4); DALLOC(cumN, (size_t)(V.n ? V.n : 1) * 4);
+    DALLOC(dN, dnaN_bytes); DALLOC(dorderN, (size_t)nN * 4); DALLOC(doffN, (size_t)nN * 8);
+    HIPCHK(hipMemcpyAsync(dN.p, dnaN, dnaN_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dorderN.p, order_N, (size_t)nN * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(doffN.p, offN.data(), (size_t)nN * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(flagN.p, 0, (size_t)total * 4, st));
+    hipLaunchKernelGGL(k_mark_N, grid(nN), dim3(256), 0, st, dorderN.as<uint32_t>(), nN, flagN.as<uint32_t>());
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32(st, tmp.p, t2, flagN.as<uint32_t>(), nb.as<uint32_t>(), total));
+    hipLaunchKernelGGL(k_cumulative, grid(total), dim3(256), 0, st, flagN.as<uint32_t>(), nb.as<uint32_t>(), total,
+                       cumN.as<uint32_t>());
+    HIPCHK(hipStreamSynchronize(st));  // flagN / nb go back to the pool
+  }
+
+  // ------------------------------------------------ contigs
+  uint32_t C = 0;
+  uint64_t seq_len = 0, maxR = 0;
+  int pb = 1;
+  DBuf cid1, cstart, cmin, cmax, Rl, ref_off, dtid, dmax;
+  DALLOC(dtid, (size_t)(T + 1) * 8);
+  HIPCHK(hipMemcpyAsync(dtid.p, V.tid_off, (size_t)(T + 1) * 8, hipMemcpyHostToDevice, st));
+  if (M) {
+    DBuf fs, fstart, h2;
+    DALLOC(fs, (size_t)M * 4); DALLOC(fstart, (size_t)M * 4); DALLOC(h2, (size_t)M * 4); DALLOC(cid1, (size_t)M * 4);
+    hipLaunchKernelGGL(k_heads, grid(M), dim3(256), 0, st, V.f_flag, M, fs.as<uint32_t>());
+    hipLaunchKernelGGL(k_tid_heads, grid(T), dim3(256), 0, st, dtid.as<uint64_t>(), T, M, fs.as<uint32_t>());
+    size_t t3 = tb;
+    HIPCHK(rocprim::inclusive_scan(tmp.p, t3, fs.as<uint32_t>(), fstart.as<uint32_t>(), (size_t)M,
+                                   rocprim::maximum<uint32_t>(), st));
+    hipLaunchKernelGGL(k_head2, grid(M), dim3(256), 0, st, fstart.as<uint32_t>(), M, h2.as<uint32_t>());
+    t3 = tb;
+    HIPCHK(rocprim::inclusive_scan(tmp.p, t3, h2.as<uint32_t>(), cid1.as<uint32_t>(), (size_t)M,
+                                   rocprim::plus<uint32_t>(), st));
+    HIPCHK(hipMemcpyAsync(&C, cid1.as<uint32_t>() + (M - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    DALLOC(cstart, (size_t)(C + 1) * 4); DALLOC(cmin, (size_t)C * 8); DALLOC(cmax, (size_t)C * 8);
+    DALLOC(Rl, (size_t)(C + 2) * 4); DALLOC(ref_off, (size_t)(C + 2) * 8); DALLOC(dmax, 8);
+    hipLaunchKernelGGL(k_cstart, grid(M), dim3(256), 0, st, h2.as<uint32_t>(), cid1.as<uint32_t>(), M,
+                       cstart.as<uint32_t>());
+    HIPCHK(hipMemcpyAsync(cstart.as<uint32_t>() + C, &M, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fill_ll, grid(C), dim3(256), 0, st, cmin.as<long long>(), C, LLONG_MAX);
+    hipLaunchKernelGGL(k_fill_ll, grid(C), dim3(256), 0, st, cmax.as<long long>(), C, LLONG_MIN);
+    hipLaunchKernelGGL(k_minmax, grid(M), dim3(256), 0, st, V.f_pos, V.f_len, cid1.as<uint32_t>(), M,
+                       cmin.as<long long>(), cmax.as<long long>());
+    HIPCHK(hipMemsetAsync(dmax.p, 0, 8, st));
+    hipLaunchKernelGGL(k_reflen, grid(C + 1), dim3(256), 0, st, cmin.as<long long>(), cmax.as<long long>(), C,
+                       Rl.as<uint32_t>(), dmax.as<unsigned long long>());
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32_to_u64(st, tmp.p, t2, Rl.as<uint32_t>(), ref_off.as<uint64_t>(), (size_t)C + 1));
+    HIPCHK(hipMemcpyAsync(&maxR, dmax.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&seq_len, ref_off.as<uint64_t>() + C, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (maxR > 0xffffffffull) return fail(SPRING_REORDER_E_ARG, "a contig consensus exceeds 2^32 bases");
+    pb = bits_for(maxR);
+    if (pb + bits_for(C) > 64) return fail(SPRING_REORDER_E_ARG, "contig count x contig length exceeds the 64-bit sort key");
+  } else {
+    DALLOC(ref_off, 16);
+    HIPCHK(hipMemsetAsync(ref_off.p, 0, 16, st));
+  }
+  HIPCHK(hipEventRecord(ev[1], st));
+
+  // ------------------------------------------------ sort by (contig, relative pos), stable
+  DBuf kA, kB, vA, vB, frec;
+  DALLOC(kA, (FMAX ? FMAX : 1) * 8); DALLOC(kB, (FMAX ? FMAX : 1) * 8);
+  DALLOC(vA, (FMAX ? FMAX : 1) * 4); DALLOC(vB, (FMAX ? FMAX : 1) * 4);
+  DALLOC(frec, (FMAX ? FMAX : 1) * 16);
+  const int key_bits = pb + bits_for(C);
+  if (M) {
+    hipLaunchKernelGGL(k_keys1, grid(M), dim3(256), 0, st, V.f_pos, cid1.as<uint32_t>(), cmin.as<long long>(), M, pb,
+                       kA.as<uint64_t>(), vA.as<uint32_t>());
+    t2 = tb;
+    HIPCHK(sr::sort_pairs(st, tmp.p, t2, kA.as<uint64_t>(), kB.as<uint64_t>(), vA.as<uint32_t>(), vB.as<uint32_t>(), M,
+                          (unsigned)key_bits));
+    hipLaunchKernelGGL(k_srec, grid(M), dim3(256), 0, st, kB.as<uint64_t>(), vB.as<uint32_t>(), V.f_order, V.f_rc,
+                       V.f_len, M, pb, frec.as<ulonglong2>());
+  }
+  HIPCHK(hipEventRecord(ev[2], st));
+
+  // ------------------------------------------------ consensus
+  DBuf refbits;
+  const uint64_t nwords = (seq_len + 31) / 32;
+  DALLOC(ctx->refc, seq_len + 64);
+  DALLOC(refbits, (nwords + 40) * 8);
+  HIPCHK(hipMemsetAsync(refbits.p, 0, (nwords + 40) * 8, st));
+  if (seq_len) {
+    hipLaunchKernelGGL(k_consensus, grid(seq_len), dim3(256), 0, st, frec.as<ulonglong2>(), cstart.as<uint32_t>(),
+                       ref_off.as<uint64_t>(), C, seq_len, V.reads, S, Lmax, ctx->refc.as<uint8_t>());
+    hipLaunchKernelGGL(k_pack_ref, grid(nwords), dim3(256), 0, st, ctx->refc.as<uint8_t>(), seq_len,
+                       refbits.as<uint64_t>(), nwords);
+  }
+  HIPCHK(hipEventRecord(ev[3], st));
+
+  // ------------------------------------------------ singleton pool + dictionaries
+  DBuf sread, srev, nmask, nmask_r, slen, ncnt, Tprev, Tnew;
+  DBuf tab[2], ids[2];
+  uint64_t tmask[2] = {0, 0};
+  bool have_tab[2] = {false, false};
+  int dstart[2], dend[2];
+  if (Lmax > 50) { dstart[0] = 0; dend[0] = 20; dstart[1] = 21; dend[1] = 41; }   // encoder.h:606-616
+  else { dstart[0] = 0; dend[0] = 20 * Lmax / 50; dstart[1] = 20 * Lmax / 50 + 1; dend[1] = 41 * Lmax / 50; }
+  uint32_t max_bin = 0;
+  DALLOC(sread, (size_t)(np ? np : 1) * S * 8); DALLOC(srev, (size_t)(np ? np : 1) * S * 8);
+  DALLOC(nmask, (size_t)(np ? np : 1) * SM * 8); DALLOC(nmask_r, (size_t)(np ? np : 1) * SM * 8);
+  DALLOC(slen, (size_t)(np ? np : 1) * 2); DALLOC(ncnt, (size_t)(np ? np : 1) * 2);
+  DALLOC(Tprev, (size_t)(np ? np : 1) * 8); DALLOC(Tnew, (size_t)(np ? np : 1) * 8);
+  DALLOC(order_sc, (size_t)(np ? np : 1) * 4);
+  if (np) {
+    HIPCHK(hipMemsetAsync(sread.p, 0, (size_t)np * S * 8, st));
+    HIPCHK(hipMemsetAsync(nmask.p, 0, (size_t)np * SM * 8, st));
+    if (ns)
+      hipLaunchKernelGGL(k_pool_clean, grid((uint64_t)ns * S), dim3(256), 0, st, V.reads, V.lens, S, V.f_order_s, ns,
+                         sread.as<uint64_t>(), slen.as<uint16_t>(), ncnt.as<uint16_t>());
+    if (nN)
+      hipLaunchKernelGGL(k_pool_N, grid(nN), dim3(256), 0, st, dN.as<uint8_t>(), doffN.as<uint64_t>(), nN, ns, S, SM,
+                         sread.as<uint64_t>(), nmask.as<uint64_t>(), slen.as<uint16_t>(), ncnt.as<uint16_t>());
+    hipLaunchKernelGGL(k_pool_rev, grid((uint64_t)np * S), dim3(256), 0, st, sread.as<uint64_t>(), nmask.as<uint64_t>(),
+                       slen.as<uint16_t>(), S, SM, np, srev.as<uint64_t>(), nmask_r.as<uint64_t>());
+    hipLaunchKernelGGL(k_pool_order, grid(np), dim3(256), 0, st, V.f_order_s, dorderN.as<uint32_t>(), ns, np,
+                       cumN.as<uint32_t>(), order_sc.as<uint32_t>());
+    DBuf flag, slot, keys, vals, skeys, ukeys, ucount, ustart, dnruns, dmx;
+    DALLOC(flag, (size_t)(np + 1) * 4); DALLOC(slot, (size_t)(np + 1) * 4); DALLOC(keys, (size_t)np * 8);
+    DALLOC(vals, (size_t)np * 4); DALLOC(skeys, (size_t)np * 8); DALLOC(ukeys, (size_t)np * 8);
+    DALLOC(ucount, (size_t)(np + 1) * 4); DALLOC(ustart, (size_t)(np + 1) * 4); DALLOC(dnruns, 16); DALLOC(dmx, 16);
+    for (int l = 0; l < 2; l++) {
+      const int klen = dend[l] - dstart[l] + 1;
+      if (klen <= 0 || klen > 32) continue;
+      HIPCHK(hipMemsetAsync(flag.p, 0, (size_t)(np + 1) * 4, st));
+      hipLaunchKernelGGL(k_pool_flag, grid(np), dim3(256), 0, st, slen.as<uint16_t>(), nmask.as<uint64_t>(), SM, np,
+                         dstart[l], dend[l], flag.as<uint32_t>());
+      t2 = tb;
+      HIPCHK(sr::excl_scan_u32(st, tmp.p, t2, flag.as<uint32_t>(), slot.as<uint32_t>(), (size_t)np + 1));
+      uint32_t nd = 0;
+      HIPCHK(hipMemcpyAsync(&nd, slot.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (!nd) continue;
+      hipLaunchKernelGGL(k_pool_keys, grid(np), dim3(256), 0, st, sread.as<uint64_t>(), S, flag.as<uint32_t>(),
+                         slot.as<uint32_t>(), np, dstart[l], klen, keys.as<uint64_t>(), vals.as<uint32_t>());
+      DALLOC(ids[l], (size_t)nd * 4);
+      t2 = tb;
+      HIPCHK(sr::sort_pairs(st, tmp.p, t2, keys.as<uint64_t>(), skeys.as<uint64_t>(), vals.as<uint32_t>(),
+                            ids[l].as<uint32_t>(), nd, (unsigned)(2 * klen)));
+      t2 = tb;
+      HIPCHK(sr::rle(st, tmp.p, t2, skeys.as<uint64_t>(), nd, ukeys.as<uint64_t>(), ucount.as<uint32_t>(),
+                     dnruns.as<uint32_t>()));
+      uint32_t nk = 0;
+      HIPCHK(hipMemcpyAsync(&nk, dnruns.p, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      t2 = tb;
+      HIPCHK(sr::excl_scan_u32(st, tmp.p, t2, ucount.as<uint32_t>(), ustart.as<uint32_t>(), nk));
+      t2 = tb;
+      HIPCHK(sr::reduce_max_u32(st, tmp.p, t2, ucount.as<uint32_t>(), dmx.as<uint32_t>(), nk));
+      uint32_t mb = 0;
+      HIPCHK(hipMemcpyAsync(&mb, dmx.p, 4, hipMemcpyDeviceToHost, st));
+      uint64_t cap = 1024;
+      while (cap < 2ull * nk) cap <<= 1;
+      tmask[l] = cap - 1;
+      DALLOC(tab[l], cap * 16);
+      HIPCHK(hipMemsetAsync(tab[l].p, 0, cap * 16, st));
+      hipLaunchKernelGGL(k_etab_insert, grid(nk), dim3(256), 0, st, ukeys.as<uint64_t>(), ustart.as<uint32_t>(),
+                         ucount.as<uint32_t>(), nk, tab[l].as<unsigned long long>(), tmask[l]);
+      HIPCHK(hipStreamSynchronize(st));
+      max_bin = std::max(max_bin, mb);
+      have_tab[l] = true;
+    }
+    HIPCHK(hipStreamSynchronize(st));  // the build scratch goes back to the pool
+  }
+  I.max_bin = max_bin;
+  HIPCHK(hipEventRecord(ev[4], st));
+
+  // ------------------------------------------------ alignment: fixed point of "first probe that takes the read"
+  uint32_t passes = 0;
+  DBuf dflag;
+  DALLOC(dflag, 16);
+  if (np) hipLaunchKernelGGL(k_fill_u64, grid(np), dim3(256), 0, st, Tprev.as<unsigned long long>(), (uint64_t)np, INF);
+  if (np && seq_len && (have_tab[0] || have_tab[1])) {
+    AlignP A;
+    A.refbits = refbits.as<uint64_t>(); A.ref_off = ref_off.as<uint64_t>(); A.C = C; A.seq_len = seq_len;
+    A.Lmax = Lmax; A.S = S;
+    for (int l = 0; l < 2; l++) {
+      A.dstart[l] = dstart[l]; A.dend[l] = dend[l];
+      A.tab[l] = have_tab[l] ? tab[l].as<unsigned long long>() : nullptr;
+      A.tmask[l] = tmask[l]; A.ids[l] = ids[l].as<uint32_t>();
+    }
+    A.sread = sread.as<uint64_t>(); A.srev = srev.as<uint64_t>(); A.slen = slen.as<uint16_t>(); A.ncnt = ncnt.as<uint16_t>();
+    const bool live = max_bin > (uint32_t)MAX_SEARCH_E;
+    for (;;) {
+      if (passes >= 1000) return fail(SPRING_REORDER_E_STATE, "singleton alignment did not reach its fixed point");
+      hipLaunchKernelGGL(k_fill_u64, grid(np), dim3(256), 0, st, Tnew.as<unsigned long long>(), (uint64_t)np, INF);
+      A.Tprev = Tprev.as<unsigned long long>(); A.Tnew = Tnew.as<unsigned long long>();
+      if (live) hipLaunchKernelGGL(k_align<true>, grid(seq_len), dim3(256), 0, st, A);
+      else hipLaunchKernelGGL(k_align<false>, grid(seq_len), dim3(256), 0, st, A);
+      passes++;
+      uint32_t changed = 0;
+      if (live) {
+        HIPCHK(hipMemsetAsync(dflag.p, 0, 4, st));
+        hipLaunchKernelGGL(k_differs, grid(np), dim3(256), 0, st, Tprev.as<unsigned long long>(),
+                           Tnew.as<unsigned long long>(), np, dflag.as<uint32_t>());
+        HIPCHK(hipMemcpyAsync(&changed, dflag.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+      }
+      std::swap(Tprev.p, Tnew.p);
+      if (!changed) break;
+    }
+  }
+  I.align_passes = passes;
+  unsigned long long *Tfin = Tprev.as<unsigned long long>();
+  HIPCHK(hipEventRecord(ev[5], st));
+
+  // ------------------------------------------------ aligned singletons join their contigs
+  uint32_t A_cnt = 0;
+  if (np) {
+    DBuf fa, sl, Pk, qv, Pks, qvs;
+    DALLOC(fa, (size_t)(np + 1) * 4); DALLOC(sl, (size_t)(np + 1) * 4);
+    HIPCHK(hipMemsetAsync(fa.p, 0, (size_t)(np + 1) * 4, st));
+    hipLaunchKernelGGL(k_flag_aligned_rev, grid(np), dim3(256), 0, st, Tfin, np, fa.as<uint32_t>());
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32(st, tmp.p, t2, fa.as<uint32_t>(), sl.as<uint32_t>(), (size_t)np + 1));
+    HIPCHK(hipMemcpyAsync(&A_cnt, sl.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (A_cnt) {
+      DALLOC(Pk, (size_t)A_cnt * 8); DALLOC(qv, (size_t)A_cnt * 4); DALLOC(Pks, (size_t)A_cnt * 8); DALLOC(qvs, (size_t)A_cnt * 4);
+      hipLaunchKernelGGL(k_gather_aligned, grid(np), dim3(256), 0, st, Tfin, fa.as<uint32_t>(), sl.as<uint32_t>(), np,
+                         Pk.as<uint64_t>(), qv.as<uint32_t>());
+      t2 = tb;
+      HIPCHK(sr::sort_pairs(st, tmp.p, t2, Pk.as<uint64_t>(), Pks.as<uint64_t>(), qv.as<uint32_t>(), qvs.as<uint32_t>(),
+                            A_cnt, (unsigned)std::min(64, bits_for(seq_len) + 2)));
+      hipLaunchKernelGGL(k_single_rec, grid(A_cnt), dim3(256), 0, st, Pks.as<uint64_t>(), qvs.as<uint32_t>(), A_cnt,
+                         ref_off.as<uint64_t>(), C, Lmax, slen.as<uint16_t>(), pb, kB.as<uint64_t>() + M,
+                         frec.as<ulonglong2>() + M);
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+  const uint64_t F = (uint64_t)M + A_cnt;
+  const uint64_t *kfin = kB.as<uint64_t>();
+  const uint32_t *vfin = vB.as<uint32_t>();
+  if (F) {
+    hipLaunchKernelGGL(k_iota, grid(F), dim3(256), 0, st, vB.as<uint32_t>(), F);
+    if (A_cnt) {
+      t2 = tb;
+      HIPCHK(sr::sort_pairs(st, tmp.p, t2, kB.as<uint64_t>(), kA.as<uint64_t>(), vB.as<uint32_t>(), vA.as<uint32_t>(), F,
+                            (unsigned)key_bits));
+      kfin = kA.as<uint64_t>();
+      vfin = vA.as<uint32_t>();
+    }
+  }
+  HIPCHK(hipEventRecord(ev[6], st));
+
+  // ------------------------------------------------ noise, pos, order, rc, readlength
+  uint64_t n_noisepos = 0;
+  uint32_t n_unal = 0;
+  DBuf fr, uslot, usz, uoff, ulen, ulsum;
+  if (np) {
+    DALLOC(fr, (size_t)(np + 2) * 4); DALLOC(uslot, (size_t)(np + 2) * 4); DALLOC(usz, (size_t)(np + 2) * 4);
+    DALLOC(uoff, (size_t)(np + 2) * 8); DALLOC(ulen, (size_t)(np + 2) * 4); DALLOC(ulsum, (size_t)(np + 2) * 8);
+    hipLaunchKernelGGL(k_flag_rem, grid(np + 1), dim3(256), 0, st, Tfin, slen.as<uint16_t>(), np, fr.as<uint32_t>(),
+                       usz.as<uint32_t>(), ulen.as<uint32_t>());
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32(st, tmp.p, t2, fr.as<uint32_t>(), uslot.as<uint32_t>(), (size_t)np + 1));
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32_to_u64(st, tmp.p, t2, usz.as<uint32_t>(), uoff.as<uint64_t>(), (size_t)np + 1));
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32_to_u64(st, tmp.p, t2, ulen.as<uint32_t>(), ulsum.as<uint64_t>(), (size_t)np + 1));
+    uint32_t rem_s = 0;
+    HIPCHK(hipMemcpyAsync(&n_unal, uslot.as<uint32_t>() + np, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&rem_s, uslot.as<uint32_t>() + ns, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&I.unaligned_bytes, uoff.as<uint64_t>() + np, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&I.len_unaligned, ulsum.as<uint64_t>() + np, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    I.matched_s = ns - rem_s;
+    I.matched_N = nN - (n_unal - rem_s);
+  }
+  I.n_aligned = F;
+  I.n_total = F + n_unal;
+  DBuf nm, noff;
+  DALLOC(nm, (size_t)(F + 2) * 4); DALLOC(noff, (size_t)(F + 2) * 8);
+  DALLOC(ctx->pos, (size_t)(F ? F : 1) * 8); DALLOC(ctx->rc, (size_t)(F ? F : 1));
+  DALLOC(ctx->order, (size_t)(I.n_total ? I.n_total : 1) * 4); DALLOC(ctx->rlen, (size_t)(I.n_total ? I.n_total : 1) * 2);
+  NoiseP N;
+  N.kfin = kfin; N.vfin = vfin; N.frec = frec.as<ulonglong2>(); N.F = F; N.pb = pb;
+  N.ref_off = ref_off.as<uint64_t>(); N.refbits = refbits.as<uint64_t>(); N.reads = V.reads; N.S = S; N.SM = SM;
+  N.sread = sread.as<uint64_t>(); N.srev = srev.as<uint64_t>(); N.nmask = nmask.as<uint64_t>();
+  N.nmask_r = nmask_r.as<uint64_t>(); N.cumN = cumN.as<uint32_t>(); N.order_sc = order_sc.as<uint32_t>();
+  N.nm = nm.as<uint32_t>(); N.noff = noff.as<uint64_t>(); N.noise = nullptr; N.noisepos = nullptr;
+  N.out_pos = ctx->pos.as<uint64_t>(); N.out_order = ctx->order.as<uint32_t>(); N.out_rlen = ctx->rlen.as<uint16_t>();
+  N.out_rc = ctx->rc.as<char>();
+  if (F) {
+    HIPCHK(hipMemsetAsync(nm.as<uint32_t>() + F, 0, 4, st));
+    hipLaunchKernelGGL(k_noise<false>, grid(F), dim3(256), 0, st, N);
+    t2 = tb;
+    HIPCHK(sr::excl_scan_u32_to_u64(st, tmp.p, t2, nm.as<uint32_t>(), noff.as<uint64_t>(), (size_t)F + 1));
+    HIPCHK(hipMemcpyAsync(&n_noisepos, noff.as<uint64_t>() + F, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  I.n_noisepos = n_noisepos;
+  I.noise_bytes = n_noisepos + F;
+  DALLOC(ctx->noise, I.noise_bytes ? I.noise_bytes : 1);
+  DALLOC(ctx->noisepos, (n_noisepos ? n_noisepos : 1) * 2);
+  if (F) {
+    N.noise = ctx->noise.as<char>();
+    N.noisepos = ctx->noisepos.as<uint16_t>();
+    hipLaunchKernelGGL(k_noise<true>, grid(F), dim3(256), 0, st, N);
+  }
+  HIPCHK(hipEventRecord(ev[7], st));
+
+  // ------------------------------------------------ unaligned reads, per-tid seq offsets
+  DALLOC(ctx->unaligned, I.unaligned_bytes ? I.unaligned_bytes : 1);
+  if (n_unal)
+    hipLaunchKernelGGL(k_unaligned, grid(np), dim3(256), 0, st, fr.as<uint32_t>(), uslot.as<uint32_t>(),
+                       uoff.as<uint64_t>(), np, sread.as<uint64_t>(), nmask.as<uint64_t>(), slen.as<uint16_t>(), S, SM,
+                       order_sc.as<uint32_t>(), F, ctx->order.as<uint32_t>(), ctx->rlen.as<uint16_t>(),
+                       ctx->unaligned.as<uint8_t>());
+  ctx->tid_seq.assign(T + 1, 0);
+  if (M) {
+    DBuf dts;
+    DALLOC(dts, (size_t)(T + 1) * 8);
+    hipLaunchKernelGGL(k_tid_seq, grid(T + 1), dim3(256), 0, st, dtid.as<uint64_t>(), T, M, cid1.as<uint32_t>(),
+                       ref_off.as<uint64_t>(), seq_len, dts.as<uint64_t>());
+    HIPCHK(hipMemcpyAsync(ctx->tid_seq.data(), dts.p, (size_t)(T + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  HIPCHK(hipEventRecord(ev[8], st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  for (int i = 0; i < 8; i++) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    I.ms_phase[i] = ms;
+    I.ms_device += ms;
+  }
+  I.seq_len = seq_len;
+  I.num_contigs = C;
+  ctx->have = true;
+  if (info_out) *info_out = I;
+  return 0;
+}
+
+int spring_encoder_download(spring_encoder_ctx *ctx, char *seq, uint64_t *seq_len_tid, uint64_t *pos, char *noise,
+                            uint16_t *noisepos, uint32_t *order, uint16_t *rlen, char *rc, uint8_t *unaligned) {
+  if (!ctx || !ctx->have) return fail(SPRING_REORDER_E_STATE, "nothing encoded yet");
+  const int dev = ctx->dev;
+  HIPCHK(hipSetDevice(dev));
+  const spring_encoder_info &I = ctx->info;
+  hipStream_t st = ctx->st;
+  if (seq && I.seq_len) {
+    DBuf a;
+    DALLOC(a, I.seq_len);
+    hipLaunchKernelGGL(k_seq_ascii, grid(I.seq_len), dim3(256), 0, st, ctx->refc.as<uint8_t>(), I.seq_len, a.as<char>());
+    HIPCHK(hipMemcpyAsync(seq, a.p, I.seq_len, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  if (seq_len_tid)
+    for (int t = 0; t < ctx->T; t++) seq_len_tid[t] = ctx->tid_seq[t + 1] - ctx->tid_seq[t];
+  if (pos && I.n_aligned) HIPCHK(hipMemcpyAsync(pos, ctx->pos.p, I.n_aligned * 8, hipMemcpyDeviceToHost, st));
+  if (noise && I.noise_bytes) HIPCHK(hipMemcpyAsync(noise, ctx->noise.p, I.noise_bytes, hipMemcpyDeviceToHost, st));
+  if (noisepos && I.n_noisepos) HIPCHK(hipMemcpyAsync(noisepos, ctx->noisepos.p, I.n_noisepos * 2, hipMemcpyDeviceToHost, st));
+  if (order && I.n_total) HIPCHK(hipMemcpyAsync(order, ctx->order.p, I.n_total * 4, hipMemcpyDeviceToHost, st));
+  if (rlen && I.n_total) HIPCHK(hipMemcpyAsync(rlen, ctx->rlen.p, I.n_total * 2, hipMemcpyDeviceToHost, st));
+  if (rc && I.n_aligned) HIPCHK(hipMemcpyAsync(rc, ctx->rc.p, I.n_aligned, hipMemcpyDeviceToHost, st));
+  if (unaligned && I.unaligned_bytes)
+    HIPCHK(hipMemcpyAsync(unaligned, ctx->unaligned.p, I.unaligned_bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int spring_encoder_download_seq_packed(spring_encoder_ctx *ctx, uint8_t *packed, char *tail) {
+  if (!ctx || !ctx->have) return fail(SPRING_REORDER_E_STATE, "nothing encoded yet");
+  if (!packed || !tail) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  const int dev = ctx->dev;
+  HIPCHK(hipSetDevice(dev));
+  hipStream_t st = ctx->st;
+  uint64_t total = 0;
+  for (int t = 0; t < ctx->T; t++) total += (ctx->tid_seq[t + 1] - ctx->tid_seq[t]) / 4;
+  DBuf d;
+  DALLOC(d, total ? total : 1);
+  uint64_t o = 0;
+  std::vector<uint8_t> tcodes(4);
+  for (int t = 0; t < ctx->T; t++) {
+    const uint64_t b0 = ctx->tid_seq[t], len = ctx->tid_seq[t + 1] - b0, nb = len / 4;
+    if (nb) hipLaunchKernelGGL(k_seq_pack, grid(nb), dim3(256), 0, st, ctx->refc.as<uint8_t>(), b0, nb, d.as<uint8_t>() + o);
+    o += nb;
+    memset(tail + 4 * t, 0, 4);
+    if (len % 4) {
+      HIPCHK(hipMemcpyAsync(tcodes.data(), ctx->refc.as<uint8_t>() + b0 + nb * 4, len % 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      for (uint64_t k = 0; k < len % 4; k++) tail[4 * t + k] = "AGCT"[tcodes[k] & 3];
+    }
+  }
+  if (total) HIPCHK(hipMemcpyAsync(packed, d.p, total, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "reorder_device.h"
+#include "reorder_internal.h"
 #include "spring_reorder.h"
 #include "synth_common.h"
 
@@ -168,6 +169,24 @@ struct spring_reorder_ctx {
     pool_free(dev, p);
   }
 };
+
+namespace sr {
+int reorder_view(spring_reorder_ctx *ctx, ReorderView *v) {
+  if (!ctx || !v) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  if (ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "reorder context is not finalized");
+  if (ctx->mg) return fail(SPRING_REORDER_E_STATE, "single-pool multi-GPU contexts hold partial streams");
+  v->dev = ctx->dev; v->st = ctx->st; v->n = ctx->n; v->L = ctx->L; v->W = ctx->W; v->S = ctx->S;
+  v->reads = ctx->d_reads; v->lens = ctx->d_lens; v->nrec = ctx->nrec; v->nsing = ctx->nsing;
+  v->f_order = ctx->P.f_order; v->f_order_s = ctx->P.f_order_s; v->f_rc = ctx->P.f_rc; v->f_flag = ctx->P.f_flag;
+  v->f_pos = ctx->P.f_pos; v->f_len = ctx->P.f_len; v->tid_off = ctx->tid_off.data(); v->num_thr = ctx->o.num_thr;
+  return 0;
+}
+hipError_t dev_alloc(int dev, size_t bytes, void **out) {
+  size_t actual = 0;
+  return pool_alloc(dev, bytes ? bytes : 16, out, &actual);
+}
+void dev_free(int dev, void *p) { if (p) pool_free(dev, p); }
+}  // namespace sr
 
 #define DMALLOC(ptr, bytes)                                   \
   do {                                                        \

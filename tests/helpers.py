@@ -109,3 +109,104 @@ def check_invariants(res, read, ln, L, n):
                 fl = res["flag"][a:b]
                 assert fl[0] == ord("0") and fl[-1] == ord("1")
                 assert not np.any((fl[:-1] == ord("0")) & (fl[1:] == ord("0")))
+
+
+# ------------------------------------------------------------------ encoder stage (row f2)
+
+DEC_NOISE = {"A": "CGTN", "C": "AGTN", "G": "TACN", "T": "GCAN", "N": "AGCT"}  # decompress.cpp:664-684
+_RC = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def decode_reads(enc):
+    """What the decompressor does with the encoder's streams (decompress.cpp:236-266): -> {order: read string}
+    for the aligned reads, in their original orientation."""
+    seq = enc["seq"].decode()
+    noise_lines = enc["noise"].decode().split("\n")
+    npos = enc["noisepos"]
+    out, k = {}, 0
+    for i in range(len(enc["pos"])):
+        p, ln = int(enc["pos"][i]), int(enc["rlen"][i])
+        r = list(seq[p:p + ln])
+        prev = 0
+        for ch in noise_lines[i]:
+            prev += int(npos[k])
+            k += 1
+            r[prev] = DEC_NOISE[r[prev]][int(ch)]
+        s = "".join(r)
+        if chr(enc["rc"][i]) == "r":
+            s = "".join(_RC[c] for c in reversed(s))
+        out[int(enc["order"][i])] = s
+    assert k == len(npos)
+    return out
+
+
+def unpack_dnaN(buf, count=None):
+    """read_dnaN_from_bits (util.cpp:350-374) over a whole stream -> list of strings."""
+    out, p = [], 0
+    while p < len(buf) and (count is None or len(out) < count):
+        n = int.from_bytes(buf[p:p + 2], "little")
+        p += 2
+        body = buf[p:p + (n + 1) // 2]
+        p += (n + 1) // 2
+        out.append("".join("AGCTN"[(body[j // 2] >> (4 * (j & 1))) & 15] for j in range(n)))
+    return out
+
+
+def read_strings(read, ln):
+    """2-bit limbs -> list of strings (bitsettostring, reorder.h:76-92)."""
+    out = []
+    lut = np.frombuffer(b"AGCT", dtype=np.uint8)
+    for i in range(len(ln)):
+        n = int(ln[i])
+        j = np.arange(n)
+        codes = (read[i][j >> 5] >> (2 * (j & 31)).astype(np.uint64)) & np.uint64(3)
+        out.append(lut[codes.astype(np.int64)].tobytes().decode())
+    return out
+
+
+def make_N_reads(strings, count, seed, max_N=3, deep=0):
+    """Reads with N for the encoder tests: `count` clean reads re-sampled with 1..max_N bases replaced
+    by N (half of them reverse complemented), plus `deep` near-copies of one read whose N sits outside
+    both dictionary windows (bins deeper than MAX_SEARCH_ENCODER).  -> list of strings."""
+    rng = np.random.default_rng(seed)
+    out = []
+    if not strings:
+        return out
+    for _ in range(count):
+        s = list(strings[int(rng.integers(len(strings)))])
+        for _ in range(int(rng.integers(1, max_N + 1))):
+            s[int(rng.integers(len(s)))] = "N"
+        s = "".join(s)
+        if rng.integers(2):
+            s = "".join(_RC[c] for c in reversed(s))
+        out.append(s)
+    if deep:
+        base = strings[int(rng.integers(len(strings)))]
+        for k in range(deep):
+            s = list(base)
+            if len(s) > 50:
+                s[45 + int(rng.integers(len(s) - 45))] = "N"
+            s = "".join(s)
+            if k % 3 == 2:
+                s = "".join(_RC[c] for c in reversed(s))
+            out.append(s)
+    return out
+
+
+def interleave_order_N(n_clean, nN, seed):
+    """Positions of the N reads in the original file (read_order_N.bin): a sorted random subset."""
+    rng = np.random.default_rng(seed)
+    return np.sort(rng.choice(n_clean + nN, size=nN, replace=False)).astype(np.uint32)
+
+
+ENC_KEYS = ("seq", "seq_len_tid", "pos", "noise", "noisepos", "order", "rlen", "rc", "unaligned", "len_unaligned",
+            "matched_s", "matched_N", "num_contigs")
+
+
+def same_encoding(a, b, what=""):
+    for k in ENC_KEYS:
+        x, y = a[k], b[k]
+        if isinstance(x, np.ndarray):
+            assert np.array_equal(x, y), (what, k, len(x), len(y))
+        else:
+            assert x == y, (what, k)

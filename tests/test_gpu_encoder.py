@@ -1,0 +1,106 @@
+"""GPU parity tests of the encoder stage: spring_encoder_* through the C ABI against
+oracle/encoder_oracle.c on identical inputs.  Bar: every output stream bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import (decode_reads, interleave_order_N, make_N_reads, named_set, read_strings, same_encoding,
+                     unpack_dnaN)
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(name, K, T, nN=0, deep=0, seed=1):
+    import spring_amd
+    from spring_amd.encoder import EncoderStage
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    strs = read_strings(read, ln) if (nN or deep) else []
+    Nreads = make_N_reads(strs, nN, seed, deep=deep)
+    dnaN = po.pack_dnaN(Nreads)
+    order_N = interleave_order_N(n, len(Nreads), seed + 7)
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=T)) as st:
+        st.load_dna(dna, n, L)
+        st.run()
+        streams = st.streams()
+        with EncoderStage() as enc:
+            info = enc.encode(st, dnaN, order_N)
+            got = enc.streams()
+            packed, tails = enc.seq_packed()
+    want = po.encode(read, ln, L, streams, num_thr=T, dnaN=dnaN, order_N=order_N)
+    return got, want, info, (packed, tails), (read, ln, Nreads, order_N, n)
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "syn1k_511", "syn2k_20", "var2k",
+                                  "var_short", "var_long", "heavy", "repeat10k", "dups", "test_1+2", "one", "empty"])
+@pytest.mark.parametrize("K,T", [(1, 1), (7, 3)])
+def test_encoder_bit_exact_vs_oracle(name, K, T):
+    got, want, info, _, _ = _run(name, K, T)
+    same_encoding(got, want, name)
+
+
+@pytest.mark.parametrize("name", ["syn5k_150", "var2k", "syn2k_251", "repeat10k", "syn3k_64"])
+def test_encoder_with_N_reads(name):
+    got, want, info, _, (read, ln, Nreads, order_N, n) = _run(name, 16, 2, nN=400, seed=3)
+    same_encoding(got, want, name)
+    assert info["matched_N"] > 0
+    # decode -> the original reads (decompress.cpp:236-266)
+    dec = decode_reads(got)
+    cum = np.zeros(n + len(Nreads), bool)
+    cum[order_N] = True
+    clean_pos = np.flatnonzero(~cum)
+    strs = read_strings(read, ln)
+    orig = {int(clean_pos[i]): strs[i] for i in range(n)}
+    orig.update({int(order_N[i]): Nreads[i] for i in range(len(Nreads))})
+    for o, s in dec.items():
+        assert orig[o] == s
+    na = len(got["pos"])
+    for k, s in enumerate(unpack_dnaN(got["unaligned"])):
+        assert orig[int(got["order"][na + k])] == s
+    assert sorted(got["order"].tolist()) == list(range(n + len(Nreads)))
+
+
+@pytest.mark.parametrize("name", ["syn5k_150", "syn2k_100"])
+def test_encoder_deep_bins_need_the_fixed_point(name):
+    """> MAX_SEARCH_ENCODER reads in one bin: the 1000-read window moves as earlier probes empty the bin."""
+    got, want, info, _, _ = _run(name, 8, 2, nN=50, deep=3500, seed=5)
+    assert info["max_bin"] > 1000 and info["align_passes"] >= 2
+    same_encoding(got, want, name)
+
+
+def test_seq_packing_matches_pack_compress_seq():
+    import ctypes as C
+    got, want, info, (packed, tails), _ = _run("syn5k_150", 9, 4)
+    L = po.lib()
+    L.orc_pack_seq.restype = C.c_uint64
+    L.orc_pack_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    off, exp, exp_tails = 0, b"", []
+    for t, sl in enumerate(want["seq_len_tid"]):
+        sl = int(sl)
+        seg = want["seq"][off:off + sl]
+        buf = np.zeros(max(sl // 4, 1), np.uint8)
+        tail = np.zeros(4, np.uint8)
+        nb = L.orc_pack_seq(seg, sl, buf.ctypes.data, tail.ctypes.data)
+        exp += buf[:nb].tobytes()
+        exp_tails.append(tail[:sl % 4].tobytes().decode())
+        off += sl
+    assert packed == exp and tails == exp_tails
+
+
+def test_encoder_100k_many_chains():
+    import readsets as rs
+    import spring_amd
+    from spring_amd.encoder import EncoderStage
+    n, L = 100000, 100
+    a = rs.np_reads(321, n * L // 30, n, L, 0.01)
+    dna = rs.pack_fixed(a)
+    read, ln = po.load_dna(dna, n, L)
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=64, num_thr=4)) as st:
+        st.load_dna(dna, n, L)
+        st.run()
+        streams = st.streams()
+        with EncoderStage() as enc:
+            enc.encode(st)
+            got = enc.streams()
+    want = po.encode(read, ln, L, streams, num_thr=4)
+    same_encoding(got, want, "100k")
