@@ -57,7 +57,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
                                   uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t numreads_N,
                                   spring_encoder_info *info);
 
-/* Copy the streams to host buffers sized from spring_encoder_info (any pointer may be NULL):
+/* Copy the streams to host buffers sized from the info struct; any pointer may be NULL:
  *   seq          seq_len chars (read_seq.bin.<tid> texts, tid-major); seq_len_tid[num_thr]
  *   pos          n_aligned u64 (read_pos.bin, absolute)
  *   noise        noise_bytes; noisepos n_noisepos u16

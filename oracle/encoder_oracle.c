@@ -264,10 +264,10 @@ int orc_encode(const orc_enc_in *in, orc_enc_out *out) {
   /* ---- dictionaries (encoder.h:606-621) */
   dict_t dict[2];
   memset(dict, 0, sizeof(dict));
-  if (L > 50) {
-    dict[0].start = 0; dict[0].end = 20; dict[1].start = 21; dict[1].end = 41;
-  } else {
-    dict[0].start = 0; dict[0].end = 20 * L / 50; dict[1].start = 20 * L / 50 + 1; dict[1].end = 41 * L / 50;
+  {
+    int ds[2], de[2];
+    orc_enc_dict_windows(L, ds, de);
+    for (int l = 0; l < 2; l++) { dict[l].start = ds[l]; dict[l].end = de[l]; }
   }
   dict[0].bpb = dict[1].bpb = 3;
   if (np > 0)
@@ -440,4 +440,28 @@ uint64_t orc_pack_seq(const char *seq, uint64_t len, uint8_t *packed, char *tail
   }
   for (uint64_t k = 0; k < len % 4; k++) tail[k] = seq[len / 4 * 4 + k];
   return len / 4;
+}
+
+/* ---- bpb = 3 primitives exposed for tests/test_oracle_vs_ref.py (pinned against the real bitset_util) */
+void orc_enc_bits3(const char *s, int n, uint64_t *b, int W) { string_to_bits3(s, n, b, W); }
+int orc_enc_hamming3(const uint64_t *a, const uint64_t *b, int W, int len) { return hamming3(a, b, W, len); }
+void orc_enc_dict_windows(int L, int start[2], int end[2]) { /* encoder.h:606-616 */
+  if (L > 50) { start[0] = 0; end[0] = 20; start[1] = 21; end[1] = 41; }
+  else { start[0] = 0; end[0] = 20 * L / 50; start[1] = 20 * L / 50 + 1; end[1] = 41 * L / 50; }
+}
+uint32_t orc_enc_build_dict(const uint64_t *read3, const uint16_t *len, uint32_t n, int L, int which, uint64_t *keys_out,
+                            uint32_t *startpos_out, uint32_t *read_id_out, uint32_t *dict_numreads) {
+  int s[2], e[2];
+  orc_enc_dict_windows(L, s, e);
+  dict_t d;
+  memset(&d, 0, sizeof(d));
+  d.start = s[which]; d.end = e[which]; d.bpb = 3;
+  orc__dict_build(&d, read3, len, n, (3 * L - 1) / 64 + 1);
+  memcpy(keys_out, d.keys, sizeof(uint64_t) * d.numkeys);
+  memcpy(startpos_out, d.startpos, sizeof(uint32_t) * ((size_t)d.numkeys + 1));
+  memcpy(read_id_out, d.read_id, sizeof(uint32_t) * d.dict_numreads);
+  *dict_numreads = d.dict_numreads;
+  uint32_t nk = d.numkeys;
+  orc__dict_free(&d);
+  return nk;
 }

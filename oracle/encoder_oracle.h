@@ -48,5 +48,10 @@ typedef struct {
 
 int orc_encode(const orc_enc_in *in, orc_enc_out *out);
 void orc_encode_free(orc_enc_out *out);
+void orc_enc_bits3(const char *s, int n, uint64_t *b, int W);
+int orc_enc_hamming3(const uint64_t *a, const uint64_t *b, int W, int len);
+void orc_enc_dict_windows(int L, int start[2], int end[2]);
+uint32_t orc_enc_build_dict(const uint64_t *read3, const uint16_t *len, uint32_t n, int L, int which, uint64_t *keys_out,
+                            uint32_t *startpos_out, uint32_t *read_id_out, uint32_t *dict_numreads);
 uint64_t orc_pack_seq(const char *seq, uint64_t len, uint8_t *packed, char *tail);
 #endif

@@ -21,14 +21,14 @@ template <size_t BS>
 int build_dict(const uint64_t *limbs, const uint16_t *len, uint32_t n, int which_start[2],
                int which_end[2], const char *basedir, int num_thr, int which,
                const uint64_t *probe_keys, uint32_t nprobe, uint32_t *bin_size,
-               uint32_t *bin_ids /* concatenated */, uint32_t *numkeys, uint32_t *dict_numreads) {
+               uint32_t *bin_ids /* concatenated */, uint32_t *numkeys, uint32_t *dict_numreads, int bpb = 2) {
   std::bitset<BS> *read = new std::bitset<BS>[n ? n : 1];
   for (uint32_t i = 0; i < n; i++) std::memcpy((void *)&read[i], limbs + (size_t)i * (BS / 64), BS / 8);
   spring::bbhashdict *dict = new spring::bbhashdict[2];
   for (int l = 0; l < 2; l++) { dict[l].start = which_start[l]; dict[l].end = which_end[l]; }
   omp_set_num_threads(num_thr);
   std::vector<uint16_t> lens(len, len + n);
-  spring::constructdictionary<BS>(read, dict, lens.data(), 2, n, 2, std::string(basedir), num_thr);
+  spring::constructdictionary<BS>(read, dict, lens.data(), 2, n, bpb, std::string(basedir), num_thr);
   spring::bbhashdict &d = dict[which];
   *numkeys = d.numkeys;
   *dict_numreads = d.dict_numreads;
@@ -47,15 +47,16 @@ int build_dict(const uint64_t *limbs, const uint16_t *len, uint32_t n, int which
 }
 
 template <size_t BS>
-int mask_hamming(const uint64_t *a, const uint64_t *b, int L, int i, int j) {
+int mask_hamming(const uint64_t *a, const uint64_t *b, int L, int i, int j, int bpb = 2) {
   static std::bitset<BS> **mask = nullptr;
-  static int maskL = -1;
-  if (maskL != L) {
+  static int maskL = -1, maskB = -1;
+  if (maskL != L || maskB != bpb) {
     if (mask) { for (int k = 0; k < maskL; k++) delete[] mask[k]; delete[] mask; }
     mask = new std::bitset<BS> *[L];
     for (int k = 0; k < L; k++) mask[k] = new std::bitset<BS>[L];
-    spring::generatemasks<BS>(mask, L, 2);
+    spring::generatemasks<BS>(mask, L, bpb);
     maskL = L;
+    maskB = bpb;
   }
   std::bitset<BS> x, y;
   std::memcpy((void *)&x, a, BS / 8);
@@ -121,6 +122,23 @@ int64_t ref_bin_live(uint32_t *read_id, uint32_t cap) {
 // ((a ^ b) & mask[i][j]).count() with the real generatemasks (bitset_util.h:223-236)
 int ref_mask_hamming(const uint64_t *a, const uint64_t *b, int W, int L, int i, int j) {
 #define CALL(BS) mask_hamming<BS>(a, b, L, i, j)
+  DISPATCH(W, CALL)
+#undef CALL
+}
+
+// the same two entry points with the encoder's 3 bits per base (encoder.h:617-619, :131-140)
+int ref_build_dict_bpb(const uint64_t *limbs, const uint16_t *len, uint32_t n, int W, int start0, int end0, int start1,
+                       int end1, const char *basedir, int num_thr, int which, const uint64_t *probe_keys,
+                       uint32_t nprobe, uint32_t *bin_size, uint32_t *bin_ids, uint32_t *numkeys,
+                       uint32_t *dict_numreads, int bpb) {
+  int s[2] = {start0, start1}, e[2] = {end0, end1};
+  if (chdir(basedir) != 0) return -2;
+#define CALL(BS) build_dict<BS>(limbs, len, n, s, e, basedir, num_thr, which, probe_keys, nprobe, bin_size, bin_ids, numkeys, dict_numreads, bpb)
+  DISPATCH(W, CALL)
+#undef CALL
+}
+int ref_mask_hamming_bpb(const uint64_t *a, const uint64_t *b, int W, int L, int i, int j, int bpb) {
+#define CALL(BS) mask_hamming<BS>(a, b, L, i, j, bpb)
   DISPATCH(W, CALL)
 #undef CALL
 }

@@ -54,7 +54,7 @@ class EncoderStage:
         return self.info
 
     def streams(self):
-        """-> dict with the same keys as oracle.pyoracle.encode()."""
+        """-> dict of the output streams (seq, seq_len_tid, pos, noise, noisepos, order, rlen, rc, unaligned, ...)."""
         i = self.info
         seq = np.zeros(max(i["seq_len"], 1), np.uint8)
         seq_len_tid = np.zeros(max(self.num_thr, 1), np.uint64)

@@ -170,6 +170,7 @@ def make_N_reads(strings, count, seed, max_N=3, deep=0):
     both dictionary windows (bins deeper than MAX_SEARCH_ENCODER).  -> list of strings."""
     rng = np.random.default_rng(seed)
     out = []
+    strings = [s for s in strings if len(s) > 0]
     if not strings:
         return out
     for _ in range(count):

@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from spring_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "spring_reorder.h")).read()
-    declared = set(re.findall(r"\b(spring_(?:reorder|synth|order)_\w+)\s*\(", hdr))
+    hdr = (open(os.path.join(ROOT, "include", "spring_reorder.h")).read()
+           + open(os.path.join(ROOT, "include", "spring_encoder.h")).read())
+    declared = set(re.findall(r"\b(spring_(?:reorder|synth|order|encoder)_\w+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     L = _lib.lib()
     for name in sorted(declared):

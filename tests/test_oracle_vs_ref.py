@@ -74,3 +74,82 @@ def test_hamming_masks_match_reference(L):
         want = ref.ref_mask_hamming(a.ctypes.data, b.ctypes.data, W, L, i, j)  # mask[i][j] = bases [i, L-j)
         got = po.lib().orc_hamming_range(a.ctypes.data, b.ctypes.data, W, i, L - j)
         assert got == want
+
+
+# ------------------------------------------------------------------ encoder stage: 3 bits per base
+
+def _bits3(strings, L):
+    W3 = (3 * L - 1) // 64 + 1
+    Lb = po.lib()
+    Lb.orc_enc_bits3.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
+    out = np.zeros((max(len(strings), 1), W3), np.uint64)
+    for i, s in enumerate(strings):
+        Lb.orc_enc_bits3(s.encode(), len(s), out[i].ctypes.data, W3)
+    return out[:len(strings)], W3
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "syn3k_64", "var2k", "var_short", "dups"])
+def test_encoder_dictionary_bpb3_matches_reference(name):
+    """constructdictionary<N>(..., bpb = 3, ...) as encoder_main calls it (encoder.h:617-619), reads with N included."""
+    from helpers import make_N_reads, read_strings
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    strs = read_strings(read, ln)
+    pool = strs[: n // 2] + make_N_reads(strs, 300, 11)
+    lens = np.array([len(s) for s in pool], np.uint16)
+    b3, W3 = _bits3(pool, L)
+    assert W3 <= 16
+    Lb = po.lib()
+    s, e = (C.c_int * 2)(), (C.c_int * 2)()
+    Lb.orc_enc_dict_windows(L, s, e)
+    Lb.orc_enc_build_dict.restype = C.c_uint32
+    Lb.orc_enc_build_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.POINTER(C.c_uint32)]
+    ref.ref_build_dict_bpb.restype = C.c_int
+    ref.ref_build_dict_bpb.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
+    m = len(pool)
+    for which in (0, 1):
+        keys = np.zeros(m, np.uint64)
+        sp = np.zeros(m + 1, np.uint32)
+        ids = np.zeros(m, np.uint32)
+        dn = C.c_uint32()
+        nk = Lb.orc_enc_build_dict(b3.ctypes.data, lens.ctypes.data, m, L, which, keys.ctypes.data, sp.ctypes.data,
+                                   ids.ctypes.data, C.byref(dn))
+        keys, sp, ids = keys[:nk], sp[:nk + 1], ids[:dn.value]
+        bin_size = np.zeros(max(nk, 1), np.uint32)
+        bin_ids = np.zeros(max(2 * len(ids), 1), np.uint32)
+        rnk, rdn = C.c_uint32(), C.c_uint32()
+        with tempfile.TemporaryDirectory() as td:
+            rc = ref.ref_build_dict_bpb(np.ascontiguousarray(b3).ctypes.data, lens.ctypes.data, m, W3, s[0], e[0], s[1],
+                                        e[1], td.encode(), 2, which, keys.ctypes.data, nk, bin_size.ctypes.data,
+                                        bin_ids.ctypes.data, C.byref(rnk), C.byref(rdn), 3)
+        assert rc == 0
+        assert rnk.value == nk and rdn.value == dn.value
+        o = 0
+        for i in range(nk):
+            sz = int(bin_size[i])
+            assert sz == sp[i + 1] - sp[i]
+            assert np.array_equal(bin_ids[o:o + sz], ids[sp[i]:sp[i + 1]])
+            o += sz
+        assert o == len(ids)
+
+
+@pytest.mark.parametrize("L", [40, 100, 151])
+def test_encoder_hamming_mask_bpb3_matches_reference(L):
+    """((a ^ b) & mask[0][L - len]).count() with generatemasks(mask, L, 3) (encoder.h:139-140, :290-297)."""
+    W3 = (3 * L - 1) // 64 + 1
+    rng = np.random.default_rng(L)
+    Lb = po.lib()
+    Lb.orc_enc_hamming3.restype = C.c_int
+    Lb.orc_enc_hamming3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    ref.ref_mask_hamming_bpb.restype = C.c_int
+    ref.ref_mask_hamming_bpb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    for _ in range(300):
+        a = rng.integers(0, 2**63, W3, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, W3, dtype=np.uint64)
+        b = rng.integers(0, 2**63, W3, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, W3, dtype=np.uint64)
+        ln = int(rng.integers(1, L + 1))
+        want = ref.ref_mask_hamming_bpb(a.ctypes.data, b.ctypes.data, W3, L, 0, L - ln, 3)
+        got = Lb.orc_enc_hamming3(a.ctypes.data, b.ctypes.data, W3, ln)
+        assert got == want
