@@ -121,11 +121,6 @@ __global__ void k_head2(const uint32_t *__restrict__ fstart, uint32_t M, uint32_
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < M) h2[i] = ((i - fstart[i]) % LIST_LIMIT == 0) ? 1u : 0u;
 }
-__global__ void k_cstart(const uint32_t *__restrict__ h2, const uint32_t *__restrict__ cid1, uint32_t M,
-                         uint32_t *__restrict__ cstart) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < M && h2[i]) cstart[cid1[i] - 1] = i;
-}
 __global__ void k_fill_ll(long long *p, uint32_t n, long long v) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -170,68 +165,98 @@ __global__ void k_reflen(const long long *__restrict__ cmin, const long long *__
   atomicMax(maxR, r);
 }
 __global__ void k_keys1(const long long *__restrict__ pos, const uint32_t *__restrict__ cid1,
-                        const long long *__restrict__ cmin, uint32_t M, int pb, uint64_t *__restrict__ keys,
-                        uint32_t *__restrict__ vals) {
+                        const long long *__restrict__ cmin, const uint64_t *__restrict__ ref_off, uint32_t M,
+                        uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
   const uint32_t c = cid1[i] - 1;
-  keys[i] = ((uint64_t)c << pb) | (uint64_t)(pos[i] - cmin[c]);
+  // contigs are laid out one after the other, so sorting by (contig, pos - min pos) is sorting by
+  // the read's first base in the concatenated consensus
+  keys[i] = ref_off[c] + (uint64_t)(pos[i] - cmin[c]);
   vals[i] = i;
 }
-// sorted record: x = pos relative to the contig, y = read id | len << 32 | rc << 48 | singleton << 49
+// sorted record: x = first base in the concatenated consensus, y = read id | len << 32 | rc << 48 | singleton << 49
 __global__ void k_srec(const uint64_t *__restrict__ kout, const uint32_t *__restrict__ vout,
                        const uint32_t *__restrict__ order, const char *__restrict__ rc,
-                       const uint16_t *__restrict__ rlen, uint32_t M, int pb, ulonglong2 *__restrict__ srec) {
+                       const uint16_t *__restrict__ rlen, uint32_t M, ulonglong2 *__restrict__ srec) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= M) return;
   const uint32_t i = vout[k];
   ulonglong2 r;
-  r.x = kout[k] & lowmask(pb);
+  r.x = kout[k];
   r.y = (uint64_t)order[i] | ((uint64_t)rlen[i] << 32) | ((uint64_t)(rc[i] == 'r') << 48);
   srec[k] = r;
 }
 
 // ------------------------------------------------------------------ consensus (buildcontig, encoder.cpp:32-74)
-__global__ __launch_bounds__(256) void k_consensus(const ulonglong2 *__restrict__ srec,
-                                                   const uint32_t *__restrict__ cstart,
-                                                   const uint64_t *__restrict__ ref_off, uint32_t C, uint64_t seq_len,
+// One block per tile of CONS_TILE consensus bases.  The records overlapping the tile are a contiguous
+// range of the sorted records (found by a 256-ary block search); every thread walks whole reads and
+// votes with LDS atomics; then one thread per base takes the arg max.
+constexpr int CONS_TILE = 2048;
+template <bool GE>  // first k in [0, M) with srec[k].x + add > bound (GE = false) or >= bound (GE = true)
+__device__ __forceinline__ uint32_t block_search(const ulonglong2 *__restrict__ srec, uint32_t M, uint64_t add,
+                                                 uint64_t bound) {
+  uint32_t lo = 0, hi = M;  // answer in [lo, hi]
+  while (hi - lo > 256) {
+    const uint64_t span = hi - lo;
+    const uint32_t idx = lo + (uint32_t)(span * (threadIdx.x + 1) / 257);
+    const uint64_t v = srec[idx].x + add;
+    const bool pred = GE ? v >= bound : v > bound;
+    const int nfalse = __syncthreads_count(!pred);
+    const uint32_t nlo = nfalse ? lo + (uint32_t)(span * (uint32_t)nfalse / 257) + 1 : lo;
+    const uint32_t nhi = nfalse < 256 ? lo + (uint32_t)(span * (uint32_t)(nfalse + 1) / 257) : hi;
+    lo = nlo;
+    hi = nhi;
+  }
+  const uint32_t idx = lo + threadIdx.x;
+  bool pred = true;
+  if (idx < hi) {
+    const uint64_t v = srec[idx].x + add;
+    pred = GE ? v >= bound : v > bound;
+  }
+  const int nfalse = __syncthreads_count(!pred);
+  return lo + (uint32_t)nfalse;
+}
+__global__ __launch_bounds__(256) void k_consensus(const ulonglong2 *__restrict__ srec, uint32_t M, uint64_t seq_len,
                                                    const uint64_t *__restrict__ reads, int S, int Lmax,
                                                    uint8_t *__restrict__ refc) {
-  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= seq_len) return;
-  const uint32_t c = find_contig(ref_off, C, g);
-  const uint64_t p = g - ref_off[c];
-  const uint32_t lo0 = cstart[c], hi0 = cstart[c + 1];
-  // a = first record with relpos + Lmax > p, b = first record with relpos > p
-  uint32_t a = lo0, b = hi0;
-  {
-    uint32_t lo = lo0, hi = hi0;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (srec[mid].x + (uint64_t)Lmax > p) hi = mid; else lo = mid + 1; }
-    a = lo;
-    hi = hi0;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (srec[mid].x > p) hi = mid; else lo = mid + 1; }
-    b = lo;
-  }
-  int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;  // A, C, G, T (chartolong, encoder.cpp:36-45)
-  for (uint32_t k = a; k < b; k++) {
+  __shared__ uint32_t cnt[CONS_TILE * 4];  // [base][A, C, G, T] (chartolong, encoder.cpp:36-45)
+  const uint64_t g0 = (uint64_t)blockIdx.x * CONS_TILE;
+  for (int i = threadIdx.x; i < CONS_TILE * 4; i += 256) cnt[i] = 0;
+  const uint32_t a = block_search<false>(srec, M, (uint64_t)Lmax, g0);        // start + Lmax > g0
+  const uint32_t b = block_search<true>(srec, M, 0, g0 + CONS_TILE);          // start >= end of the tile
+  __syncthreads();
+  for (uint32_t k = a + threadIdx.x; k < b; k += 256) {
     const ulonglong2 r = srec[k];
     const int len = (int)((r.y >> 32) & 0xffff);
-    const uint64_t j64 = p - r.x;
-    if (j64 >= (uint64_t)len) continue;
-    const int j = (int)j64;
     const bool rc = (r.y >> 48) & 1;
-    const int jj = rc ? len - 1 - j : j;
-    int code = (int)((reads[(size_t)(uint32_t)r.y * S + (jj >> 5)] >> (2 * (jj & 31))) & 3);
-    if (rc) code = 3 - code;
-    // SPRING code A0 G1 C2 T3
-    cnt0 += code == 0; cnt2 += code == 1; cnt1 += code == 2; cnt3 += code == 3;
+    const uint64_t *rd = reads + (size_t)(uint32_t)r.y * S;
+    const int jlo = r.x < g0 ? (int)(g0 - r.x) : 0;
+    const long long jend = (long long)(g0 + CONS_TILE - r.x);
+    const int jhi = jend < len ? (int)jend : len;
+    int cur = -1;
+    uint64_t w = 0;
+    for (int j = jlo; j < jhi; j++) {
+      const int jj = rc ? len - 1 - j : j;
+      if ((jj >> 5) != cur) { cur = jj >> 5; w = rd[cur]; }
+      int code = (int)((w >> (2 * (jj & 31))) & 3);
+      if (rc) code = 3 - code;
+      const int nat = code == 1 ? 2 : code == 2 ? 1 : code;  // SPRING code A0 G1 C2 T3 -> A C G T
+      atomicAdd(&cnt[(int)(r.x + j - g0) * 4 + nat], 1u);
+    }
   }
-  int mx = 0, ind = 0;  // strict >, order A C G T; nothing covering the base -> 'A' (encoder.cpp:62-72)
-  if (cnt0 > mx) { mx = cnt0; ind = 0; }
-  if (cnt1 > mx) { mx = cnt1; ind = 1; }
-  if (cnt2 > mx) { mx = cnt2; ind = 2; }
-  if (cnt3 > mx) { mx = cnt3; ind = 3; }
-  refc[g] = (uint8_t)(ind == 1 ? 2 : ind == 2 ? 1 : ind);  // back to the SPRING code
+  __syncthreads();
+  for (int p = threadIdx.x; p < CONS_TILE; p += 256) {
+    if (g0 + p >= seq_len) break;
+    const uint4 c = *(const uint4 *)&cnt[p * 4];
+    uint32_t mx = 0;
+    int ind = 0;  // strict >, order A C G T; nothing covering the base -> 'A' (encoder.cpp:62-72)
+    if (c.x > mx) { mx = c.x; ind = 0; }
+    if (c.y > mx) { mx = c.y; ind = 1; }
+    if (c.z > mx) { mx = c.z; ind = 2; }
+    if (c.w > mx) { mx = c.w; ind = 3; }
+    refc[g0 + p] = (uint8_t)(ind == 1 ? 2 : ind == 2 ? 1 : ind);  // back to the SPRING code
+  }
 }
 __global__ void k_pack_ref(const uint8_t *__restrict__ refc, uint64_t seq_len, uint64_t *__restrict__ refbits,
                            uint64_t nwords) {
@@ -426,33 +451,29 @@ __global__ void k_gather_aligned(const unsigned long long *__restrict__ T, const
   Pk[slot[j]] = T[q];
   qv[slot[j]] = q;
 }
-__global__ void k_single_rec(const uint64_t *__restrict__ Pk, const uint32_t *__restrict__ qv, uint32_t A,
-                             const uint64_t *__restrict__ ref_off, uint32_t C, int Lmax,
-                             const uint16_t *__restrict__ slen, int pb, uint64_t *__restrict__ keys,
+__global__ void k_single_rec(const uint64_t *__restrict__ Pk, const uint32_t *__restrict__ qv, uint32_t A, int Lmax,
+                             const uint16_t *__restrict__ slen, uint64_t *__restrict__ keys,
                              ulonglong2 *__restrict__ frec) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A) return;
   const uint64_t P = Pk[j], g = P >> 2;
   const int rev = (int)((P >> 1) & 1);
-  const uint32_t q = qv[j], c = find_contig(ref_off, C, g);
-  const uint64_t p = g - ref_off[c];
+  const uint32_t q = qv[j];
   const int len = slen[q];
-  const uint64_t relpos = rev ? p + Lmax - len : p;  // encoder.h:309-311
-  keys[j] = ((uint64_t)c << pb) | relpos;
+  const uint64_t gstart = rev ? g + Lmax - len : g;  // pos = j (+ max_readlen - len when reversed), encoder.h:309-311
+  keys[j] = gstart;
   ulonglong2 r;
-  r.x = relpos;
+  r.x = gstart;
   r.y = (uint64_t)q | ((uint64_t)len << 32) | ((uint64_t)rev << 48) | (1ull << 49);
   frec[j] = r;
 }
 
 // ------------------------------------------------------------------ noise streams (writecontig, encoder.cpp:76-109)
 struct NoiseP {
-  const uint64_t *kfin;
   const uint32_t *vfin;
   const ulonglong2 *frec;
   uint64_t F;
-  int pb;
-  const uint64_t *ref_off, *refbits;
+  const uint64_t *refbits;
   const uint64_t *reads;
   int S, SM;
   const uint64_t *sread, *srev, *nmask, *nmask_r;
@@ -475,10 +496,8 @@ template <bool WRITE>
 __global__ __launch_bounds__(256) void k_noise(NoiseP N) {
   const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= N.F) return;
-  const uint64_t key = N.kfin[f];
   const ulonglong2 rec = N.frec[N.vfin[f]];
-  const uint32_t c = (uint32_t)(key >> N.pb);
-  const uint64_t gpos = N.ref_off[c] + rec.x;
+  const uint64_t gpos = rec.x;
   const uint32_t id = (uint32_t)rec.y;
   const int len = (int)((rec.y >> 32) & 0xffff);
   const bool rc = (rec.y >> 48) & 1, single = (rec.y >> 49) & 1;
@@ -743,8 +762,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   // ------------------------------------------------ contigs
   uint32_t C = 0;
   uint64_t seq_len = 0, maxR = 0;
-  int pb = 1;
-  DBuf cid1, cstart, cmin, cmax, Rl, ref_off, dtid, dmax;
+  DBuf cid1, cmin, cmax, Rl, ref_off, dtid, dmax;
   DALLOC(dtid, (size_t)(T + 1) * 8);
   HIPCHK(hipMemcpyAsync(dtid.p, V.tid_off, (size_t)(T + 1) * 8, hipMemcpyHostToDevice, st));
   if (M) {
@@ -761,11 +779,8 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
                                    rocprim::plus<uint32_t>(), st));
     HIPCHK(hipMemcpyAsync(&C, cid1.as<uint32_t>() + (M - 1), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    DALLOC(cstart, (size_t)(C + 1) * 4); DALLOC(cmin, (size_t)C * 8); DALLOC(cmax, (size_t)C * 8);
+    DALLOC(cmin, (size_t)C * 8); DALLOC(cmax, (size_t)C * 8);
     DALLOC(Rl, (size_t)(C + 2) * 4); DALLOC(ref_off, (size_t)(C + 2) * 8); DALLOC(dmax, 8);
-    hipLaunchKernelGGL(k_cstart, grid(M), dim3(256), 0, st, h2.as<uint32_t>(), cid1.as<uint32_t>(), M,
-                       cstart.as<uint32_t>());
-    HIPCHK(hipMemcpyAsync(cstart.as<uint32_t>() + C, &M, 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_fill_ll, grid(C), dim3(256), 0, st, cmin.as<long long>(), C, LLONG_MAX);
     hipLaunchKernelGGL(k_fill_ll, grid(C), dim3(256), 0, st, cmax.as<long long>(), C, LLONG_MIN);
     hipLaunchKernelGGL(k_minmax, grid(M), dim3(256), 0, st, V.f_pos, V.f_len, cid1.as<uint32_t>(), M,
@@ -779,8 +794,6 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
     HIPCHK(hipMemcpyAsync(&seq_len, ref_off.as<uint64_t>() + C, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (maxR > 0xffffffffull) return fail(SPRING_REORDER_E_ARG, "a contig consensus exceeds 2^32 bases");
-    pb = bits_for(maxR);
-    if (pb + bits_for(C) > 64) return fail(SPRING_REORDER_E_ARG, "contig count x contig length exceeds the 64-bit sort key");
   } else {
     DALLOC(ref_off, 16);
     HIPCHK(hipMemsetAsync(ref_off.p, 0, 16, st));
@@ -792,15 +805,15 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   DALLOC(kA, (FMAX ? FMAX : 1) * 8); DALLOC(kB, (FMAX ? FMAX : 1) * 8);
   DALLOC(vA, (FMAX ? FMAX : 1) * 4); DALLOC(vB, (FMAX ? FMAX : 1) * 4);
   DALLOC(frec, (FMAX ? FMAX : 1) * 16);
-  const int key_bits = pb + bits_for(C);
+  const int key_bits = bits_for(seq_len);
   if (M) {
-    hipLaunchKernelGGL(k_keys1, grid(M), dim3(256), 0, st, V.f_pos, cid1.as<uint32_t>(), cmin.as<long long>(), M, pb,
-                       kA.as<uint64_t>(), vA.as<uint32_t>());
+    hipLaunchKernelGGL(k_keys1, grid(M), dim3(256), 0, st, V.f_pos, cid1.as<uint32_t>(), cmin.as<long long>(),
+                       ref_off.as<uint64_t>(), M, kA.as<uint64_t>(), vA.as<uint32_t>());
     t2 = tb;
     HIPCHK(sr::sort_pairs(st, tmp.p, t2, kA.as<uint64_t>(), kB.as<uint64_t>(), vA.as<uint32_t>(), vB.as<uint32_t>(), M,
                           (unsigned)key_bits));
     hipLaunchKernelGGL(k_srec, grid(M), dim3(256), 0, st, kB.as<uint64_t>(), vB.as<uint32_t>(), V.f_order, V.f_rc,
-                       V.f_len, M, pb, frec.as<ulonglong2>());
+                       V.f_len, M, frec.as<ulonglong2>());
   }
   HIPCHK(hipEventRecord(ev[2], st));
 
@@ -811,8 +824,8 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   DALLOC(refbits, (nwords + 40) * 8);
   HIPCHK(hipMemsetAsync(refbits.p, 0, (nwords + 40) * 8, st));
   if (seq_len) {
-    hipLaunchKernelGGL(k_consensus, grid(seq_len), dim3(256), 0, st, frec.as<ulonglong2>(), cstart.as<uint32_t>(),
-                       ref_off.as<uint64_t>(), C, seq_len, V.reads, S, Lmax, ctx->refc.as<uint8_t>());
+    hipLaunchKernelGGL(k_consensus, dim3((unsigned)((seq_len + CONS_TILE - 1) / CONS_TILE)), dim3(256), 0, st,
+                       frec.as<ulonglong2>(), M, seq_len, V.reads, S, Lmax, ctx->refc.as<uint8_t>());
     hipLaunchKernelGGL(k_pack_ref, grid(nwords), dim3(256), 0, st, ctx->refc.as<uint8_t>(), seq_len,
                        refbits.as<uint64_t>(), nwords);
   }
@@ -952,14 +965,12 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
       t2 = tb;
       HIPCHK(sr::sort_pairs(st, tmp.p, t2, Pk.as<uint64_t>(), Pks.as<uint64_t>(), qv.as<uint32_t>(), qvs.as<uint32_t>(),
                             A_cnt, (unsigned)std::min(64, bits_for(seq_len) + 2)));
-      hipLaunchKernelGGL(k_single_rec, grid(A_cnt), dim3(256), 0, st, Pks.as<uint64_t>(), qvs.as<uint32_t>(), A_cnt,
-                         ref_off.as<uint64_t>(), C, Lmax, slen.as<uint16_t>(), pb, kB.as<uint64_t>() + M,
-                         frec.as<ulonglong2>() + M);
+      hipLaunchKernelGGL(k_single_rec, grid(A_cnt), dim3(256), 0, st, Pks.as<uint64_t>(), qvs.as<uint32_t>(), A_cnt, Lmax,
+                         slen.as<uint16_t>(), kB.as<uint64_t>() + M, frec.as<ulonglong2>() + M);
       HIPCHK(hipStreamSynchronize(st));
     }
   }
   const uint64_t F = (uint64_t)M + A_cnt;
-  const uint64_t *kfin = kB.as<uint64_t>();
   const uint32_t *vfin = vB.as<uint32_t>();
   if (F) {
     hipLaunchKernelGGL(k_iota, grid(F), dim3(256), 0, st, vB.as<uint32_t>(), F);
@@ -967,7 +978,6 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
       t2 = tb;
       HIPCHK(sr::sort_pairs(st, tmp.p, t2, kB.as<uint64_t>(), kA.as<uint64_t>(), vB.as<uint32_t>(), vA.as<uint32_t>(), F,
                             (unsigned)key_bits));
-      kfin = kA.as<uint64_t>();
       vfin = vA.as<uint32_t>();
     }
   }
@@ -1004,8 +1014,8 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   DALLOC(ctx->pos, (size_t)(F ? F : 1) * 8); DALLOC(ctx->rc, (size_t)(F ? F : 1));
   DALLOC(ctx->order, (size_t)(I.n_total ? I.n_total : 1) * 4); DALLOC(ctx->rlen, (size_t)(I.n_total ? I.n_total : 1) * 2);
   NoiseP N;
-  N.kfin = kfin; N.vfin = vfin; N.frec = frec.as<ulonglong2>(); N.F = F; N.pb = pb;
-  N.ref_off = ref_off.as<uint64_t>(); N.refbits = refbits.as<uint64_t>(); N.reads = V.reads; N.S = S; N.SM = SM;
+  N.vfin = vfin; N.frec = frec.as<ulonglong2>(); N.F = F;
+  N.refbits = refbits.as<uint64_t>(); N.reads = V.reads; N.S = S; N.SM = SM;
   N.sread = sread.as<uint64_t>(); N.srev = srev.as<uint64_t>(); N.nmask = nmask.as<uint64_t>();
   N.nmask_r = nmask_r.as<uint64_t>(); N.cumN = cumN.as<uint32_t>(); N.order_sc = order_sc.as<uint32_t>();
   N.nm = nm.as<uint32_t>(); N.noff = noff.as<uint64_t>(); N.noise = nullptr; N.noisepos = nullptr;
