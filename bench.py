@@ -132,6 +132,28 @@ def main():
             "algorithmic_bytes_per_read": round(alg / n, 1),
             "work": {"probes": sr["probes"], "keyok": sr["keyok"], "cands": sr["cands"], "hits": sr["hits"]},
         }
+    if rank == 0 and world == 1 and not a.no_roofline:
+        # row f2: the encoder stage chained on the same workload, streams never leave HBM.
+        # Reported beside the headline, never part of `value`.
+        try:
+            from spring_amd.encoder import EncoderStage
+            s = spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=a.chains, num_thr=a.num_thr))
+            s.load_dna_device(buf.data_ptr(), nb, n, L, True)
+            s.run()
+            with EncoderStage(dev) as enc:
+                enc.encode(s)          # first call pays the allocations
+                info = enc.encode(s)
+            s.close()
+            names = ("contigs", "sort", "consensus", "pool_dict", "align", "merge", "noise", "tail")
+            out["encoder_stage"] = {
+                "ms_device": round(info["ms_device"], 2), "Mreads_per_s": round(n / info["ms_device"] / 1e3, 1),
+                "phases_ms": {k: round(v, 2) for k, v in zip(names, info["ms_phase"])},
+                "contigs": info["num_contigs"], "consensus_bases": info["seq_len"],
+                "singletons_aligned": info["matched_s"], "substitutions": info["n_noisepos"],
+                "align_passes": info["align_passes"],
+            }
+        except Exception as e:  # the widened row must never break the headline line
+            out["encoder_stage"] = {"error": repr(e)}
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         # CPU baseline on the GPU box's host cores: the C port of the reference algorithm
         # (oracle/reorder_oracle.c).  Multi-thread leg = free-running OpenMP chains like the

@@ -70,6 +70,21 @@ int spring_encoder_download(spring_encoder_ctx *ctx, char *seq, uint64_t *seq_le
  * bits) concatenated tid-major into packed, and the len%4 tail characters into tail[4*tid..]. */
 int spring_encoder_download_seq_packed(spring_encoder_ctx *ctx, uint8_t *packed, char *tail);
 
+int spring_encoder_get_info(spring_encoder_ctx *ctx, spring_encoder_info *info);
+
+/* File contract of the two stages back to back (spring::call_reorder followed by spring::call_encoder,
+ * reference src/spring.cpp:150-160): reads temp_dir/input_clean_{1,2}.dna, input_N.dna and
+ * read_order_N.bin, runs the reorder chains and the encoder with everything resident in HBM (the
+ * per-tid intermediate files of reorder.h:355-368 are never written), and leaves the encoder's
+ * outputs in temp_dir: read_pos.bin, read_noise.txt, read_noisepos.bin, read_order.bin, read_rev.txt,
+ * read_lengths.bin, read_unaligned.txt, read_unaligned.txt.count (encoder.h:365-494) and, per tid,
+ * read_seq.bin.<tid>.tmp (2-bit packed) + read_seq.bin.<tid>.tail -- the state of
+ * pack_compress_seq (encoder.cpp:111-156) just before its BSC_compress call, which stays with the
+ * caller.  Inputs are removed like the reference does.  num_reads = clean + N reads (cp.num_reads). */
+int spring_reorder_encode_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, int32_t paired_end,
+                              uint32_t num_reads_clean_1, uint32_t num_reads_clean_2, uint32_t num_reads,
+                              const spring_reorder_opts *opts, spring_encoder_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -662,7 +662,7 @@ int spring_encoder_create(int device, spring_encoder_ctx **out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(SPRING_REORDER_E_HIP, "no HIP device available (the encoder stage has no CPU fallback)");
-  if (device < 0) device = 0;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;  // like spring_reorder_create
   if (device >= ndev) return fail(SPRING_REORDER_E_ARG, "device %d out of range", device);
   spring_encoder_ctx *c = new spring_encoder_ctx();
   c->dev = device;
@@ -1069,6 +1069,13 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   I.num_contigs = C;
   ctx->have = true;
   if (info_out) *info_out = I;
+  return 0;
+}
+
+int spring_encoder_get_info(spring_encoder_ctx *ctx, spring_encoder_info *info) {
+  if (!ctx || !info) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  if (!ctx->have) return fail(SPRING_REORDER_E_STATE, "nothing encoded yet");
+  *info = ctx->info;
   return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "call_reorder.h"
+#include "spring_encoder.h"
 #include "spring_reorder.h"
 
 namespace sr {
@@ -181,6 +182,96 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
   const uint32_t numreads_s = (uint32_t)ns;
   if ((r = write_raw(base + "/temp.dna.singleton.count", &numreads_s, 4))) return r;  // reorder.h:699-701
   printf("Reordering done, %llu were unmatched\n", (unsigned long long)st.unmatched);  // reorder.h:633-635
+  return 0;
+}
+
+namespace {
+struct EncGuard {
+  spring_encoder_ctx *c = nullptr;
+  ~EncGuard() { spring_encoder_destroy(c); }
+};
+bool file_exists(const std::string &p) {
+  FILE *f = fopen(p.c_str(), "rb");
+  if (f) fclose(f);
+  return f != nullptr;
+}
+}  // namespace
+
+extern "C" int spring_reorder_encode_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, int32_t paired_end,
+                                         uint32_t n0, uint32_t n1, uint32_t num_reads, const spring_reorder_opts *opts,
+                                         spring_encoder_info *info_out) {
+  if (!temp_dir) return fail(SPRING_REORDER_E_ARG, "temp_dir is NULL");
+  if (num_thr <= 0) return fail(SPRING_REORDER_E_ARG, "num_thr must be >= 1");
+  spring_reorder_opts o;
+  if (opts) o = *opts; else spring_reorder_default_opts(&o);
+  o.num_thr = num_thr;
+  const std::string base(temp_dir);
+  const std::string in1 = base + "/input_clean_1.dna", in2 = base + "/input_clean_2.dna";
+  const std::string inN = base + "/input_N.dna", inON = base + "/read_order_N.bin";  // encoder.h:587,:583
+  const uint64_t ntot = (uint64_t)n0 + (paired_end ? n1 : 0);
+  if (ntot > 4294967290ull || num_reads < ntot) return fail(SPRING_REORDER_E_ARG, "bad read counts");
+  const uint32_t n = (uint32_t)ntot, nN = num_reads - n;  // getDataParams, encoder.cpp:158-175
+
+  std::vector<uint8_t> dna, dnaN, ordN;
+  int r = read_file(in1, dna);
+  if (r) return r;
+  if (paired_end && (r = read_file(in2, dna))) return r;
+  if (nN) {
+    if ((r = read_file(inN, dnaN))) return r;
+    if ((r = read_file(inON, ordN))) return r;
+    if (ordN.size() < (size_t)nN * 4) return fail(SPRING_REORDER_E_IO, "%s is too short", inON.c_str());
+  }
+  CtxGuard g;
+  EncGuard e;
+  if ((r = spring_reorder_create(&g.c, &o))) return r;
+  if ((r = spring_reorder_load_dna(g.c, dna.data(), dna.size(), n, max_readlen))) return r;
+  std::vector<uint8_t>().swap(dna);
+  if ((r = spring_reorder_build_dict(g.c))) return r;
+  if ((r = spring_reorder_run_chains(g.c))) return r;
+  if ((r = spring_reorder_finalize(g.c))) return r;
+  spring_reorder_stats st;
+  if ((r = spring_reorder_get_stats(g.c, &st))) return r;
+  printf("Reordering done, %llu were unmatched\n", (unsigned long long)st.unmatched);  // reorder.h:633-635
+  if ((r = spring_encoder_create(o.device, &e.c))) return r;
+  spring_encoder_info I;
+  if ((r = spring_encoder_encode_reorder(e.c, g.c, dnaN.data(), dnaN.size(), (const uint32_t *)ordN.data(), nN, &I)))
+    return r;
+
+  std::vector<uint64_t> seq_len_tid(num_thr), pos(I.n_aligned ? I.n_aligned : 1);
+  std::vector<char> noise(I.noise_bytes ? I.noise_bytes : 1), rc(I.n_aligned ? I.n_aligned : 1);
+  std::vector<uint16_t> noisepos(I.n_noisepos ? I.n_noisepos : 1), rlen(I.n_total ? I.n_total : 1);
+  std::vector<uint32_t> order(I.n_total ? I.n_total : 1);
+  std::vector<uint8_t> un(I.unaligned_bytes ? I.unaligned_bytes : 1);
+  if ((r = spring_encoder_download(e.c, nullptr, seq_len_tid.data(), pos.data(), noise.data(), noisepos.data(),
+                                   order.data(), rlen.data(), rc.data(), un.data())))
+    return r;
+  uint64_t packed_total = 0;
+  for (int t = 0; t < num_thr; t++) packed_total += seq_len_tid[t] / 4;
+  std::vector<uint8_t> packed(packed_total ? packed_total : 1);
+  std::vector<char> tail((size_t)num_thr * 4);
+  if ((r = spring_encoder_download_seq_packed(e.c, packed.data(), tail.data()))) return r;
+  uint64_t po = 0;
+  for (int t = 0; t < num_thr; t++) {  // pack_compress_seq up to the BSC call (encoder.cpp:111-150)
+    const std::string ts = "." + std::to_string(t);
+    if ((r = write_raw(base + "/read_seq.bin" + ts + ".tmp", packed.data() + po, seq_len_tid[t] / 4))) return r;
+    if ((r = write_raw(base + "/read_seq.bin" + ts + ".tail", tail.data() + 4 * t, seq_len_tid[t] % 4))) return r;
+    po += seq_len_tid[t] / 4;
+  }
+  if ((r = write_raw(base + "/read_pos.bin", pos.data(), I.n_aligned * 8))) return r;          // encoder.h:465-480
+  if ((r = write_raw(base + "/read_noise.txt", noise.data(), I.noise_bytes))) return r;         // encoder.h:365-395
+  if ((r = write_raw(base + "/read_noisepos.bin", noisepos.data(), I.n_noisepos * 2))) return r;
+  if ((r = write_raw(base + "/read_order.bin", order.data(), I.n_total * 4))) return r;         // + unaligned, :425-445
+  if ((r = write_raw(base + "/read_rev.txt", rc.data(), I.n_aligned))) return r;
+  if ((r = write_raw(base + "/read_lengths.bin", rlen.data(), I.n_total * 2))) return r;
+  if ((r = write_raw(base + "/read_unaligned.txt", un.data(), I.unaligned_bytes))) return r;
+  if ((r = write_raw(base + "/read_unaligned.txt.count", &I.len_unaligned, 8))) return r;      // encoder.h:457-460
+  remove(in1.c_str());
+  if (paired_end) remove(in2.c_str());
+  if (file_exists(inN)) remove(inN.c_str());    // encoder.h:601
+  if (file_exists(inON)) remove(inON.c_str());  // encoder.cpp:218
+  printf("Encoding done:\n%u singleton reads were aligned\n%u reads with N were aligned\n", I.matched_s,
+         I.matched_N);  // encoder.h:489-491
+  if (info_out) *info_out = I;
   return 0;
 }
 

@@ -1137,7 +1137,7 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
 }
 void launch_mg_post_exchange(hipStream_t st, const DevParams &P) {
   const uint32_t nw = (P.Ktot + 31) / 32;
-  hipMemsetAsync(P.alive_round, 0, 4, st);
+  (void)hipMemsetAsync(P.alive_round, 0, 4, st);
   hipLaunchKernelGGL(k_mg_bits, GRID1(nw, 256), dim3(256), 0, st, P);
   hipLaunchKernelGGL(k_mg_seed, dim3((P.Ktot + 3) / 4), dim3(256), 0, st, P);
   hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);

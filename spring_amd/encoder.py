@@ -17,7 +17,7 @@ class EncoderStage:
     """encode(): consensus + singleton alignment + noise streams of the contigs a finalized
     ReorderStage holds in HBM.  Streams are fetched with streams()."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = -1):
         self._L = _lib.lib()
         self._h = C.c_void_p()
         _chk(self._L.spring_encoder_create(device, C.byref(self._h)))

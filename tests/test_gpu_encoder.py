@@ -104,3 +104,49 @@ def test_encoder_100k_many_chains():
             got = enc.streams()
     want = po.encode(read, ln, L, streams, num_thr=4)
     same_encoding(got, want, "100k")
+
+
+def test_reorder_encode_run_file_contract(tmp_path):
+    """spring_reorder_encode_run: input_clean_1.dna + input_N.dna + read_order_N.bin in, the encoder's files out."""
+    import ctypes as C
+    import os
+
+    import spring_amd
+    from spring_amd import _lib
+    name, T, K = "syn5k_150", 3, 16
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    Nreads = make_N_reads(read_strings(read, ln), 300, 4)
+    dnaN = po.pack_dnaN(Nreads)
+    order_N = interleave_order_N(n, len(Nreads), 12)
+    d = str(tmp_path)
+    open(os.path.join(d, "input_clean_1.dna"), "wb").write(dna)
+    open(os.path.join(d, "input_N.dna"), "wb").write(dnaN)
+    open(os.path.join(d, "read_order_N.bin"), "wb").write(order_N.tobytes())
+    o = spring_amd.ReorderOpts(num_chains=K, num_thr=T).to_c()
+    info = _lib.EncoderInfo()
+    L_ = _lib.lib()
+    rc = L_.spring_reorder_encode_run(d.encode(), L, T, 0, n, 0, n + len(Nreads), C.byref(o), C.byref(info))
+    assert rc == 0, L_.spring_reorder_last_error()
+    want = po.encode(read, ln, L, po.reorder_rounds(read, ln, L, K, T), num_thr=T, dnaN=dnaN, order_N=order_N)
+    rd = lambda f: open(os.path.join(d, f), "rb").read()  # noqa: E731
+    assert rd("read_pos.bin") == want["pos"].tobytes()
+    assert rd("read_noise.txt") == want["noise"]
+    assert rd("read_noisepos.bin") == want["noisepos"].tobytes()
+    assert rd("read_order.bin") == want["order"].tobytes()
+    assert rd("read_rev.txt") == want["rc"].tobytes()
+    assert rd("read_lengths.bin") == want["rlen"].tobytes()
+    assert rd("read_unaligned.txt") == want["unaligned"]
+    assert int.from_bytes(rd("read_unaligned.txt.count"), "little") == want["len_unaligned"]
+    Lo = po.lib()
+    Lo.orc_pack_seq.restype = C.c_uint64
+    Lo.orc_pack_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    off = 0
+    for t, sl in enumerate(int(x) for x in want["seq_len_tid"]):
+        buf, tail = np.zeros(max(sl // 4, 1), np.uint8), np.zeros(4, np.uint8)
+        nb = Lo.orc_pack_seq(want["seq"][off:off + sl], sl, buf.ctypes.data, tail.ctypes.data)
+        assert rd("read_seq.bin.%d.tmp" % t) == buf[:nb].tobytes()
+        assert rd("read_seq.bin.%d.tail" % t) == tail[:sl % 4].tobytes()
+        off += sl
+    for gone in ("input_clean_1.dna", "input_N.dna", "read_order_N.bin"):
+        assert not os.path.exists(os.path.join(d, gone))

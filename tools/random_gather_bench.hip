@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <vector>
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x;
 }
@@ -22,7 +23,9 @@ __global__ __launch_bounds__(256) void gather(const uint64_t* __restrict__ tab, 
   if (acc == 0x1234567) out[0] = acc;
 }
 int main(int argc, char** argv) {
-  for (double gb : {0.25, 1.0, 4.0, 8.0, 16.0}) {
+  std::vector<double> sizes = {0.25, 1.0, 4.0, 8.0, 16.0};
+  if (argc > 1) { sizes.clear(); for (int i = 1; i < argc; i++) sizes.push_back(atof(argv[i])); }  // GiB
+  for (double gb : sizes) {
     uint64_t nb = 1; while (nb * 64 * 2 <= (uint64_t)(gb * (1ull << 30))) nb <<= 1;
     uint64_t* tab; uint64_t* out;
     if (hipMalloc(&tab, nb * 64) != hipSuccess) { printf("alloc fail %.2f\n", gb); continue; }
