@@ -84,3 +84,31 @@ def test_fuzz_single_pool_virtual_ranks(block):
             vp.close()
         for k in KEYS:
             assert np.array_equal(got[k], want[k]), ("seed", seed, "G", G, "K", K, k)
+
+
+@pytest.mark.parametrize("block", range(max(_BLOCKS // 2, 1)))
+def test_fuzz_encoder_equals_oracle(block):
+    """Row f2: reorder on the GPU, then the encoder stage on the GPU vs the encoder oracle on the same streams,
+    with random N reads (sometimes thousands of near-copies -> bins deeper than MAX_SEARCH_ENCODER)."""
+    import spring_amd
+    from helpers import interleave_order_N, make_N_reads, read_strings, same_encoding
+    from spring_amd.encoder import EncoderStage
+    for seed in range(9000 + 12 * block, 9000 + 12 * (block + 1)):
+        dna, n, L, K, T = _random_case(seed)
+        rng = np.random.default_rng(seed + 1)
+        read, ln = po.load_dna(dna, n, L)
+        nN = int(rng.choice([0, 0, 5, 60, 400]))
+        deep = int(rng.choice([0, 0, 0, 1500, 2600])) if L > 50 else 0
+        Nreads = make_N_reads(read_strings(read, ln), nN, seed, deep=deep) if (nN or deep) else []
+        dnaN = po.pack_dnaN(Nreads)
+        order_N = interleave_order_N(n, len(Nreads), seed + 2)
+        with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=T)) as st:
+            st.load_dna(dna, n, L)
+            st.run()
+            streams = st.streams()
+            with EncoderStage() as enc:
+                info = enc.encode(st, dnaN, order_N)
+                got = enc.streams()
+        want = po.encode(read, ln, L, streams, num_thr=T, dnaN=dnaN, order_N=order_N)
+        same_encoding(got, want, ("seed", seed, "n", n, "L", L, "K", K, "T", T, "nN", len(Nreads), "passes",
+                                  info["align_passes"]))
