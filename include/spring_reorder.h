@@ -183,11 +183,15 @@ int spring_reorder_download_reads(spring_reorder_ctx *ctx, uint64_t *limbs /* n*
  *                            (m entries: the per-tid order streams and the singleton order) is shifted by the
  *                            number of N reads that precede that clean read in the original file;
  *                            order_N = original positions of the nN reads with N, n_clean = clean reads.
+ *   spring_order_pe_encode : pe_encode (pe_encode.cpp:24-84): read_order.bin of a paired-end run -> position
+ *                            of every reordered read in the decompressed files: file-1 reads keep their
+ *                            reordered rank among file-1 reads, a file-2 read gets its mate's rank + n/2.
  */
 int spring_order_invert_se(const uint32_t *order, uint32_t n, uint32_t *order_array, double *kernel_ms);
 int spring_order_invert_pe(const uint32_t *order, uint32_t n, uint32_t *order_array, double *kernel_ms);
 int spring_order_correct(uint32_t *order, uint64_t m, const uint32_t *order_N, uint32_t nN, uint32_t n_clean,
                          double *kernel_ms);
+int spring_order_pe_encode(const uint32_t *order, uint32_t n, uint32_t *new_order, double *kernel_ms);
 
 /* ---------------------------------------------------------------------------
  * Synthetic input for bench.py / tests: uniform random

@@ -222,6 +222,14 @@ def generate_order_pe(order):
     return out[:len(order) // 2]
 
 
+def pe_encode(order):
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    out = np.zeros(max(len(order), 1), np.uint32)
+    lib().orc_pe_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib().orc_pe_encode(order.ctypes.data, len(order), out.ctypes.data)
+    return out[:len(order)]
+
+
 def correct_order(order, order_N, n_clean):
     order = np.array(order, dtype=np.uint32, copy=True)
     order_N = np.ascontiguousarray(order_N, dtype=np.uint32)

@@ -1194,6 +1194,27 @@ void orc_generate_order_pe(const uint32_t *order, uint32_t numreads, uint32_t *o
   for (uint32_t i = 0; i < numreads; i++)
     if (order[i] < numreads_by_2) order_array[order[i]] = pos_after_reordering++;
 }
+/* pe_encode (pe_encode.cpp:24-84), the three loops kept literal */
+void orc_pe_encode(const uint32_t *order, uint32_t numreads, uint32_t *order_array) {
+  uint32_t numreads_by_2 = numreads / 2;
+  uint32_t *inverse_order_array = (uint32_t *)malloc(sizeof(uint32_t) * (numreads ? numreads : 1));
+  for (uint32_t i = 0; i < numreads; i++) {
+    order_array[i] = order[i];
+    inverse_order_array[order[i]] = i;
+  }
+  uint32_t pos_in_file_1 = 0;
+  for (uint32_t i = 0; i < numreads; i++)
+    if (order_array[i] < numreads_by_2) order_array[i] = pos_in_file_1++;
+  for (uint32_t i = 0; i < numreads; i++)
+    if (order_array[i] >= numreads_by_2) {
+      uint32_t pos_in_original = order_array[i];
+      uint32_t pos_of_pair_in_original = pos_in_original - numreads_by_2;
+      uint32_t pos_of_pair_in_reordered = inverse_order_array[pos_of_pair_in_original];
+      uint32_t new_order_of_pair = order_array[pos_of_pair_in_reordered];
+      order_array[i] = new_order_of_pair + numreads_by_2;
+    }
+  free(inverse_order_array);
+}
 /* correct_order (encoder.cpp:177-222) on an in-memory index array */
 void orc_correct_order(uint32_t *order, uint64_t m, const uint32_t *order_N, uint32_t numreads_N, uint32_t n_clean) {
   uint32_t numreads_total = n_clean + numreads_N;

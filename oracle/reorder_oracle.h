@@ -109,4 +109,7 @@ void orc_dict_windows(int max_readlen, int start[2], int end[2]);
 #ifdef __cplusplus
 }
 #endif
+/* pe_encode (pe_encode.cpp:24-84) */
+void orc_pe_encode(const uint32_t *order, uint32_t numreads, uint32_t *order_array);
+
 #endif

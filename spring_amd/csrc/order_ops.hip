@@ -55,6 +55,15 @@ __global__ void k_apply_cum(uint32_t *__restrict__ order, uint64_t m, const uint
   if (i < m) order[i] += cum[order[i]];
 }
 
+// pe_encode (pe_encode.cpp:51-70): rank1 = exclusive scan of "is a file-1 read" over the reordered file
+__global__ void k_pe_encode(const uint32_t *__restrict__ order, const uint32_t *__restrict__ inv,
+                            const uint32_t *__restrict__ rank1, uint32_t n, uint32_t half, uint32_t *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t o = order[i];
+  out[i] = o < half ? rank1[i] : rank1[inv[o - half]] + half;
+}
+
 struct Buf {
   void *p = nullptr;
   ~Buf() { if (p) (void)hipFree(p); }
@@ -142,6 +151,34 @@ int spring_order_correct(uint32_t *order, uint64_t m, const uint32_t *order_N, u
   hipLaunchKernelGGL(k_apply_cum, grid(m), dim3(256), 0, nullptr, dord.as<uint32_t>(), m, dcum.as<uint32_t>());
   HIPCHK(hipEventRecord(ev.b, nullptr));
   HIPCHK(hipMemcpy(order, dord.p, m * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipEventSynchronize(ev.b));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
+  if (kernel_ms) *kernel_ms = ms;
+  return 0;
+}
+
+int spring_order_pe_encode(const uint32_t *order, uint32_t n, uint32_t *new_order, double *kernel_ms) {
+  if (n && (!order || !new_order)) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  if (kernel_ms) *kernel_ms = 0;
+  if (!n) return 0;
+  if (n & 1) return fail(SPRING_REORDER_E_ARG, "pe_encode needs an even number of reads (pairs)");
+  const uint32_t half = n / 2;
+  Buf din, dinv, dflag, drank, dout, dtmp; Ev ev;
+  HIPCHK(din.alloc((size_t)n * 4)); HIPCHK(dinv.alloc((size_t)n * 4)); HIPCHK(dflag.alloc((size_t)n * 4));
+  HIPCHK(drank.alloc((size_t)n * 4)); HIPCHK(dout.alloc((size_t)n * 4));
+  HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+  HIPCHK(hipMemcpy(din.p, order, (size_t)n * 4, hipMemcpyHostToDevice));
+  size_t tb = 0;
+  HIPCHK(sr::excl_scan_u32(nullptr, nullptr, tb, dflag.as<uint32_t>(), drank.as<uint32_t>(), n));
+  HIPCHK(dtmp.alloc(tb));
+  HIPCHK(hipEventRecord(ev.a, nullptr));
+  hipLaunchKernelGGL(k_invert_se, grid(n), dim3(256), 0, nullptr, din.as<uint32_t>(), n, dinv.as<uint32_t>());
+  hipLaunchKernelGGL(k_flag_lt, grid(n), dim3(256), 0, nullptr, din.as<uint32_t>(), n, half, dflag.as<uint32_t>());
+  HIPCHK(sr::excl_scan_u32(nullptr, dtmp.p, tb, dflag.as<uint32_t>(), drank.as<uint32_t>(), n));
+  hipLaunchKernelGGL(k_pe_encode, grid(n), dim3(256), 0, nullptr, din.as<uint32_t>(), dinv.as<uint32_t>(),
+                     drank.as<uint32_t>(), n, half, dout.as<uint32_t>());
+  HIPCHK(hipEventRecord(ev.b, nullptr));
+  HIPCHK(hipMemcpy(new_order, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipEventSynchronize(ev.b));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev.a, ev.b));
   if (kernel_ms) *kernel_ms = ms;

@@ -35,3 +35,12 @@ def correct_order(order, order_N, n_clean):
     _chk(_lib.lib().spring_order_correct(order.ctypes.data, len(order), order_N.ctypes.data if len(order_N) else None,
                                          len(order_N), n_clean, C.byref(ms)))
     return order, ms.value
+
+
+def pe_encode(order):
+    """pe_encode (pe_encode.cpp:24-84): reordered position -> position in the decompressed paired files."""
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    out = np.zeros(max(len(order), 1), np.uint32)
+    ms = C.c_double()
+    _chk(_lib.lib().spring_order_pe_encode(order.ctypes.data, len(order), out.ctypes.data, C.byref(ms)))
+    return out[:len(order)], ms.value

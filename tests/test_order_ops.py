@@ -22,10 +22,13 @@ def test_oracle_order_ops_known_answers():
     assert po.generate_order_pe(np.array([3, 0, 2, 1], np.uint32)).tolist() == [0, 1]
     # clean index -> original index: 0->0, 1->2, 2->3, 3->5, 4->6
     assert po.correct_order(order, np.array([1, 4], np.uint32), 5).tolist() == [5, 0, 6, 2, 3]
+    # pe_encode, 3 pairs (file-1 reads 0..2, mates 3..5): reordered file = [4, 1, 5, 0, 3, 2]
+    # file-1 ranks: read 1 -> 0, read 0 -> 1, read 2 -> 2; mates: 4 -> rank(1)+3 = 3, 5 -> rank(2)+3 = 5, 3 -> 4
+    assert po.pe_encode(np.array([4, 1, 5, 0, 3, 2], np.uint32)).tolist() == [3, 0, 5, 1, 4, 2]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,nN", [(1, 0), (2, 1), (1000, 37), (100_001, 5000), (3_000_000, 250_000)])
+@pytest.mark.parametrize("n,nN", [(1, 0), (2, 1), (1000, 37), (100_001, 5000), (100_002, 1), (3_000_000, 250_000)])
 def test_order_ops_bit_exact(n, nN):
     from spring_amd import order_ops as oo
     order, order_N = _data(n, nN, n + nN)
@@ -35,6 +38,12 @@ def test_order_ops_bit_exact(n, nN):
     assert np.array_equal(got, po.generate_order_pe(order))
     got, _ = oo.correct_order(order, order_N, n)
     assert np.array_equal(got, po.correct_order(order, order_N, n))
+    if n % 2 == 0:  # paired-end pools hold 2 x pairs reads
+        got, _ = oo.pe_encode(order)
+        assert np.array_equal(got, po.pe_encode(order))
+    else:
+        with pytest.raises(Exception):
+            oo.pe_encode(order)
 
 
 @pytest.mark.gpu
@@ -52,3 +61,11 @@ def test_order_ops_full_size_properties():
     corr, ms2 = oo.correct_order(ident, order_N, n)
     assert np.all(np.diff(corr.astype(np.int64)) >= 1) and not np.isin(corr[:: 997], order_N).any()
     assert int(corr[-1]) <= n + nN - 1
+    # pe_encode: a permutation in which mates end up exactly n/2 apart
+    new, ms3 = oo.pe_encode(order)
+    inv_new = np.empty(n, np.uint32)
+    inv_new[new] = np.arange(n, dtype=np.uint32)          # decompressed position -> reordered position
+    assert np.array_equal(np.sort(new), np.arange(n, dtype=np.uint32))
+    half = n // 2
+    first = order[inv_new[:half]]                          # original ids at decompressed positions 0 .. n/2-1
+    assert np.all(first < half) and np.array_equal(order[inv_new[half:2 * half]], first + half)
