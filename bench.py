@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+RANDOM_REQ_PEAK_G = 49.0  # measured: independent random <=32-byte reads, tables >= 4 GiB (tools/random_gather_bench.hip)
 
 
 def parse():
@@ -124,6 +125,18 @@ def main():
                 traffic = round(ks["fetch_bytes_per_launch"] + ks["write_bytes_per_launch"], 1)
         except Exception:
             traffic = None
+        # the same PMC figure read as a request rate: this kernel's loads are independent random 64-byte
+        # requests, for which the measured ceiling on this GPU is ~49 G requests/s
+        # (tools/random_gather_bench.hip, profiles/r01_pmc_calibration_random_gather.csv), not 8 TB/s / 64 B
+        req = None
+        try:
+            fetch = pmc["kernels"]["sr::k_search<false>"]["fetch_bytes_per_launch"] if traffic is not None else None
+            if fetch:
+                rate = fetch / 64.0 / (ms * 1e-3 / launches) / 1e9
+                req = {"achieved": round(rate, 2), "peak": RANDOM_REQ_PEAK_G, "unit": "G random 64-byte requests/s",
+                       "frac": round(rate / RANDOM_REQ_PEAK_G, 3)}
+        except Exception:
+            req = None
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -131,6 +144,7 @@ def main():
             "algorithmic_bytes_per_launch": round(alg / launches, 1),
             "algorithmic_bytes_per_read": round(alg / n, 1),
             "work": {"probes": sr["probes"], "keyok": sr["keyok"], "cands": sr["cands"], "hits": sr["hits"]},
+            "random_request_ceiling": req,
         }
     if rank == 0 and world == 1 and not a.no_roofline:
         # row f2: the encoder stage chained on the same workload, streams never leave HBM.

@@ -211,3 +211,30 @@ def same_encoding(a, b, what=""):
             assert np.array_equal(x, y), (what, k, len(x), len(y))
         else:
             assert x == y, (what, k)
+
+
+def decode_fixed_len(e, L):
+    """Vectorised decompress.cpp:236-266 for equal-length reads: -> uint8 [n_aligned, L] letters of the aligned
+    reads in their original orientation, row i belonging to read e["order"][i]."""
+    na = len(e["pos"])
+    seq = np.frombuffer(e["seq"], np.uint8)
+    reads = seq[e["pos"][:, None].astype(np.int64) + np.arange(L)[None, :]]
+    noise = np.frombuffer(e["noise"], np.uint8)
+    nl = np.flatnonzero(noise == 10)
+    cnt = np.diff(np.concatenate([[-1], nl])) - 1     # substitutions per read
+    assert len(cnt) == na and cnt.sum() == len(e["noisepos"])
+    rid = np.repeat(np.arange(na), cnt)
+    first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    cs = np.cumsum(e["noisepos"].astype(np.int64))
+    col = cs - np.repeat(np.concatenate([[0], cs])[first], cnt)   # position deltas -> positions inside the read
+    codes = noise[noise != 10] - ord("0")
+    lut = np.zeros((256, 4), np.uint8)
+    for r, row in DEC_NOISE.items():
+        lut[ord(r)] = np.frombuffer(row.encode(), np.uint8)
+    reads[rid, col] = lut[reads[rid, col], codes]
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    rc = e["rc"] == ord("r")
+    reads[rc] = comp[reads[rc][:, ::-1]]
+    return reads

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 import spring_amd  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import decode_fixed_len  # noqa: E402
 from spring_amd.encoder import EncoderStage  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
@@ -39,30 +41,8 @@ with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=0, num_thr=8)) as
             e = enc.streams()
             dna = st.download_dna() if hasattr(st, "download_dna") else None
             print("download %.1f s" % (time.time() - t0))
-            # vectorised decode (decompress.cpp:236-266) for fixed-length reads
             na = len(e["pos"])
-            seq = np.frombuffer(e["seq"], np.uint8)
-            idx = e["pos"][:, None].astype(np.int64) + np.arange(L)[None, :]
-            reads = seq[idx]                                  # [na, L] consensus letters
-            noise = np.frombuffer(e["noise"], np.uint8)
-            nl = np.flatnonzero(noise == 10)
-            cnt = np.diff(np.concatenate([[-1], nl])) - 1     # mismatches per read
-            assert len(cnt) == na and cnt.sum() == len(e["noisepos"])
-            rid = np.repeat(np.arange(na), cnt)
-            first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
-            cs = np.cumsum(e["noisepos"].astype(np.int64))
-            base = np.repeat(np.concatenate([[0], cs])[first], cnt)   # running sum before each read's first entry
-            col = cs - base
-            codes = noise[noise != 10] - ord("0")
-            lut = np.zeros((256, 4), np.uint8)
-            for r, row in {"A": "CGTN", "C": "AGTN", "G": "TACN", "T": "GCAN"}.items():
-                lut[ord(r)] = np.frombuffer(row.encode(), np.uint8)
-            reads[rid, col] = lut[reads[rid, col], codes]
-            comp = np.zeros(256, np.uint8)
-            for a, b in zip(b"ACGTN", b"TGCAN"):
-                comp[a] = b
-            rc = e["rc"] == ord("r")
-            reads[rc] = comp[reads[rc][:, ::-1]]
+            reads = decode_fixed_len(e, L)
             # original reads from the synthetic generator
             want = np.frombuffer(spring_amd.synth_dna_host(n, L, G, 7), np.uint8)
             rec = 2 + (L + 3) // 4
