@@ -635,11 +635,12 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
       const int kind = tab_find(fpt, bmask, hsh, skip, pay);
       if (kind == 0) break;  // key absent
       if (kind == 2) {       // single-read bin: pay is the read id
+        // a taken read contributes nothing whether this slot is the key's bin or a fingerprint collision:
+        // test the bitmap (12.5 MB, cache-resident) before spending a random 64-byte read on the key check
+        if (is_taken(P.taken, pay)) continue;
         if (read_window(P.reads + (uint64_t)pay * P.S, P.S, ds, klen2) != key) continue;  // fingerprint collision
-        if (!is_taken(P.taken, pay)) {
-          keyok = true; ncand = 1;
-          if (within_thresh(pay)) { hit = true; rid = pay; }
-        }
+        keyok = true; ncand = 1;
+        if (within_thresh(pay)) { hit = true; rid = pay; }
         break;
       }
       const ulonglong2 rec = urec[pay];
