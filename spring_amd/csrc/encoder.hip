@@ -20,6 +20,7 @@
 // consensus window.  No CPU fallback: every pass is a kernel or a rocPRIM primitive.
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -430,6 +431,127 @@ __global__ __launch_bounds__(256) void k_align(AlignP A) {
     }
   }
 }
+// bitmap of contig starts over the concatenated consensus (bit seq_len is set too): lets a thread find how far
+// its contig extends to the left and right with a few sequential word reads instead of a binary search
+__global__ void k_contig_bits(const uint64_t *__restrict__ ref_off, uint32_t C, unsigned long long *__restrict__ cbits) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  const uint64_t g = ref_off[c];
+  atomicOr(&cbits[g >> 6], 1ull << (g & 63));
+}
+// db = x - (start of x's contig), df = (end of x's contig) - x, both capped at `cap` (>= cap means "at least cap")
+__device__ __forceinline__ void contig_span(const unsigned long long *__restrict__ cbits, uint64_t x, int cap, int &db,
+                                            int &df) {
+  const uint64_t w = x >> 6;
+  const int o = (int)(x & 63);
+  db = cap;
+  {
+    unsigned long long m = cbits[w] & (o == 63 ? ~0ull : ((1ull << (o + 1)) - 1));
+    int dist = 0;  // distance from x down to bit 63 of the word being examined
+    uint64_t ww = w;
+    for (;;) {
+      if (m) { db = dist + (ww == w ? o : 63) - (63 - __clzll(m)); break; }
+      dist += (ww == w ? o : 63) + 1;
+      if (dist >= cap || ww == 0) break;
+      ww--;
+      m = cbits[ww];
+    }
+    if (db > cap) db = cap;
+  }
+  df = cap;
+  {
+    unsigned long long m = o == 63 ? 0ull : (cbits[w] >> (o + 1));
+    int dist = 1;  // distance from x to bit 0 of the shifted word
+    uint64_t ww = w;
+    for (;;) {
+      if (m) { df = dist + (__ffsll((unsigned long long)m) - 1); break; }
+      dist += (ww == w ? 63 - o : 64);
+      if (dist > cap) break;
+      ww++;
+      m = cbits[ww];
+    }
+    if (df > cap) df = cap;
+  }
+}
+
+// Both dictionaries have windows of the same length (always when max_readlen > 50), so one table keyed by
+// the 21-mer holds the bin of dictionary 0 and the bin of dictionary 1: 32-byte slots
+// {key | 1<<63, bin0, bin1, -}.  A thread then owns one 21-mer of the consensus and does 2 lookups (the
+// 21-mer and its reverse complement) for the 4 probes it takes part in, instead of 4 lookups per window.
+__global__ void k_mtab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
+                              const uint32_t *__restrict__ ucount, uint32_t numkeys, int l,
+                              unsigned long long *__restrict__ tab, uint64_t tmask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numkeys) return;
+  const unsigned long long tag = ukeys[i] | (1ull << 63);
+  uint64_t h = mix64(ukeys[i]) & tmask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&tab[4 * h], 0ull, tag);
+    if (old == 0ull || old == tag) {
+      tab[4 * h + 1 + l] = (unsigned long long)ustart[i] | ((unsigned long long)ucount[i] << 32);
+      break;
+    }
+    h = (h + 1) & tmask;
+  }
+}
+
+template <bool LIVE>
+__global__ __launch_bounds__(256) void k_align_m(AlignP A, const unsigned long long *__restrict__ mtab, uint64_t mmask,
+                                                 const unsigned long long *__restrict__ cbits) {
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // first base of this thread's 21-mer
+  if (x >= A.seq_len) return;
+  const uint64_t Lmax = (uint64_t)A.Lmax;
+  const int klen = A.dend[0] - A.dstart[0] + 1;
+  int db, df;  // bases of this contig at and before x / from x to its end, capped at Lmax
+  contig_span(cbits, x, A.Lmax, db, df);
+  if (df < klen) return;
+  const uint64_t kf = win64(A.refbits, 2 * x) & lowmask(2 * klen);
+  const uint64_t kr = (~(rev2(kf) >> (64 - 2 * klen))) & lowmask(2 * klen);
+#pragma unroll 1
+  for (int rev = 0; rev < 2; rev++) {
+    const uint64_t key = rev ? kr : kf;
+    const unsigned long long tag = key | (1ull << 63);
+    uint64_t h = mix64(key) & mmask;
+    ulonglong2 s01;
+    for (;;) {
+      s01 = *(const ulonglong2 *)&mtab[4 * h];  // {key, bin0}
+      if (s01.x == 0ull || s01.x == tag) break;
+      h = (h + 1) & mmask;
+    }
+    if (s01.x == 0ull) continue;
+#pragma unroll 1
+    for (int l = 0; l < 2; l++) {
+      const unsigned long long sy = l ? mtab[4 * h + 2] : s01.y;
+      const uint32_t bstart = (uint32_t)sy, bcount = (uint32_t)(sy >> 32);
+      if (!bcount) continue;
+      // the window this probe belongs to: forward key = window bases [dstart, dend]; reverse key = reverse
+      // complement of window bases [Lmax-1-dend, Lmax-1-dstart]
+      const int back = rev ? A.Lmax - 1 - A.dend[l] : A.dstart[l];
+      if (back > db || A.Lmax - back > df) continue;  // the window [g, g + Lmax) must lie inside this contig
+      const uint64_t g = x - (uint64_t)back;
+      const unsigned long long Pkey = (g << 2) | (unsigned long long)(rev << 1) | (unsigned long long)l;
+      int seen = 0;
+      for (long long k = (long long)bstart + bcount - 1; k >= (long long)bstart; k--) {
+        const uint32_t rid = A.ids[l][k];
+        if (LIVE && A.Tprev[rid] < Pkey) continue;
+        if (++seen > MAX_SEARCH_E) break;
+        const int nc = A.ncnt[rid];
+        if (nc > THRESH_E) continue;
+        const int len = A.slen[rid];
+        const uint64_t bo = rev ? g + Lmax - len : g;
+        const uint64_t *rd = (rev ? A.srev : A.sread) + (size_t)rid * A.S;
+        int hd = nc;
+        const int nl = (len + 31) >> 5;
+        for (int t = 0; t < nl; t++) {
+          const uint64_t xx = (win64(A.refbits, 2 * bo + 64ull * t) ^ rd[t]) & lowmask(2 * (len - 32 * t));
+          hd += __popcll(xx);
+          if (hd > THRESH_E) break;
+        }
+        if (hd <= THRESH_E) atomicMin(&A.Tnew[rid], Pkey);
+      }
+    }
+  }
+}
 __global__ void k_differs(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b,
                           uint32_t n, uint32_t *__restrict__ flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -833,12 +955,15 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
 
   // ------------------------------------------------ singleton pool + dictionaries
   DBuf sread, srev, nmask, nmask_r, slen, ncnt, Tprev, Tnew;
-  DBuf tab[2], ids[2];
-  uint64_t tmask[2] = {0, 0};
+  DBuf tab[2], ids[2], mtab;
+  uint64_t tmask[2] = {0, 0}, mmask = 0;
   bool have_tab[2] = {false, false};
   int dstart[2], dend[2];
   if (Lmax > 50) { dstart[0] = 0; dend[0] = 20; dstart[1] = 21; dend[1] = 41; }   // encoder.h:606-616
   else { dstart[0] = 0; dend[0] = 20 * Lmax / 50; dstart[1] = 20 * Lmax / 50 + 1; dend[1] = 41 * Lmax / 50; }
+  // one table for both dictionaries when their windows have the same length (max_readlen > 50 and most others)
+  const bool merged = (dend[0] - dstart[0]) == (dend[1] - dstart[1]) && dend[0] - dstart[0] + 1 <= 31 &&
+                      !getenv("SPRING_ENC_SPLIT_TABLES");
   uint32_t max_bin = 0;
   DALLOC(sread, (size_t)(np ? np : 1) * S * 8); DALLOC(srev, (size_t)(np ? np : 1) * S * 8);
   DALLOC(nmask, (size_t)(np ? np : 1) * SM * 8); DALLOC(nmask_r, (size_t)(np ? np : 1) * SM * 8);
@@ -858,6 +983,13 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
                        slen.as<uint16_t>(), S, SM, np, srev.as<uint64_t>(), nmask_r.as<uint64_t>());
     hipLaunchKernelGGL(k_pool_order, grid(np), dim3(256), 0, st, V.f_order_s, dorderN.as<uint32_t>(), ns, np,
                        cumN.as<uint32_t>(), order_sc.as<uint32_t>());
+    if (merged) {
+      uint64_t cap = 1024;
+      while (cap < 4ull * np) cap <<= 1;  // <= 2 np distinct keys: load <= 0.5
+      mmask = cap - 1;
+      DALLOC(mtab, cap * 32);
+      HIPCHK(hipMemsetAsync(mtab.p, 0, cap * 32, st));
+    }
     DBuf flag, slot, keys, vals, skeys, ukeys, ucount, ustart, dnruns, dmx;
     DALLOC(flag, (size_t)(np + 1) * 4); DALLOC(slot, (size_t)(np + 1) * 4); DALLOC(keys, (size_t)np * 8);
     DALLOC(vals, (size_t)np * 4); DALLOC(skeys, (size_t)np * 8); DALLOC(ukeys, (size_t)np * 8);
@@ -892,13 +1024,18 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
       HIPCHK(sr::reduce_max_u32(st, tmp.p, t2, ucount.as<uint32_t>(), dmx.as<uint32_t>(), nk));
       uint32_t mb = 0;
       HIPCHK(hipMemcpyAsync(&mb, dmx.p, 4, hipMemcpyDeviceToHost, st));
-      uint64_t cap = 1024;
-      while (cap < 2ull * nk) cap <<= 1;
-      tmask[l] = cap - 1;
-      DALLOC(tab[l], cap * 16);
-      HIPCHK(hipMemsetAsync(tab[l].p, 0, cap * 16, st));
-      hipLaunchKernelGGL(k_etab_insert, grid(nk), dim3(256), 0, st, ukeys.as<uint64_t>(), ustart.as<uint32_t>(),
-                         ucount.as<uint32_t>(), nk, tab[l].as<unsigned long long>(), tmask[l]);
+      if (merged) {
+        hipLaunchKernelGGL(k_mtab_insert, grid(nk), dim3(256), 0, st, ukeys.as<uint64_t>(), ustart.as<uint32_t>(),
+                           ucount.as<uint32_t>(), nk, l, mtab.as<unsigned long long>(), mmask);
+      } else {
+        uint64_t cap = 1024;
+        while (cap < 2ull * nk) cap <<= 1;
+        tmask[l] = cap - 1;
+        DALLOC(tab[l], cap * 16);
+        HIPCHK(hipMemsetAsync(tab[l].p, 0, cap * 16, st));
+        hipLaunchKernelGGL(k_etab_insert, grid(nk), dim3(256), 0, st, ukeys.as<uint64_t>(), ustart.as<uint32_t>(),
+                           ucount.as<uint32_t>(), nk, tab[l].as<unsigned long long>(), tmask[l]);
+      }
       HIPCHK(hipStreamSynchronize(st));
       max_bin = std::max(max_bin, mb);
       have_tab[l] = true;
@@ -910,7 +1047,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
 
   // ------------------------------------------------ alignment: fixed point of "first probe that takes the read"
   uint32_t passes = 0;
-  DBuf dflag;
+  DBuf dflag, cbits;
   DALLOC(dflag, 16);
   if (np) hipLaunchKernelGGL(k_fill_u64, grid(np), dim3(256), 0, st, Tprev.as<unsigned long long>(), (uint64_t)np, INF);
   if (np && seq_len && (have_tab[0] || have_tab[1])) {
@@ -919,17 +1056,31 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
     A.Lmax = Lmax; A.S = S;
     for (int l = 0; l < 2; l++) {
       A.dstart[l] = dstart[l]; A.dend[l] = dend[l];
-      A.tab[l] = have_tab[l] ? tab[l].as<unsigned long long>() : nullptr;
+      A.tab[l] = (have_tab[l] && !merged) ? tab[l].as<unsigned long long>() : nullptr;
       A.tmask[l] = tmask[l]; A.ids[l] = ids[l].as<uint32_t>();
     }
     A.sread = sread.as<uint64_t>(); A.srev = srev.as<uint64_t>(); A.slen = slen.as<uint16_t>(); A.ncnt = ncnt.as<uint16_t>();
     const bool live = max_bin > (uint32_t)MAX_SEARCH_E;
+    if (merged) {
+      const uint64_t nw = seq_len / 64 + 16;
+      DALLOC(cbits, nw * 8);
+      HIPCHK(hipMemsetAsync(cbits.p, 0, nw * 8, st));
+      hipLaunchKernelGGL(k_contig_bits, grid((uint64_t)C + 1), dim3(256), 0, st, ref_off.as<uint64_t>(), C,
+                         cbits.as<unsigned long long>());
+    }
     for (;;) {
       if (passes >= 1000) return fail(SPRING_REORDER_E_STATE, "singleton alignment did not reach its fixed point");
       hipLaunchKernelGGL(k_fill_u64, grid(np), dim3(256), 0, st, Tnew.as<unsigned long long>(), (uint64_t)np, INF);
       A.Tprev = Tprev.as<unsigned long long>(); A.Tnew = Tnew.as<unsigned long long>();
-      if (live) hipLaunchKernelGGL(k_align<true>, grid(seq_len), dim3(256), 0, st, A);
-      else hipLaunchKernelGGL(k_align<false>, grid(seq_len), dim3(256), 0, st, A);
+      if (merged) {
+        if (live) hipLaunchKernelGGL(k_align_m<true>, grid(seq_len), dim3(256), 0, st, A, mtab.as<unsigned long long>(), mmask,
+                                     cbits.as<unsigned long long>());
+        else hipLaunchKernelGGL(k_align_m<false>, grid(seq_len), dim3(256), 0, st, A, mtab.as<unsigned long long>(), mmask,
+                                cbits.as<unsigned long long>());
+      } else {
+        if (live) hipLaunchKernelGGL(k_align<true>, grid(seq_len), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(k_align<false>, grid(seq_len), dim3(256), 0, st, A);
+      }
       passes++;
       uint32_t changed = 0;
       if (live) {
