@@ -177,3 +177,59 @@ def test_encoder_2M_decode_round_trip():
     for k, s in enumerate(un):
         assert s.encode() == orig[e["order"][na + k]].tobytes()
     assert np.array_equal(np.sort(e["order"]), np.arange(n, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_fastq_to_encoder_streams_end_to_end(paired):
+    """Rows f1 -> hot path -> f2 chained on the GPU: FASTQ text in, encoder streams out; decoding them
+    (decompress.cpp:236-266) must return the reads of the FASTQ at their original positions, N reads included.
+    Overlapping reads of a small genome so that contigs, aligned singletons and aligned N reads all occur."""
+    import spring_amd
+    from spring_amd.encoder import EncoderStage
+    rng = np.random.default_rng(77 + paired)
+    G, L, n = 30000, 120, 12000
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, G)]
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+
+    def make(nreads, seed):
+        r = np.random.default_rng(seed)
+        reads = []
+        for i in range(nreads):
+            ln = int(r.integers(60, L + 1))
+            p = int(r.integers(0, G - ln))
+            s = genome[p:p + ln].copy()
+            flip = r.random(ln) < 0.01
+            s[flip] = np.frombuffer(b"ACGT", np.uint8)[r.integers(0, 4, int(flip.sum()))]
+            if r.random() < 0.08:
+                s[r.integers(0, ln, 2)] = ord("N")
+            if r.random() < 0.5:
+                s = comp[s[::-1]]
+            reads.append(s.tobytes())
+        return reads
+
+    files = [make(n, 1)] + ([make(n, 2)] if paired else [])
+    texts = [b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(f)) for f in files]
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=32, num_thr=3)) as st:
+        info = st.load_fastq(texts[0], texts[1] if paired else None)
+        st.run()
+        dnaN, order_N = b"", np.zeros(0, np.uint32)
+        for w in range(len(files)):  # merge of input_N.dna(.2) / read_order_N.bin(.2), preprocess.cpp:362-383
+            b_, o_ = st.fastq_N(w)
+            dnaN += b_
+            order_N = np.concatenate([order_N, o_ + np.uint32(w * info["num_reads"][0])])
+        with EncoderStage() as enc:
+            ei = enc.encode(st, dnaN, order_N)
+            e = enc.streams()
+    allreads = [s.decode() for f in files for s in f]
+    assert ei["n_total"] == len(allreads) and ei["matched_s"] > 0 and ei["matched_N"] > 0
+    dec = decode_reads(e)
+    for o, s in dec.items():
+        assert allreads[o] == s
+    na = len(e["pos"])
+    un = unpack_dnaN(e["unaligned"])
+    assert len(un) == len(allreads) - na
+    for k, s in enumerate(un):
+        assert allreads[int(e["order"][na + k])] == s
+    assert sorted(e["order"].tolist()) == list(range(len(allreads)))
