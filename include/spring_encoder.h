@@ -57,6 +57,21 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
                                   uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t numreads_N,
                                   spring_encoder_info *info);
 
+/* The same from the in-memory images of the files encoder_main reads (encoder.h:580-593), for streams produced
+ * by any reorder implementation (the reference's included):
+ *   tid_count[num_thr]   records per tid; the five streams below hold the tids one after the other
+ *   dna_stream           temp.dna.<tid> images concatenated (reads already reverse-complemented for 'r')
+ *   order/rc/flag/pos/rlen   read_order.bin.<tid>, read_rev.txt.<tid>, tempflag.txt.<tid>, temppos.txt.<tid>,
+ *                        read_lengths.bin.<tid> (decompressed)
+ *   dna_single, order_s  temp.dna.singleton, read_order.bin.singleton (numreads_s records)
+ *   dnaN, order_N        input_N.dna, read_order_N.bin */
+int spring_encoder_encode_host(spring_encoder_ctx *ctx, uint32_t max_readlen, int32_t num_thr, const uint64_t *tid_count,
+                               const uint8_t *dna_stream, uint64_t dna_bytes, const uint32_t *order, const char *rc,
+                               const char *flag, const int64_t *pos, const uint16_t *rlen, const uint8_t *dna_single,
+                               uint64_t single_bytes, const uint32_t *order_s, uint32_t numreads_s, const uint8_t *dnaN,
+                               uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t numreads_N,
+                               spring_encoder_info *info);
+
 /* Copy the streams to host buffers sized from the info struct; any pointer may be NULL:
  *   seq          seq_len chars (read_seq.bin.<tid> texts, tid-major); seq_len_tid[num_thr]
  *   pos          n_aligned u64 (read_pos.bin, absolute)
@@ -84,6 +99,14 @@ int spring_encoder_get_info(spring_encoder_ctx *ctx, spring_encoder_info *info);
 int spring_reorder_encode_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, int32_t paired_end,
                               uint32_t num_reads_clean_1, uint32_t num_reads_clean_2, uint32_t num_reads,
                               const spring_reorder_opts *opts, spring_encoder_info *info);
+
+/* File contract of the encoder stage alone: drop-in for spring::call_encoder(temp_dir, cp)
+ * (call_template_functions.cpp:65-142).  Reads the per-tid files a reorder stage left in temp_dir (the
+ * reference's reorder_main or spring_reorder_run; gzip members are read through zlib), the singleton files,
+ * input_N.dna and read_order_N.bin; writes the same outputs as spring_reorder_encode_run and removes its
+ * inputs.  num_reads = cp.num_reads, num_reads_clean = cp.num_reads_clean[0] + cp.num_reads_clean[1]. */
+int spring_encoder_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, uint32_t num_reads,
+                       uint32_t num_reads_clean, int32_t device, spring_encoder_info *info);
 
 #ifdef __cplusplus
 }

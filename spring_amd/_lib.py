@@ -17,7 +17,7 @@ EXPORTS = [
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct", "spring_order_pe_encode",
     "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
     "spring_encoder_create", "spring_encoder_destroy", "spring_encoder_encode_reorder", "spring_encoder_download",
-    "spring_encoder_download_seq_packed", "spring_encoder_get_info", "spring_reorder_encode_run",
+    "spring_encoder_download_seq_packed", "spring_encoder_get_info", "spring_reorder_encode_run", "spring_encoder_encode_host", "spring_encoder_run",
 ]
 
 
@@ -118,6 +118,11 @@ def lib():
     L.spring_encoder_encode_reorder.argtypes = [vp, vp, u8p, C.c_uint64, vp, C.c_uint32, C.POINTER(EncoderInfo)]
     L.spring_encoder_download.argtypes = [vp] + [vp] * 9
     L.spring_encoder_download_seq_packed.argtypes = [vp, vp, vp]
+    L.spring_encoder_encode_host.argtypes = [vp, C.c_uint32, C.c_int32, vp, u8p, C.c_uint64, vp, vp, vp, vp, vp, u8p,
+                                             C.c_uint64, vp, C.c_uint32, u8p, C.c_uint64, vp, C.c_uint32,
+                                             C.POINTER(EncoderInfo)]
+    L.spring_encoder_run.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32,
+                                     C.POINTER(EncoderInfo)]
     L.spring_encoder_get_info.argtypes = [vp, C.POINTER(EncoderInfo)]
     L.spring_reorder_encode_run.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.POINTER(Opts), C.POINTER(EncoderInfo)]

@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     subprocess.run(cmd, check=True)
     return LIB
 

@@ -130,9 +130,9 @@ __global__ void k_fill_u64(unsigned long long *p, uint64_t n, unsigned long long
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
-__global__ void k_iota(uint32_t *p, uint64_t n) {
+__global__ void k_iota(uint32_t *p, uint64_t n, uint32_t base = 0) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (uint32_t)i;
+  if (i < n) p[i] = base + (uint32_t)i;
 }
 // per-contig min(pos), max(pos+len): one atomic per wave when the wave sits inside one contig
 __global__ void k_minmax(const long long *__restrict__ pos, const uint16_t *__restrict__ rlen,
@@ -219,7 +219,7 @@ __device__ __forceinline__ uint32_t block_search(const ulonglong2 *__restrict__ 
   return lo + (uint32_t)nfalse;
 }
 __global__ __launch_bounds__(256) void k_consensus(const ulonglong2 *__restrict__ srec, uint32_t M, uint64_t seq_len,
-                                                   const uint64_t *__restrict__ reads, int S, int Lmax,
+                                                   const uint64_t *__restrict__ reads, int S, int Lmax, bool oriented,
                                                    uint8_t *__restrict__ refc) {
   __shared__ uint32_t cnt[CONS_TILE * 4];  // [base][A, C, G, T] (chartolong, encoder.cpp:36-45)
   const uint64_t g0 = (uint64_t)blockIdx.x * CONS_TILE;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_consensus(const ulonglong2 *__restrict_
   for (uint32_t k = a + threadIdx.x; k < b; k += 256) {
     const ulonglong2 r = srec[k];
     const int len = (int)((r.y >> 32) & 0xffff);
-    const bool rc = (r.y >> 48) & 1;
+    const bool rc = ((r.y >> 48) & 1) && !oriented;  // temp.dna.<tid> reads are stored already reverse-complemented
     const uint64_t *rd = reads + (size_t)(uint32_t)r.y * S;
     const int jlo = r.x < g0 ? (int)(g0 - r.x) : 0;
     const long long jend = (long long)(g0 + CONS_TILE - r.x);
@@ -599,6 +599,8 @@ struct NoiseP {
   const uint64_t *reads;
   int S, SM;
   const uint64_t *sread, *srev, *nmask, *nmask_r;
+  bool oriented;             // stream reads are stored already reverse-complemented
+  const uint32_t *oid;       // clean-read id of a stream record's read (null: the gather index is the id)
   const uint32_t *cumN;      // may be null (no N reads)
   const uint32_t *order_sc;  // corrected order of the pool reads
   uint32_t *nm;              // mismatches per record
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256) void k_noise(NoiseP N) {
   int prevj = 0;
   if (WRITE) o = N.noff[f];
   for (int t = 0; t < nl; t++) {
-    const uint64_t r = (single || !rc) ? rd[t] : rc_limb(rd, N.S, len, t);
+    const uint64_t r = (single || !rc || N.oriented) ? rd[t] : rc_limb(rd, N.S, len, t);
     const uint32_t nh = nmk ? (uint32_t)(nmk[t >> 1] >> (32 * (t & 1))) : 0u;
     const uint64_t w = win64(N.refbits, 2 * gpos + 64ull * t);
     const uint64_t x = w ^ r;
@@ -659,7 +661,8 @@ __global__ __launch_bounds__(256) void k_noise(NoiseP N) {
     N.out_pos[f] = gpos;
     N.out_rlen[f] = (uint16_t)len;
     N.out_rc[f] = rc ? 'r' : 'd';
-    N.out_order[f] = single ? N.order_sc[id] : id + (N.cumN ? N.cumN[id] : 0u);
+    const uint32_t cid = single ? 0u : (N.oid ? N.oid[id] : id);
+    N.out_order[f] = single ? N.order_sc[id] : cid + (N.cumN ? N.cumN[cid] : 0u);
   }
 }
 
@@ -765,8 +768,8 @@ struct DBuf {
 
 struct spring_encoder_ctx {
   int dev = 0;
-  hipStream_t st = nullptr;
-  bool own_stream = false;
+  hipStream_t st = nullptr;      // stream of the last encode (the reorder context's, or `own`)
+  hipStream_t own = nullptr;     // created on first use by spring_encoder_encode_host
   int T = 0;
   spring_encoder_info info;
   bool have = false;
@@ -797,18 +800,24 @@ void spring_encoder_destroy(spring_encoder_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev);
   (void)hipDeviceSynchronize();
+  if (ctx->own) (void)hipStreamDestroy(ctx->own);
   delete ctx;
 }
 
-int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *reorder, const uint8_t *dnaN,
-                                  uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t nN,
-                                  spring_encoder_info *info_out) {
-  if (!ctx || !reorder) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+}  // extern "C"
+
+// where the reads of the records come from
+struct EncSrc {
+  sr::ReorderView V;      // pool + streams on the device (f_order / f_order_s = gather index into V.reads)
+  bool oriented;          // stream reads are stored already reverse-complemented (temp.dna.<tid> image)
+  const uint32_t *oid;    // clean-read id of stream record i (null: the gather index is the id)
+  const uint32_t *oid_s;  // clean-read id of singleton q (null: V.f_order_s)
+};
+
+static int encode_core(spring_encoder_ctx *ctx, const EncSrc &E, const uint8_t *dnaN, uint64_t dnaN_bytes,
+                       const uint32_t *order_N, uint32_t nN, spring_encoder_info *info_out) {
+  const sr::ReorderView &V = E.V;
   if (nN && (!dnaN || !order_N)) return fail(SPRING_REORDER_E_ARG, "numreads_N > 0 but dnaN / order_N is NULL");
-  sr::ReorderView V;
-  int rcv = sr::reorder_view(reorder, &V);
-  if (rcv) return rcv;
-  if (V.dev != ctx->dev) return fail(SPRING_REORDER_E_ARG, "encoder and reorder contexts live on different devices");
   const int dev = ctx->dev;
   HIPCHK(hipSetDevice(dev));
   hipStream_t st = V.st;
@@ -947,7 +956,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   HIPCHK(hipMemsetAsync(refbits.p, 0, (nwords + 40) * 8, st));
   if (seq_len) {
     hipLaunchKernelGGL(k_consensus, dim3((unsigned)((seq_len + CONS_TILE - 1) / CONS_TILE)), dim3(256), 0, st,
-                       frec.as<ulonglong2>(), M, seq_len, V.reads, S, Lmax, ctx->refc.as<uint8_t>());
+                       frec.as<ulonglong2>(), M, seq_len, V.reads, S, Lmax, E.oriented, ctx->refc.as<uint8_t>());
     hipLaunchKernelGGL(k_pack_ref, grid(nwords), dim3(256), 0, st, ctx->refc.as<uint8_t>(), seq_len,
                        refbits.as<uint64_t>(), nwords);
   }
@@ -981,7 +990,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
                          sread.as<uint64_t>(), nmask.as<uint64_t>(), slen.as<uint16_t>(), ncnt.as<uint16_t>());
     hipLaunchKernelGGL(k_pool_rev, grid((uint64_t)np * S), dim3(256), 0, st, sread.as<uint64_t>(), nmask.as<uint64_t>(),
                        slen.as<uint16_t>(), S, SM, np, srev.as<uint64_t>(), nmask_r.as<uint64_t>());
-    hipLaunchKernelGGL(k_pool_order, grid(np), dim3(256), 0, st, V.f_order_s, dorderN.as<uint32_t>(), ns, np,
+    hipLaunchKernelGGL(k_pool_order, grid(np), dim3(256), 0, st, E.oid_s ? E.oid_s : V.f_order_s, dorderN.as<uint32_t>(), ns, np,
                        cumN.as<uint32_t>(), order_sc.as<uint32_t>());
     if (merged) {
       uint64_t cap = 1024;
@@ -1124,7 +1133,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   const uint64_t F = (uint64_t)M + A_cnt;
   const uint32_t *vfin = vB.as<uint32_t>();
   if (F) {
-    hipLaunchKernelGGL(k_iota, grid(F), dim3(256), 0, st, vB.as<uint32_t>(), F);
+    hipLaunchKernelGGL(k_iota, grid(F), dim3(256), 0, st, vB.as<uint32_t>(), F, 0u);
     if (A_cnt) {
       t2 = tb;
       HIPCHK(sr::sort_pairs(st, tmp.p, t2, kB.as<uint64_t>(), kA.as<uint64_t>(), vB.as<uint32_t>(), vA.as<uint32_t>(), F,
@@ -1168,7 +1177,7 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   N.vfin = vfin; N.frec = frec.as<ulonglong2>(); N.F = F;
   N.refbits = refbits.as<uint64_t>(); N.reads = V.reads; N.S = S; N.SM = SM;
   N.sread = sread.as<uint64_t>(); N.srev = srev.as<uint64_t>(); N.nmask = nmask.as<uint64_t>();
-  N.nmask_r = nmask_r.as<uint64_t>(); N.cumN = cumN.as<uint32_t>(); N.order_sc = order_sc.as<uint32_t>();
+  N.nmask_r = nmask_r.as<uint64_t>(); N.oriented = E.oriented; N.oid = E.oid; N.cumN = cumN.as<uint32_t>(); N.order_sc = order_sc.as<uint32_t>();
   N.nm = nm.as<uint32_t>(); N.noff = noff.as<uint64_t>(); N.noise = nullptr; N.noisepos = nullptr;
   N.out_pos = ctx->pos.as<uint64_t>(); N.out_order = ctx->order.as<uint32_t>(); N.out_rlen = ctx->rlen.as<uint16_t>();
   N.out_rc = ctx->rc.as<char>();
@@ -1221,6 +1230,95 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   ctx->have = true;
   if (info_out) *info_out = I;
   return 0;
+}
+
+extern "C" {
+
+int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *reorder, const uint8_t *dnaN,
+                                  uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t nN,
+                                  spring_encoder_info *info_out) {
+  if (!ctx || !reorder) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  EncSrc E;
+  int rcv = sr::reorder_view(reorder, &E.V);
+  if (rcv) return rcv;
+  if (E.V.dev != ctx->dev) return fail(SPRING_REORDER_E_ARG, "encoder and reorder contexts live on different devices");
+  E.oriented = false;
+  E.oid = nullptr;
+  E.oid_s = nullptr;
+  return encode_core(ctx, E, dnaN, dnaN_bytes, order_N, nN, info_out);
+}
+
+int spring_encoder_encode_host(spring_encoder_ctx *ctx, uint32_t max_readlen, int32_t num_thr, const uint64_t *tid_count,
+                               const uint8_t *dna_stream, uint64_t dna_bytes, const uint32_t *order, const char *rc,
+                               const char *flag, const int64_t *pos, const uint16_t *rlen, const uint8_t *dna_single,
+                               uint64_t single_bytes, const uint32_t *order_s, uint32_t ns, const uint8_t *dnaN,
+                               uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t nN, spring_encoder_info *info_out) {
+  if (!ctx || !tid_count || num_thr <= 0) return fail(SPRING_REORDER_E_ARG, "bad argument");
+  if (max_readlen == 0 || max_readlen > (uint32_t)sr::MAX_READ_LEN) return fail(SPRING_REORDER_E_ARG, "Wrong bitset size.");
+  const int dev = ctx->dev;
+  HIPCHK(hipSetDevice(dev));
+  if (!ctx->own) HIPCHK(hipStreamCreate(&ctx->own));
+  hipStream_t st = ctx->own;
+  std::vector<uint64_t> tid_off(num_thr + 1, 0);
+  for (int t = 0; t < num_thr; t++) tid_off[t + 1] = tid_off[t] + tid_count[t];
+  const uint64_t M = tid_off[num_thr];
+  if (M + ns > 4294967290ull) return fail(SPRING_REORDER_E_ARG, "too many reads");
+  if (M && (!dna_stream || !order || !rc || !flag || !pos || !rlen)) return fail(SPRING_REORDER_E_ARG, "NULL stream");
+  if (ns && (!dna_single || !order_s)) return fail(SPRING_REORDER_E_ARG, "NULL singleton image");
+  // record offsets: temp.dna.<tid> records follow read_lengths.bin; the singleton records carry their own length
+  const uint64_t R = M + ns;
+  std::vector<uint64_t> off(R ? R : 1);
+  uint64_t o = 0;
+  for (uint64_t i = 0; i < M; i++) { off[i] = o; o += 2 + (rlen[i] + 3u) / 4u; }
+  if (o != dna_bytes) return fail(SPRING_REORDER_E_ARG, "temp.dna image does not match read_lengths (%llu vs %llu bytes)",
+                                  (unsigned long long)o, (unsigned long long)dna_bytes);
+  uint64_t so = 0;
+  for (uint32_t q = 0; q < ns; q++) {
+    if (so + 2 > single_bytes) return fail(SPRING_REORDER_E_ARG, "temp.dna.singleton image is truncated");
+    const uint32_t len = dna_single[so] | (dna_single[so + 1] << 8);
+    if (len > max_readlen) return fail(SPRING_REORDER_E_ARG, "singleton longer than max_readlen");
+    off[M + q] = dna_bytes + so;
+    so += 2 + (len + 3) / 4;
+  }
+  if (so > single_bytes) return fail(SPRING_REORDER_E_ARG, "temp.dna.singleton image is truncated");
+  const int L = (int)max_readlen, W = (2 * L - 1) / 64 + 1;
+  int S = 1;
+  while (S < W) S <<= 1;
+  DBuf d_dna, d_off, d_reads, d_lens, d_src, d_ssrc, d_oid, d_oids, d_rc, d_flag, d_pos, d_len;
+  DALLOC(d_dna, dna_bytes + single_bytes + 16); DALLOC(d_off, (R ? R : 1) * 8);
+  DALLOC(d_reads, (R ? R : 1) * S * 8); DALLOC(d_lens, (R ? R : 1) * 2);
+  DALLOC(d_src, (M ? M : 1) * 4); DALLOC(d_ssrc, (size_t)(ns ? ns : 1) * 4); DALLOC(d_oid, (M ? M : 1) * 4);
+  DALLOC(d_oids, (size_t)(ns ? ns : 1) * 4); DALLOC(d_rc, M ? M : 1); DALLOC(d_flag, M ? M : 1);
+  DALLOC(d_pos, (M ? M : 1) * 8); DALLOC(d_len, (M ? M : 1) * 2);
+  if (dna_bytes) HIPCHK(hipMemcpyAsync(d_dna.p, dna_stream, dna_bytes, hipMemcpyHostToDevice, st));
+  if (so) HIPCHK(hipMemcpyAsync(d_dna.as<uint8_t>() + dna_bytes, dna_single, so, hipMemcpyHostToDevice, st));
+  if (R) HIPCHK(hipMemcpyAsync(d_off.p, off.data(), R * 8, hipMemcpyHostToDevice, st));
+  if (M) {
+    HIPCHK(hipMemcpyAsync(d_oid.p, order, M * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_rc.p, rc, M, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_flag.p, flag, M, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_pos.p, pos, M * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_len.p, rlen, M * 2, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_iota, grid(M), dim3(256), 0, st, d_src.as<uint32_t>(), M, 0u);
+  }
+  if (ns) {
+    HIPCHK(hipMemcpyAsync(d_oids.p, order_s, (size_t)ns * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_iota, grid(ns), dim3(256), 0, st, d_ssrc.as<uint32_t>(), (uint64_t)ns, (uint32_t)M);
+  }
+  if (R) sr::launch_unpack(st, d_dna.as<uint8_t>(), d_off.as<uint64_t>(), (uint32_t)R, L, W, S, 0, d_reads.as<uint64_t>(),
+                           d_lens.as<uint16_t>());
+  EncSrc E;
+  E.V.dev = dev; E.V.st = st; E.V.n = (uint32_t)R; E.V.L = L; E.V.W = W; E.V.S = S;
+  E.V.reads = d_reads.as<uint64_t>(); E.V.lens = d_lens.as<uint16_t>(); E.V.nrec = M; E.V.nsing = ns;
+  E.V.f_order = d_src.as<uint32_t>(); E.V.f_order_s = d_ssrc.as<uint32_t>(); E.V.f_rc = d_rc.as<char>();
+  E.V.f_flag = d_flag.as<char>(); E.V.f_pos = d_pos.as<long long>(); E.V.f_len = d_len.as<uint16_t>();
+  E.V.tid_off = tid_off.data(); E.V.num_thr = num_thr;
+  E.oriented = true;
+  E.oid = d_oid.as<uint32_t>();
+  E.oid_s = d_oids.as<uint32_t>();
+  const int r = encode_core(ctx, E, dnaN, dnaN_bytes, order_N, nN, info_out);
+  (void)hipStreamSynchronize(st);
+  return r;
 }
 
 int spring_encoder_get_info(spring_encoder_ctx *ctx, spring_encoder_info *info) {

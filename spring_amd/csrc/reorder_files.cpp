@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "call_reorder.h"
 #include "spring_encoder.h"
 #include "spring_reorder.h"
@@ -190,6 +192,55 @@ struct EncGuard {
   spring_encoder_ctx *c = nullptr;
   ~EncGuard() { spring_encoder_destroy(c); }
 };
+// the files encoder_main leaves behind (encoder.h:365-494), read_seq as .tmp + .tail (state before BSC_compress)
+int write_encoder_files(const std::string &base, spring_encoder_ctx *ec, const spring_encoder_info &I, int num_thr) {
+  int r;
+  std::vector<uint64_t> seq_len_tid(num_thr), pos(I.n_aligned ? I.n_aligned : 1);
+  std::vector<char> noise(I.noise_bytes ? I.noise_bytes : 1), rc(I.n_aligned ? I.n_aligned : 1);
+  std::vector<uint16_t> noisepos(I.n_noisepos ? I.n_noisepos : 1), rlen(I.n_total ? I.n_total : 1);
+  std::vector<uint32_t> order(I.n_total ? I.n_total : 1);
+  std::vector<uint8_t> un(I.unaligned_bytes ? I.unaligned_bytes : 1);
+  if ((r = spring_encoder_download(ec, nullptr, seq_len_tid.data(), pos.data(), noise.data(), noisepos.data(),
+                                   order.data(), rlen.data(), rc.data(), un.data())))
+    return r;
+  uint64_t packed_total = 0;
+  for (int t = 0; t < num_thr; t++) packed_total += seq_len_tid[t] / 4;
+  std::vector<uint8_t> packed(packed_total ? packed_total : 1);
+  std::vector<char> tail((size_t)num_thr * 4);
+  if ((r = spring_encoder_download_seq_packed(ec, packed.data(), tail.data()))) return r;
+  uint64_t po = 0;
+  for (int t = 0; t < num_thr; t++) {  // pack_compress_seq up to the BSC call (encoder.cpp:111-150)
+    const std::string ts = "." + std::to_string(t);
+    if ((r = write_raw(base + "/read_seq.bin" + ts + ".tmp", packed.data() + po, seq_len_tid[t] / 4))) return r;
+    if ((r = write_raw(base + "/read_seq.bin" + ts + ".tail", tail.data() + 4 * t, seq_len_tid[t] % 4))) return r;
+    po += seq_len_tid[t] / 4;
+  }
+  if ((r = write_raw(base + "/read_pos.bin", pos.data(), I.n_aligned * 8))) return r;          // encoder.h:465-480
+  if ((r = write_raw(base + "/read_noise.txt", noise.data(), I.noise_bytes))) return r;         // encoder.h:365-395
+  if ((r = write_raw(base + "/read_noisepos.bin", noisepos.data(), I.n_noisepos * 2))) return r;
+  if ((r = write_raw(base + "/read_order.bin", order.data(), I.n_total * 4))) return r;         // + unaligned, :425-445
+  if ((r = write_raw(base + "/read_rev.txt", rc.data(), I.n_aligned))) return r;
+  if ((r = write_raw(base + "/read_lengths.bin", rlen.data(), I.n_total * 2))) return r;
+  if ((r = write_raw(base + "/read_unaligned.txt", un.data(), I.unaligned_bytes))) return r;
+  if ((r = write_raw(base + "/read_unaligned.txt.count", &I.len_unaligned, 8))) return r;      // encoder.h:457-460
+  return 0;
+}
+
+// whole file -> memory through zlib (accepts the reference's boost::iostreams gzip members and our stored ones)
+int read_gz(const std::string &path, std::vector<uint8_t> &buf) {
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (!f) return fail(SPRING_REORDER_E_IO, "cannot open %s", path.c_str());
+  gzbuffer(f, 1 << 20);
+  uint8_t tmp[1 << 16];
+  for (;;) {
+    const int k = gzread(f, tmp, sizeof(tmp));
+    if (k < 0) { gzclose(f); return fail(SPRING_REORDER_E_IO, "gzip error in %s", path.c_str()); }
+    if (k == 0) break;
+    buf.insert(buf.end(), tmp, tmp + k);
+  }
+  gzclose(f);
+  return 0;
+}
 bool file_exists(const std::string &p) {
   FILE *f = fopen(p.c_str(), "rb");
   if (f) fclose(f);
@@ -237,40 +288,81 @@ extern "C" int spring_reorder_encode_run(const char *temp_dir, uint32_t max_read
   if ((r = spring_encoder_encode_reorder(e.c, g.c, dnaN.data(), dnaN.size(), (const uint32_t *)ordN.data(), nN, &I)))
     return r;
 
-  std::vector<uint64_t> seq_len_tid(num_thr), pos(I.n_aligned ? I.n_aligned : 1);
-  std::vector<char> noise(I.noise_bytes ? I.noise_bytes : 1), rc(I.n_aligned ? I.n_aligned : 1);
-  std::vector<uint16_t> noisepos(I.n_noisepos ? I.n_noisepos : 1), rlen(I.n_total ? I.n_total : 1);
-  std::vector<uint32_t> order(I.n_total ? I.n_total : 1);
-  std::vector<uint8_t> un(I.unaligned_bytes ? I.unaligned_bytes : 1);
-  if ((r = spring_encoder_download(e.c, nullptr, seq_len_tid.data(), pos.data(), noise.data(), noisepos.data(),
-                                   order.data(), rlen.data(), rc.data(), un.data())))
-    return r;
-  uint64_t packed_total = 0;
-  for (int t = 0; t < num_thr; t++) packed_total += seq_len_tid[t] / 4;
-  std::vector<uint8_t> packed(packed_total ? packed_total : 1);
-  std::vector<char> tail((size_t)num_thr * 4);
-  if ((r = spring_encoder_download_seq_packed(e.c, packed.data(), tail.data()))) return r;
-  uint64_t po = 0;
-  for (int t = 0; t < num_thr; t++) {  // pack_compress_seq up to the BSC call (encoder.cpp:111-150)
-    const std::string ts = "." + std::to_string(t);
-    if ((r = write_raw(base + "/read_seq.bin" + ts + ".tmp", packed.data() + po, seq_len_tid[t] / 4))) return r;
-    if ((r = write_raw(base + "/read_seq.bin" + ts + ".tail", tail.data() + 4 * t, seq_len_tid[t] % 4))) return r;
-    po += seq_len_tid[t] / 4;
-  }
-  if ((r = write_raw(base + "/read_pos.bin", pos.data(), I.n_aligned * 8))) return r;          // encoder.h:465-480
-  if ((r = write_raw(base + "/read_noise.txt", noise.data(), I.noise_bytes))) return r;         // encoder.h:365-395
-  if ((r = write_raw(base + "/read_noisepos.bin", noisepos.data(), I.n_noisepos * 2))) return r;
-  if ((r = write_raw(base + "/read_order.bin", order.data(), I.n_total * 4))) return r;         // + unaligned, :425-445
-  if ((r = write_raw(base + "/read_rev.txt", rc.data(), I.n_aligned))) return r;
-  if ((r = write_raw(base + "/read_lengths.bin", rlen.data(), I.n_total * 2))) return r;
-  if ((r = write_raw(base + "/read_unaligned.txt", un.data(), I.unaligned_bytes))) return r;
-  if ((r = write_raw(base + "/read_unaligned.txt.count", &I.len_unaligned, 8))) return r;      // encoder.h:457-460
+  if ((r = write_encoder_files(base, e.c, I, num_thr))) return r;
   remove(in1.c_str());
   if (paired_end) remove(in2.c_str());
   if (file_exists(inN)) remove(inN.c_str());    // encoder.h:601
   if (file_exists(inON)) remove(inON.c_str());  // encoder.cpp:218
   printf("Encoding done:\n%u singleton reads were aligned\n%u reads with N were aligned\n", I.matched_s,
          I.matched_N);  // encoder.h:489-491
+  if (info_out) *info_out = I;
+  return 0;
+}
+
+extern "C" int spring_encoder_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, uint32_t num_reads,
+                                  uint32_t num_reads_clean, int32_t device, spring_encoder_info *info_out) {
+  if (!temp_dir) return fail(SPRING_REORDER_E_ARG, "temp_dir is NULL");
+  if (num_thr <= 0) return fail(SPRING_REORDER_E_ARG, "num_thr must be >= 1");
+  if (num_reads < num_reads_clean) return fail(SPRING_REORDER_E_ARG, "bad read counts");
+  const std::string base(temp_dir);
+  const std::string f_dna = base + "/temp.dna", f_pos = base + "/temppos.txt", f_flag = base + "/tempflag.txt",
+                    f_order = base + "/read_order.bin", f_rc = base + "/read_rev.txt", f_len = base + "/read_lengths.bin",
+                    f_N = base + "/input_N.dna", f_oN = base + "/read_order_N.bin";  // encoder.h:580-593
+  int r;
+  std::vector<uint8_t> cnt;
+  if ((r = read_file(f_dna + ".singleton.count", cnt))) return r;  // getDataParams, encoder.cpp:158-175
+  if (cnt.size() < 4) return fail(SPRING_REORDER_E_IO, "temp.dna.singleton.count is too short");
+  uint32_t ns;
+  memcpy(&ns, cnt.data(), 4);
+  const uint32_t nN = num_reads - num_reads_clean;
+  std::vector<uint8_t> dna, order, rc, flag, pos, rlen, dna_s, order_s, dnaN, ordN;
+  std::vector<uint64_t> tid_count(num_thr);
+  for (int t = 0; t < num_thr; t++) {
+    const std::string ts = "." + std::to_string(t);
+    const size_t before = order.size();
+    if ((r = read_file(f_order + ts, order))) return r;
+    tid_count[t] = (order.size() - before) / 4;
+    if ((r = read_file(f_dna + ts, dna))) return r;
+    if ((r = read_gz(f_rc + ts, rc))) return r;
+    if ((r = read_gz(f_flag + ts, flag))) return r;
+    if ((r = read_gz(f_pos + ts, pos))) return r;
+    if ((r = read_gz(f_len + ts, rlen))) return r;
+  }
+  const uint64_t M = order.size() / 4;
+  if (rc.size() != M || flag.size() != M || pos.size() != M * 8 || rlen.size() != M * 2)
+    return fail(SPRING_REORDER_E_IO, "per-tid streams disagree on the number of reads");
+  if ((uint64_t)M + ns != num_reads_clean) return fail(SPRING_REORDER_E_ARG, "streams hold %llu + %u reads, expected %u clean",
+                                                      (unsigned long long)M, ns, num_reads_clean);
+  if ((r = read_file(f_dna + ".singleton", dna_s))) return r;
+  if ((r = read_file(f_order + ".singleton", order_s))) return r;
+  if (order_s.size() < (size_t)ns * 4) return fail(SPRING_REORDER_E_IO, "read_order.bin.singleton is too short");
+  if (nN) {
+    if ((r = read_file(f_N, dnaN))) return r;
+    if ((r = read_file(f_oN, ordN))) return r;
+    if (ordN.size() < (size_t)nN * 4) return fail(SPRING_REORDER_E_IO, "read_order_N.bin is too short");
+  }
+  EncGuard e;
+  if ((r = spring_encoder_create(device, &e.c))) return r;
+  spring_encoder_info I;
+  r = spring_encoder_encode_host(e.c, max_readlen, num_thr, tid_count.data(), dna.data(), dna.size(),
+                                 (const uint32_t *)order.data(), (const char *)rc.data(), (const char *)flag.data(),
+                                 (const int64_t *)pos.data(), (const uint16_t *)rlen.data(), dna_s.data(), dna_s.size(),
+                                 (const uint32_t *)order_s.data(), ns, dnaN.data(), dnaN.size(),
+                                 (const uint32_t *)ordN.data(), nN, &I);
+  if (r) return r;
+  // inputs are consumed (encoder.h:412-422, :556, :565, :601; encoder.cpp:163-167, :218) before the outputs of the
+  // same name (read_order.bin, read_rev.txt, read_lengths.bin) are written
+  for (int t = 0; t < num_thr; t++) {
+    const std::string ts = "." + std::to_string(t);
+    for (const std::string &f : {f_order, f_dna, f_rc, f_flag, f_pos, f_len}) remove((f + ts).c_str());
+  }
+  remove((f_dna + ".singleton").c_str());
+  remove((f_dna + ".singleton.count").c_str());
+  remove((f_order + ".singleton").c_str());
+  if (file_exists(f_N)) remove(f_N.c_str());
+  if (file_exists(f_oN)) remove(f_oN.c_str());
+  if ((r = write_encoder_files(base, e.c, I, num_thr))) return r;
+  printf("Encoding done:\n%u singleton reads were aligned\n%u reads with N were aligned\n", I.matched_s, I.matched_N);
   if (info_out) *info_out = I;
   return 0;
 }

@@ -233,3 +233,53 @@ def test_fastq_to_encoder_streams_end_to_end(paired):
     for k, s in enumerate(un):
         assert allreads[int(e["order"][na + k])] == s
     assert sorted(e["order"].tolist()) == list(range(len(allreads)))
+
+
+@pytest.mark.parametrize("recompress", [False, True])
+def test_encoder_run_file_contract_after_reorder_run(tmp_path, recompress):
+    """spring_encoder_run as a drop-in for call_encoder: it consumes the per-tid files a reorder stage left in
+    temp_dir (here spring_reorder_run's; with recompress=True the gzip members are rewritten with real deflate
+    blocks, as boost::iostreams::gzip_compressor produces them) and leaves encoder_main's files."""
+    import ctypes as C
+    import gzip
+    import os
+
+    import spring_amd
+    from spring_amd import _lib
+    name, T, K = "var2k", 3, 12
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    Nreads = make_N_reads(read_strings(read, ln), 250, 8)
+    dnaN = po.pack_dnaN(Nreads)
+    order_N = interleave_order_N(n, len(Nreads), 18)
+    d = str(tmp_path)
+    open(os.path.join(d, "input_clean_1.dna"), "wb").write(dna)
+    open(os.path.join(d, "input_N.dna"), "wb").write(dnaN)
+    open(os.path.join(d, "read_order_N.bin"), "wb").write(order_N.tobytes())
+    L_ = _lib.lib()
+    o = spring_amd.ReorderOpts(num_chains=K, num_thr=T).to_c()
+    assert L_.spring_reorder_run(d.encode(), L, T, 0, n, 0, C.byref(o)) == 0, L_.spring_reorder_last_error()
+    if recompress:
+        for t in range(T):
+            for f in ("read_rev.txt", "tempflag.txt", "temppos.txt", "read_lengths.bin"):
+                p = os.path.join(d, "%s.%d" % (f, t))
+                raw = gzip.decompress(open(p, "rb").read())
+                open(p, "wb").write(gzip.compress(raw, 6))
+    info = _lib.EncoderInfo()
+    rc = L_.spring_encoder_run(d.encode(), L, T, n + len(Nreads), n, -1, C.byref(info))
+    assert rc == 0, L_.spring_reorder_last_error()
+    want = po.encode(read, ln, L, po.reorder_rounds(read, ln, L, K, T), num_thr=T, dnaN=dnaN, order_N=order_N)
+    rd = lambda f: open(os.path.join(d, f), "rb").read()  # noqa: E731
+    assert rd("read_pos.bin") == want["pos"].tobytes()
+    assert rd("read_noise.txt") == want["noise"]
+    assert rd("read_noisepos.bin") == want["noisepos"].tobytes()
+    assert rd("read_order.bin") == want["order"].tobytes()
+    assert rd("read_rev.txt") == want["rc"].tobytes()
+    assert rd("read_lengths.bin") == want["rlen"].tobytes()
+    assert rd("read_unaligned.txt") == want["unaligned"]
+    assert int.from_bytes(rd("read_unaligned.txt.count"), "little") == want["len_unaligned"]
+    assert info.matched_s == want["matched_s"] and info.matched_N == want["matched_N"]
+    left = sorted(os.listdir(d))
+    assert not [f for f in left if f.startswith(("temp", "input_", "read_order_N"))], left
+    for t in range(T):
+        assert not os.path.exists(os.path.join(d, "read_order.bin.%d" % t))
