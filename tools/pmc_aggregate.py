@@ -1,0 +1,52 @@
+"""tools/pmc_aggregate.py <pmc_dir> <reads> <out.json>: per-kernel totals of the rocprofv3 --pmc passes written by
+tools/pmc_probe.sh (one sub-directory per pass: fetch, write, sq, tcc, grbm), in the shape bench.py reads
+(profiles/pmc_latest.json).  FETCH_SIZE / WRITE_SIZE are in KiB-units of the guide: bytes = value * 1024
+(calibrated on tools/random_gather_bench.hip: one 64-byte request per random access, no x2 correction)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+pmc_dir, reads, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n.replace("sr::k_search<false, false>", "sr::k_search<false>")
+
+
+kern = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+dur = collections.defaultdict(lambda: collections.defaultdict(float))
+for p in ("fetch", "write", "sq", "tcc", "grbm"):
+    d = os.path.join(pmc_dir, p)
+    if not os.path.isdir(d):
+        continue
+    for r in csv.DictReader(open(os.path.join(d, "pmc_counter_collection.csv"))):
+        k = short(r["Kernel_Name"])
+        kern[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if p == "fetch":
+            launches[k].add(r["Dispatch_Id"])
+    for r in csv.DictReader(open(os.path.join(d, "pmc_kernel_trace.csv"))):
+        dur[short(r["Kernel_Name"])][p] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+res = {"reads": reads, "read_len": 150, "chains": 65536,
+       "source": "tools/pmc_probe.sh (5 separate rocprofv3 --pmc passes) aggregated by tools/pmc_aggregate.py", "kernels": {}}
+for k, c in kern.items():
+    if not ("k_search" in k or "k_apply" in k):
+        continue
+    n = max(len(launches[k]), 1)
+    e = dict(launches=n, total_us_by_pass={p: round(v, 1) for p, v in dur[k].items()})
+    e.update(c)
+    e["fetch_bytes_per_launch"] = c.get("FETCH_SIZE", 0) * 1024 / n
+    e["write_bytes_per_launch"] = c.get("WRITE_SIZE", 0) * 1024 / n
+    e["rdreq_per_launch"] = c.get("TCC_EA0_RDREQ_sum", 0) / n
+    hm = c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)
+    e["l2_hit_rate"] = c.get("TCC_HIT_sum", 0) / hm if hm else None
+    e["wait_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
+    res["kernels"][k] = e
+json.dump(res, open(out, "w"), indent=1)
+for k, e in res["kernels"].items():
+    print(k, "launches", e["launches"], "fetch MB/launch %.1f" % (e["fetch_bytes_per_launch"] / 1e6),
+          "write MB/launch %.1f" % (e["write_bytes_per_launch"] / 1e6), "rdreq M/launch %.2f" % (e["rdreq_per_launch"] / 1e6))
