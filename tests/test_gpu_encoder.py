@@ -283,3 +283,12 @@ def test_encoder_run_file_contract_after_reorder_run(tmp_path, recompress):
     assert not [f for f in left if f.startswith(("temp", "input_", "read_order_N"))], left
     for t in range(T):
         assert not os.path.exists(os.path.join(d, "read_order.bin.%d" % t))
+
+
+@pytest.mark.parametrize("name", ["syn5k_150", "var2k"])
+def test_split_table_alignment_kernel_agrees(name, monkeypatch):
+    """SPRING_ENC_SPLIT_TABLES forces the one-thread-per-window kernel (the one used when the two dictionary
+    windows differ in length, max_readlen <= 50) on data that normally takes the merged-table kernel."""
+    monkeypatch.setenv("SPRING_ENC_SPLIT_TABLES", "1")
+    got, want, info, _, _ = _run(name, 16, 2, nN=300, deep=1200, seed=6)
+    same_encoding(got, want, name)
