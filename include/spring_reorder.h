@@ -194,6 +194,15 @@ int spring_order_correct(uint32_t *order, uint64_t m, const uint32_t *order_N, u
 int spring_order_pe_encode(const uint32_t *order, uint32_t n, uint32_t *new_order, double *kernel_ms);
 
 /* ---------------------------------------------------------------------------
+ * reorder-only output.  Output record k = 4-line record order[k] of the FASTQ text (host
+ * buffers; records keep their bytes, a missing final newline is added).  With order = the encoder stage's
+ * read_order.bin (single-end) this is the order in which the decompressor emits reads without
+ * --preserve-order.  out == NULL: *out_bytes receives the size needed.
+ */
+int spring_fastq_reorder(const uint8_t *fastq, size_t nbytes, const uint32_t *order, uint32_t n, uint8_t *out,
+                         size_t out_cap, size_t *out_bytes, double *kernel_ms);
+
+/* ---------------------------------------------------------------------------
  * Synthetic input for bench.py / tests: uniform random
  * genome of G bases, n reads of length L at uniform positions, i.i.d.
  * substitutions at rate err_ppm/1e6, 50 % reverse complemented, no N.  A

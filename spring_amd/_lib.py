@@ -15,6 +15,7 @@ EXPORTS = [
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
     "spring_reorder_load_fastq", "spring_reorder_fastq_N",
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct", "spring_order_pe_encode",
+    "spring_fastq_reorder",
     "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
     "spring_encoder_create", "spring_encoder_destroy", "spring_encoder_encode_reorder", "spring_encoder_download",
     "spring_encoder_download_seq_packed", "spring_encoder_get_info", "spring_reorder_encode_run", "spring_encoder_encode_host", "spring_encoder_run",
@@ -104,6 +105,8 @@ def lib():
     L.spring_reorder_fastq_N.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_uint32)]
     L.spring_order_invert_se.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
     L.spring_order_invert_pe.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
+    L.spring_fastq_reorder.argtypes = [u8p, C.c_size_t, vp, C.c_uint32, u8p, C.c_size_t, C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_double)]
     L.spring_order_pe_encode.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_double)]
     L.spring_order_correct.argtypes = [vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.spring_synth_dna_bytes.restype = C.c_size_t

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspring_reorder_hip.so")
 SOURCES = ["reorder_kernels.hip", "reorder_pipeline.cpp", "reorder_files.cpp", "order_ops.hip", "fastq_kernels.hip",
-           "encoder.hip"]
+           "encoder.hip", "fastq_reorder.hip"]
 HEADERS = ["reorder_device.h", "reorder_internal.h", "synth_common.h", "call_reorder.h"]
 
 

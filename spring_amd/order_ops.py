@@ -44,3 +44,17 @@ def pe_encode(order):
     ms = C.c_double()
     _chk(_lib.lib().spring_order_pe_encode(order.ctypes.data, len(order), out.ctypes.data, C.byref(ms)))
     return out[:len(order)], ms.value
+
+
+def fastq_reorder(fastq: bytes, order):
+    """the 4-line records of `fastq` in the order order[0], order[1], ... -> (bytes, kernel ms)."""
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    buf = np.frombuffer(fastq, dtype=np.uint8)
+    L = _lib.lib()
+    need, ms = C.c_size_t(), C.c_double()
+    _chk(L.spring_fastq_reorder(buf.ctypes.data if len(buf) else None, len(buf), order.ctypes.data if len(order) else None,
+                                len(order), None, 0, C.byref(need), None))
+    out = np.zeros(max(need.value, 1), np.uint8)
+    _chk(L.spring_fastq_reorder(buf.ctypes.data if len(buf) else None, len(buf), order.ctypes.data if len(order) else None,
+                                len(order), out.ctypes.data, need.value, C.byref(need), C.byref(ms)))
+    return out[:need.value].tobytes(), ms.value

@@ -107,3 +107,61 @@ def test_fastq_frontend_errors():
     with spring_amd.ReorderStage() as s:
         with pytest.raises(spring_amd.ReorderError, match="paired files do not match"):
             s.load_fastq(_synth_fastq(6, 10, 50, 50), _synth_fastq(7, 11, 50, 50))
+
+
+# ------------------------------------------------------------------ row f4: reorder-only output
+
+def _py_reorder(text, order):
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines = lines[:-1]
+    recs = [b"\n".join(lines[4 * i:4 * i + 4]) + b"\n" for i in range(len(lines) // 4)]
+    return b"".join(recs[int(k)] for k in order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,crlf,final_nl", [(1, False, True), (7, False, False), (500, True, True), (20000, False, True)])
+def test_fastq_reorder_matches_python(n, crlf, final_nl):
+    from spring_amd import order_ops as oo
+    t = _synth_fastq(n + 5, n, 1, 200, crlf=crlf, final_newline=final_nl)
+    rng = np.random.default_rng(n)
+    for order in (rng.permutation(n), rng.integers(0, n, max(n // 3, 1)), np.arange(n)[::-1]):
+        got, _ = oo.fastq_reorder(t, order.astype(np.uint32))
+        assert got == _py_reorder(t, order)
+    with pytest.raises(Exception):
+        oo.fastq_reorder(t, np.array([n], np.uint32))
+
+
+@pytest.mark.gpu
+def test_reorder_only_pipeline_external_validity():
+    """FASTQ -> front end -> reorder -> encoder -> read_order.bin -> reordered FASTQ: same multiset of records,
+    and record k of the output is the read the encoder streams decode at position k."""
+    import spring_amd
+    from helpers import decode_reads
+    from spring_amd import order_ops as oo
+    from spring_amd.encoder import EncoderStage
+    rng = np.random.default_rng(5)
+    G, L, n = 20000, 100, 6000
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, G)]
+    recs = []
+    for i in range(n):
+        p = int(rng.integers(0, G - L))
+        s = genome[p:p + L].copy()
+        if rng.random() < 0.05:
+            s[int(rng.integers(0, L))] = ord("N")
+        recs.append(b"@id%d/x\n%s\n+\n%s\n" % (i, s.tobytes(), bytes(33 + (i + np.arange(L)) % 40)))
+    text = b"".join(recs)
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=16, num_thr=2)) as st:
+        st.load_fastq(text)
+        st.run()
+        dnaN, order_N = st.fastq_N(0)
+        with EncoderStage() as enc:
+            enc.encode(st, dnaN, order_N)
+            e = enc.streams()
+    out, _ = oo.fastq_reorder(text, e["order"])
+    got = [b"\n".join(x) + b"\n" for x in zip(*[iter(out.split(b"\n")[:-1])] * 4)]
+    assert sorted(got) == sorted(recs) and len(got) == n
+    assert got == [recs[int(k)] for k in e["order"]]
+    dec = decode_reads(e)   # aligned reads by original position
+    for k in range(len(e["pos"])):
+        assert got[k].split(b"\n")[1].decode() == dec[int(e["order"][k])]

@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     from spring_amd import _lib
     hdr = (open(os.path.join(ROOT, "include", "spring_reorder.h")).read()
            + open(os.path.join(ROOT, "include", "spring_encoder.h")).read())
-    declared = set(re.findall(r"\b(spring_(?:reorder|synth|order|encoder)_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(spring_(?:reorder|synth|order|encoder|fastq)_\w+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     L = _lib.lib()
     for name in sorted(declared):
