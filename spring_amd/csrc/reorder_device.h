@@ -67,7 +67,7 @@ struct DevParams {
   uint32_t numkeys[2];
   const uint4 *fpt[2];        // buckets [tag x4 | payload x4], 32 B each
   const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key (multi-read bins)
-  uint64_t bmask[2];
+  int bshift[2];              // bucket = hash >> bshift (tables have 2^(64-bshift) buckets, at least 2)
   const uint32_t *ids[2];
   // shared mutable state
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
@@ -93,12 +93,12 @@ void launch_unpack(hipStream_t st, const uint8_t *dna, const uint64_t *off, uint
 void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int dend, uint32_t *flag);
 void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
                  int S, int dstart, int dend, uint64_t *keys, uint32_t *vals);
-void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask,
+void launch_tab_insert(hipStream_t st, const uint64_t *uhash /* sorted unique mix64(key) */, const uint32_t *ustart, const uint32_t *ucount,
+                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, int bshift,
                        uint32_t *deep, uint32_t *ndeep);
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
                       ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken);
-void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
+void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count);
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);

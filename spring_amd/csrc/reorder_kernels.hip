@@ -87,15 +87,25 @@ __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uin
 //         against the read's own window (as the reference does with the first read of a bin,
 //         reorder.h:282-285), so the hot path is bucket -> read: no offsets/ids hops.
 //   single = 0: pay indexes urec, a 16-byte record {key, start | count << 32}.
+// bucket = top bits of the hash (the dictionary is built in hash order, so unique keys arrive at
+// k_tab_insert in bucket order and their writes stream), fingerprint = low 31 bits
 __device__ __forceinline__ uint32_t fp31_of(uint64_t h) {
-  const uint32_t f = (uint32_t)(h >> 33);
+  const uint32_t f = (uint32_t)h & 0x7fffffffu;
   return f ? f : 1u;
 }
+__device__ __forceinline__ uint64_t bucket_of(uint64_t h, int bshift) { return h >> bshift; }
+__device__ __forceinline__ uint64_t bucket_mask(int bshift) { return (1ull << (64 - bshift)) - 1; }
+// mix64 is a bijection (murmur3 finaliser): the key is recovered from the sorted hashes
+__device__ __forceinline__ uint64_t unmix64(uint64_t x) {
+  x ^= x >> 33; x *= 0x9cb4b2f8129337dbull; x ^= x >> 33; x *= 0x4f74430c22a54005ull; x ^= x >> 33;
+  return x;
+}
 // kind of the (skip+1)-th slot whose fingerprint matches: 0 = none (key absent), 1 = multi, 2 = single
-__device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, uint64_t bmask, uint64_t h, int skip,
+__device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshift, uint64_t h, int skip,
                                         uint32_t &pay) {
   const uint32_t fp = fp31_of(h);
-  uint64_t b = h & bmask;
+  const uint64_t bmask = bucket_mask(bshift);
+  uint64_t b = bucket_of(h, bshift);
   for (;;) {
     const uint4 t = fpt[b * 2], x = fpt[b * 2 + 1];
 #define SLOT(T, X)                                              \
@@ -159,27 +169,27 @@ __global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__res
   if (offb && li + 1 < S) v |= r[li + 1] << (64 - offb);
   if (nbits < 64) v &= (1ull << nbits) - 1;
   uint32_t o = slot ? slot[i] : i;
-  keys[o] = v;
+  keys[o] = mix64(v);  // the dictionary is sorted by hash: equal keys stay adjacent, buckets come out in order
   vals[o] = i;
 }
 
 // ------------------------------------------------ K3 table insert (bitset_util.h:122-217)
 // one thread per unique key: writes its {key,start,count} record and claims a bucket slot.
-__global__ void k_tab_insert(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ustart,
+__global__ void k_tab_insert(const uint64_t *__restrict__ uhash, const uint32_t *__restrict__ ustart,
                              const uint32_t *__restrict__ ucount, const uint32_t *__restrict__ ids,
-                             uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, uint64_t bmask,
+                             uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, int bshift,
                              uint32_t *__restrict__ deep, uint32_t *__restrict__ ndeep) {
   uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= numkeys) return;
-  const uint64_t key = ukeys[u];
+  const uint64_t h = uhash[u], key = unmix64(h);
+  const uint64_t bmask = bucket_mask(bshift);
   const uint32_t st = ustart[u], cn = ucount[u];
   if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
   urec[u] = make_ulonglong2(key, (uint64_t)st | ((uint64_t)cn << 32));
-  const uint64_t h = mix64(key);
   const bool single = cn == 1;
   const uint32_t tag = (fp31_of(h) << 1) | (single ? 1u : 0u);
   const uint32_t pay = single ? ids[st] : u;
-  uint64_t b = h & bmask;
+  uint64_t b = bucket_of(h, bshift);
   for (;;) {
     uint32_t *bk = fpt + b * 8;
     for (int sl = 0; sl < 4; sl++) {
@@ -213,7 +223,7 @@ __global__ void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *_
 
 // test hook: start/count of the bin of each key; single-read bins report count = 1 | 0x80000000
 // and the read id in start[]
-__global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, uint64_t bmask,
+__global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, int bshift,
                               const uint64_t *__restrict__ reads, int S, int dstart, int klen2,
                               const uint64_t *__restrict__ keys, uint32_t nkeys, uint32_t *__restrict__ start,
                               uint32_t *__restrict__ count) {
@@ -223,7 +233,7 @@ __global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *_
   uint32_t s = 0, c = 0xffffffffu;
   for (int skip = 0;; skip++) {
     uint32_t pay;
-    const int kind = tab_find(fpt, bmask, h, skip, pay);
+    const int kind = tab_find(fpt, bshift, h, skip, pay);
     if (kind == 0) break;
     if (kind == 1) {
       const ulonglong2 r = urec[pay];
@@ -594,7 +604,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   const uint4 *__restrict__ fpt = P.fpt[l];
   const ulonglong2 *__restrict__ urec = P.urec[l];
-  const uint64_t bmask = P.bmask[l];
+  const int bshift = P.bshift[l];
   const uint32_t *__restrict__ ids = P.ids[l];
   const bool have_keys = P.numkeys[l] > 0;
   const uint64_t *sx = rev ? srev : sref;
@@ -632,7 +642,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
     };
     for (int skip = 0;; skip++) {
       uint32_t pay;
-      const int kind = tab_find(fpt, bmask, hsh, skip, pay);
+      const int kind = tab_find(fpt, bshift, hsh, skip, pay);
       if (kind == 0) break;  // key absent
       if (kind == 2) {       // single-read bin: pay is the read id
         // a taken read contributes nothing whether this slot is the key's bin or a fingerprint collision:
@@ -1063,22 +1073,22 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
   hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
 }
 void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, uint64_t bmask,
+                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, int bshift,
                        uint32_t *deep, uint32_t *ndeep) {
   if (!numkeys) return;
   hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
-                     reinterpret_cast<uint32_t *>(fpt), urec, bmask, deep, ndeep);
+                     reinterpret_cast<uint32_t *>(fpt), urec, bshift, deep, ndeep);
 }
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
                       ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken) {
   if (!ndeep_host) return;
   hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 256), dim3(256), 0, st, deep, ndeep, urec, ids, taken);
 }
-void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, uint64_t bmask,
+void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count) {
   if (!nkeys) return;
-  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bmask, reads, S, dstart,
+  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bshift, reads, S, dstart,
                      2 * (dend - dstart + 1), keys, nkeys, start, count);
 }
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {

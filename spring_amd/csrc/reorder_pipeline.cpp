@@ -105,7 +105,7 @@ enum { ST_CREATED = 0, ST_LOADED = 1, ST_DICT = 2, ST_CHAINS = 3, ST_FINAL = 4 }
 struct DictDev {
   int start = 0, end = 0;
   uint32_t numkeys = 0, numreads = 0;
-  uint64_t bmask = 0;
+  int bshift = 63;  // bucket = hash >> bshift
   uint4 *fpt = nullptr;
   ulonglong2 *urec = nullptr;
   uint32_t *ids = nullptr;
@@ -647,7 +647,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     d.numreads = m;
     d.numkeys = 0;
     if (m == 0) {
-      d.bmask = 0;
+      d.bshift = 63;
       DMALLOC(d.fpt, 64);
       HIPCHK(hipMemsetAsync(d.fpt, 0, 64, st));
       DMALLOC(d.urec, 16);
@@ -665,8 +665,9 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     launch_keys(st, ctx->d_reads, ctx->d_lens, ctx->uniform ? nullptr : d_slot, n, ctx->S, d.start, d.end, k_in, v_in);
     HIPCHK(hipGetLastError());
     DBG_T("k_keys");
-    const unsigned end_bit = (unsigned)(2 * (d.end - d.start + 1));
-    // stable LSD radix sort: equal keys keep ascending read id (bitset_util.h:192-210)
+    const unsigned end_bit = 64;  // k_keys emits mix64(key): all 64 bits are significant
+    // stable LSD radix sort: equal keys (equal hashes: mix64 is a bijection) keep ascending read id
+    // (bitset_util.h:192-210), and the unique keys come out in bucket order for k_tab_insert
     tmp_bytes = 0;
     HIPCHK(sort_pairs(st, nullptr, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
     DMALLOC(d_tmp, tmp_bytes);
@@ -694,8 +695,9 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     DMALLOC(d_tmp, tmp_bytes);
     HIPCHK(excl_scan_u32(st, d_tmp, tmp_bytes, cnt, ustart, numkeys));
     // exact map: 4-slot 32-byte fingerprint buckets (load <= 0.4) + 16-byte records
-    const uint64_t nb = pow2ceil(std::max<uint64_t>(1, ((uint64_t)numkeys * 10 + 15) / 16));
-    d.bmask = nb - 1;
+    const uint64_t nb = pow2ceil(std::max<uint64_t>(2, ((uint64_t)numkeys * 10 + 15) / 16));
+    d.bshift = 64;
+    for (uint64_t v = nb; v > 1; v >>= 1) d.bshift--;
     DBG_T("scan");
     DMALLOC(d.fpt, nb * 32);
     DMALLOC(d.urec, (size_t)numkeys * 16);
@@ -706,7 +708,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     DMALLOC(d.deep, ((size_t)m / DEEP_BIN + 1) * 4);
     DMALLOC(d.d_ndeep, 16);
     HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 4, st));
-    launch_tab_insert(st, k_in, ustart, cnt, d.ids, numkeys, d.fpt, d.urec, d.bmask, d.deep, d.d_ndeep);
+    launch_tab_insert(st, k_in, ustart, cnt, d.ids, numkeys, d.fpt, d.urec, d.bshift, d.deep, d.d_ndeep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&d.ndeep, d.d_ndeep, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -735,7 +737,7 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
   std::vector<uint32_t> hs(nkeys), hc(nkeys), hids(d.numreads);
   if (nkeys) {
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)nkeys * 8, hipMemcpyHostToDevice, ctx->st));
-    launch_dict_lookup(ctx->st, d.fpt, d.urec, d.bmask, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
+    launch_dict_lookup(ctx->st, d.fpt, d.urec, d.bshift, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
     HIPCHK(hipMemcpyAsync(hs.data(), ds, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(hc.data(), dc, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
   }
@@ -781,7 +783,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   P.uniform_len = ctx->uniform ? 1 : 0;
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
-    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bmask[l] = ctx->dict[l].bmask;
+    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bshift[l] = ctx->dict[l].bshift;
     P.ids[l] = ctx->dict[l].ids;
   }
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
@@ -888,7 +890,7 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   P.uniform_len = ctx->uniform ? 1 : 0;
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
-    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bmask[l] = ctx->dict[l].bmask;
+    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bshift[l] = ctx->dict[l].bshift;
     P.ids[l] = ctx->dict[l].ids;
   }
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
