@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libspring_reorder_hip.so")
+LIB_PATH = os.environ.get("SPRING_AMD_LIB") or os.path.join(HERE, "lib", "libspring_reorder_hip.so")  # env: A/B runs
 
 EXPORTS = [
     "spring_reorder_default_opts", "spring_reorder_last_error", "spring_reorder_trim_pool", "spring_reorder_run", "spring_reorder_create",

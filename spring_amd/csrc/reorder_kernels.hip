@@ -174,22 +174,39 @@ __global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__res
 }
 
 // ------------------------------------------------ K3 table insert (bitset_util.h:122-217)
-// one thread per unique key: writes its {key,start,count} record and claims a bucket slot.
+// one thread per unique key, keys sorted by hash = by bucket.  Pass 0 (OVERFLOW = false): the first four keys
+// of a bucket take its slots 0..3 directly (rank = number of predecessors with the same bucket, found by
+// looking back at most 4 entries) -- no atomics, streaming writes; every key writes its {key,start,count}
+// record.  Pass 1 (OVERFLOW = true): the few keys of rank >= 4 (about 1 % at load 0.4) claim the next free
+// slot further on with CAS, after pass 0 has placed all native keys.  A lookup scans slots in order and
+// stops at the first empty one, so which free slot an overflow key gets does not matter.
+template <bool OVERFLOW>
 __global__ void k_tab_insert(const uint64_t *__restrict__ uhash, const uint32_t *__restrict__ ustart,
                              const uint32_t *__restrict__ ucount, const uint32_t *__restrict__ ids,
                              uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, int bshift,
                              uint32_t *__restrict__ deep, uint32_t *__restrict__ ndeep) {
   uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= numkeys) return;
-  const uint64_t h = uhash[u], key = unmix64(h);
-  const uint64_t bmask = bucket_mask(bshift);
+  const uint64_t h = uhash[u];
+  const uint64_t b0 = bucket_of(h, bshift);
+  int rank = 0;
+  while (rank < 4 && u > (uint32_t)rank && bucket_of(uhash[u - 1 - rank], bshift) == b0) rank++;
+  if (OVERFLOW != (rank >= 4)) return;
   const uint32_t st = ustart[u], cn = ucount[u];
-  if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
-  urec[u] = make_ulonglong2(key, (uint64_t)st | ((uint64_t)cn << 32));
   const bool single = cn == 1;
   const uint32_t tag = (fp31_of(h) << 1) | (single ? 1u : 0u);
   const uint32_t pay = single ? ids[st] : u;
-  uint64_t b = bucket_of(h, bshift);
+  if (!OVERFLOW) {
+    if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
+    urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
+    fpt[b0 * 8 + rank] = tag;
+    fpt[b0 * 8 + 4 + rank] = pay;
+    return;
+  }
+  if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;
+  urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
+  const uint64_t bmask = bucket_mask(bshift);
+  uint64_t b = (b0 + 1) & bmask;  // the home bucket is full by construction
   for (;;) {
     uint32_t *bk = fpt + b * 8;
     for (int sl = 0; sl < 4; sl++) {
@@ -1076,7 +1093,9 @@ void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *us
                        const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, int bshift,
                        uint32_t *deep, uint32_t *ndeep) {
   if (!numkeys) return;
-  hipLaunchKernelGGL(k_tab_insert, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
+  hipLaunchKernelGGL(k_tab_insert<false>, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
+                     reinterpret_cast<uint32_t *>(fpt), urec, bshift, deep, ndeep);
+  hipLaunchKernelGGL(k_tab_insert<true>, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
                      reinterpret_cast<uint32_t *>(fpt), urec, bshift, deep, ndeep);
 }
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
