@@ -25,5 +25,15 @@ struct reorder_params {          // subset of spring::compression_params (util.h
 void call_reorder(const std::string &temp_dir, const reorder_params &cp,
                   const spring_reorder_opts *opts = nullptr);
 
+// Mirror of void spring::call_encoder(const std::string &temp_dir, compression_params &cp)
+// (reference src/call_template_functions.h:11, .cpp:65-142): consumes the files call_reorder left in temp_dir;
+// num_reads = cp.num_reads (clean + N reads).  Throws std::runtime_error ("Wrong bitset size." when
+// 3 * max_readlen does not fit 1536 bits).  read_seq.bin.<tid> is left as .tmp + .tail for the caller's BSC step.
+void call_encoder(const std::string &temp_dir, const reorder_params &cp, uint32_t num_reads, int device = -1);
+
+// Both stages back to back with the intermediate streams kept in HBM (spring.cpp:150-160).
+void call_reorder_encoder(const std::string &temp_dir, const reorder_params &cp, uint32_t num_reads,
+                          const spring_reorder_opts *opts = nullptr);
+
 }  // namespace spring_amd
 #endif

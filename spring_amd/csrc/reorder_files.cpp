@@ -375,4 +375,19 @@ void call_reorder(const std::string &temp_dir, const reorder_params &cp, const s
                              cp.num_reads_clean[0], cp.num_reads_clean[1], opts);
   if (r != 0) throw std::runtime_error(std::string("spring_reorder_run: ") + spring_reorder_last_error());
 }
+void call_encoder(const std::string &temp_dir, const reorder_params &cp, uint32_t num_reads, int device) {
+  const size_t bitset_size_encoder = (3 * (size_t)cp.max_readlen - 1) / 64 * 64 + 64;  // call_template_functions.cpp:66
+  if (cp.max_readlen == 0 || bitset_size_encoder > 1536) throw std::runtime_error("Wrong bitset size.");
+  int r = spring_encoder_run(temp_dir.c_str(), cp.max_readlen, cp.num_thr, num_reads,
+                             cp.num_reads_clean[0] + (cp.paired_end ? cp.num_reads_clean[1] : 0), device, nullptr);
+  if (r != 0) throw std::runtime_error(std::string("spring_encoder_run: ") + spring_reorder_last_error());
+}
+void call_reorder_encoder(const std::string &temp_dir, const reorder_params &cp, uint32_t num_reads,
+                          const spring_reorder_opts *opts) {
+  const size_t bitset_size_reorder = (2 * (size_t)cp.max_readlen - 1) / 64 * 64 + 64;
+  if (cp.max_readlen == 0 || bitset_size_reorder > 1024) throw std::runtime_error("Wrong bitset size.");
+  int r = spring_reorder_encode_run(temp_dir.c_str(), cp.max_readlen, cp.num_thr, cp.paired_end ? 1 : 0,
+                                    cp.num_reads_clean[0], cp.num_reads_clean[1], num_reads, opts, nullptr);
+  if (r != 0) throw std::runtime_error(std::string("spring_reorder_encode_run: ") + spring_reorder_last_error());
+}
 }  // namespace spring_amd

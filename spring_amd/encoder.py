@@ -85,3 +85,30 @@ class EncoderStage:
         _chk(self._L.spring_encoder_download_seq_packed(self._h, packed.ctypes.data, tail.ctypes.data))
         tails = [tail[4 * t:4 * t + int(sl[t]) % 4].tobytes().decode() for t in range(self.num_thr)]
         return packed[:total].tobytes(), tails
+
+
+def call_encoder(temp_dir: str, cp, num_reads: int, device: int = -1):
+    """spring::call_encoder(temp_dir, cp) (reference call_template_functions.cpp:65-142): consumes the files a
+    reorder stage left in temp_dir, writes encoder_main's outputs.  cp is a reorder.CompressionParams,
+    num_reads = cp.num_reads of the reference (clean + N reads).  -> info dict."""
+    bitset_size = (3 * cp.max_readlen - 1) // 64 * 64 + 64
+    if cp.max_readlen <= 0 or bitset_size > 1536:
+        raise ReorderError("Wrong bitset size.")
+    info = _lib.EncoderInfo()
+    n_clean = cp.num_reads_clean[0] + (cp.num_reads_clean[1] if cp.paired_end else 0)
+    _chk(_lib.lib().spring_encoder_run(temp_dir.encode(), cp.max_readlen, cp.num_thr, num_reads, n_clean, device,
+                                       C.byref(info)))
+    return info.asdict()
+
+
+def call_reorder_encoder(temp_dir: str, cp, num_reads: int, opts=None):
+    """call_reorder + call_encoder back to back with the intermediate streams kept in HBM (spring.cpp:150-160)."""
+    from .reorder import ReorderOpts
+    if cp.max_readlen <= 0 or (2 * cp.max_readlen - 1) // 64 * 64 + 64 > 1024:
+        raise ReorderError("Wrong bitset size.")
+    o = (opts or ReorderOpts(num_thr=cp.num_thr)).to_c()
+    info = _lib.EncoderInfo()
+    _chk(_lib.lib().spring_reorder_encode_run(temp_dir.encode(), cp.max_readlen, cp.num_thr, int(cp.paired_end),
+                                              cp.num_reads_clean[0], cp.num_reads_clean[1], num_reads, C.byref(o),
+                                              C.byref(info)))
+    return info.asdict()

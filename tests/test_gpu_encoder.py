@@ -292,3 +292,31 @@ def test_split_table_alignment_kernel_agrees(name, monkeypatch):
     monkeypatch.setenv("SPRING_ENC_SPLIT_TABLES", "1")
     got, want, info, _, _ = _run(name, 16, 2, nN=300, deep=1200, seed=6)
     same_encoding(got, want, name)
+
+
+def test_python_mirrors_of_call_encoder(tmp_path):
+    """spring_amd.encoder.call_encoder / call_reorder_encoder: same files either way, error behaviour of the
+    reference's switch ("Wrong bitset size.")."""
+    import os
+
+    import spring_amd
+    from spring_amd.encoder import call_encoder, call_reorder_encoder
+    from spring_amd.reorder import CompressionParams, ReorderError
+    dna, n, L = named_set("syn2k_100")
+    outs = []
+    for mode in (0, 1):
+        d = os.path.join(str(tmp_path), "m%d" % mode)
+        os.makedirs(d)
+        open(os.path.join(d, "input_clean_1.dna"), "wb").write(dna)
+        cp = CompressionParams(L, [n, 0], num_thr=2)
+        opts = spring_amd.ReorderOpts(num_chains=8, num_thr=2)
+        if mode == 0:
+            spring_amd.call_reorder(d, cp, opts)
+            info = call_encoder(d, cp, n)
+        else:
+            info = call_reorder_encoder(d, cp, n, opts)
+        outs.append({f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))})
+        assert info["n_total"] == n
+    assert outs[0] == outs[1] and "read_pos.bin" in outs[0] and "read_seq.bin.1.tmp" in outs[0]
+    with pytest.raises(ReorderError):
+        call_encoder(str(tmp_path), CompressionParams(600, [1, 0]), 1)
