@@ -4,8 +4,8 @@ import torch, numpy as np
 import spring_amd
 from spring_amd import _lib
 L_ = _lib.lib()
-def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False):
-    G = n * L // 25
+def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False, cov=25):
+    G = max(n * L // cov, 4 * L)
     nb = L_.spring_synth_dna_bytes(n, L)
     buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
     rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 11, err | (0x80000000 if repeats else 0)); assert rc == 0
@@ -23,4 +23,5 @@ def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False):
 for a in sys.argv[1:]:
     f = a.split(",")
     n, L, K = [int(x) for x in f[:3]]
-    run(n, L, K, err=int(f[3]) if len(f) > 3 else 10000, repeats=len(f) > 4 and f[4] == "rep")
+    run(n, L, K, err=int(f[3]) if len(f) > 3 else 10000, repeats=len(f) > 4 and f[4] == "rep",
+        cov=int(f[5]) if len(f) > 5 else 25)
