@@ -4,11 +4,13 @@
 // :572-633; src/encoder.cpp:32-109,:177-222), re-designed as data-parallel passes over HBM-resident
 // arrays:
 //   contigs     heads from the flag stream + the 10 000 001-read cut (encoder.h:215), two scans
-//   sort        one stable radix sort by (contig, pos - min pos)            (list::sort, encoder.h:222)
-//   consensus   one thread per consensus base votes over the reads covering it   (buildcontig)
+//   sort        one stable radix sort by the read's first base in the concatenated consensus
+//               (= contig, pos - min pos)                                   (list::sort, encoder.h:222)
+//   consensus   one block per 2048 consensus bases, votes in LDS            (buildcontig)
 //   pool        singleton + N reads as 2-bit limbs + N mask, forward and reverse complement;
 //               two exact hash dictionaries on their 21-base windows        (constructdictionary, bpb 3)
-//   align       one thread per consensus position probes 4 windows; every hit proposes
+//   align       one thread per consensus 21-mer: 2 lookups in a table holding both dictionaries serve the
+//               4 probes (fwd/rev x dict 0/1) it takes part in; every hit proposes
 //               atomicMin(T[read], probe key): the first probe in the reference's serial order wins.
 //               Bins deeper than MAX_SEARCH_ENCODER are handled by iterating to the fixed point
 //               with "live at probe P" = T_prev[read] >= P                  (encode, encoder.h:243-343)
