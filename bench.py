@@ -190,6 +190,14 @@ def main():
         po.reorder_omp(read, ln, L, T)
         tm = time.perf_counter() - t0
         ph_dict, ph_chains = po.last_omp_phases()
+        # the reference's default thread count (-t 8, main.cpp:70) on a quarter of the sample
+        ns8 = min(max(ns // 4, 200_000), ns)
+        dna8 = sample(ns8)
+        t0 = time.perf_counter()
+        read8, ln8 = po.load_dna(dna8, ns8, L)
+        po.reorder_omp(read8, ln8, L, 8)
+        t8 = time.perf_counter() - t0
+        del read8, ln8, dna8
         ns1 = min(max(ns // 8, 200_000), ns)
         dna1 = sample(ns1)
         t0 = time.perf_counter()
@@ -202,6 +210,7 @@ def main():
                       "free-running OpenMP threads (load + dictionaries + reorder), %.1f s" % (ns, L, T, tm),
             "phases_s": {"dictionaries": round(ph_dict, 2), "chains": round(ph_chains, 2)},
             "chains_only_value": round(ns / ph_chains / 1e6, 4) if ph_chains > 0 else None,
+            "threads_8": {"value": round(ns8 / t8 / 1e6, 4), "sample_reads": ns8, "seconds": round(t8, 1)},
             "single_thread": {"value": round(ns1 / t1 / 1e6, 4), "sample_reads": ns1, "seconds": round(t1, 1)},
             "host_cpus": os.cpu_count(),
         }
