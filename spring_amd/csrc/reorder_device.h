@@ -62,6 +62,8 @@ struct DevParams {
   const uint16_t *lens;
   uint32_t n;
   int L, W, S, Lpad, maxshift, uniform_len;
+  int first_shifts;   // shifts probed by the first batch of a search (1..16); later batches cover 16 each
+  int seed_wide;      // 1: a chain whose seed has no match yet probes all 16 shifts in its first batch
   // dictionaries (reorder.h:751-759)
   int dstart[2], dend[2];
   uint32_t numkeys[2];

@@ -613,7 +613,7 @@ struct BatchOut {
 
 template <bool STATS>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev, int b,
-                                            int lane, int ref_len, BatchOut &out) {
+                                            int lane, int ref_len, int fs, BatchOut &out) {
   const int W = P.W;
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int ds = P.dstart[l], de = P.dend[l];
@@ -625,8 +625,10 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   const uint32_t *__restrict__ ids = P.ids[l];
   const bool have_keys = P.numkeys[l] > 0;
   const uint64_t *sx = rev ? srev : sref;
-  const int shift = b * 16 + (lane >> 2);
-  bool valid = shift < P.maxshift;
+  // batch 0 covers only the first P.first_shifts shifts (its upper lanes stay idle): most searches that succeed do
+  // so within a few shifts, and every lane past the winner is a wasted 64-byte request
+  const int shift = b == 0 ? (lane >> 2) : fs + (b - 1) * 16 + (lane >> 2);
+  bool valid = shift < P.maxshift && (b != 0 || (lane >> 2) < fs);
   if (!rev) valid = valid && (de + shift < ref_len);
   else valid = valid && (de < ref_len + shift) && (ds > shift);
   bool hit = false, keyok = false;
@@ -776,19 +778,21 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   const uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
   wave_sync();
   // batches of 16 shifts in priority order; most chains match in batch 0
-  const int nbatch = (P.maxshift + 15) >> 4;
+  // a fresh seed (nothing matched to it yet) fails about every second search: it gets the full first batch
+  const int fs = (h.prev_unmatched && P.seed_wide) ? 16 : P.first_shifts;
+  const int nbatch = P.maxshift <= fs ? 1 : 1 + ((P.maxshift - fs + 15) >> 4);
   BatchOut o;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
   int wb = 0;
   for (int b = 0; b < nbatch; b++) {
-    probe_batch<STATS>(P, sref, srev, b, lane, ref_len, o);
+    probe_batch<STATS>(P, sref, srev, b, lane, ref_len, fs, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     if (o.found) { wb = b; break; }
   }
   if (lane == 0) {
     if (o.found) {
       c->h.prop_rid = o.rid;
-      c->h.prop_shift = wb * 16 + (int)(o.win >> 2);
+      c->h.prop_shift = (wb == 0 ? 0 : fs + (wb - 1) * 16) + (int)(o.win >> 2);
       c->h.prop_rev = (uint8_t)((o.win >> 1) & 1);
       c->h.prop_kind = PROP_MATCH;
       if (MG) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;  // resolved after the exchange

@@ -767,6 +767,11 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
 }
 
 // ------------------------------------------------------------------ chains
+// width of a search's first batch: 8 of the 16 shift slots; SPRING_FIRST_SHIFTS overrides
+static int first_shifts_knob() {
+  static const int v = getenv("SPRING_FIRST_SHIFTS") ? std::min(16, std::max(1, atoi(getenv("SPRING_FIRST_SHIFTS")))) : 8;
+  return v;
+}
 static uint32_t auto_chains(uint32_t n) {
   uint64_t k = n >> 10;  // ~1000 reads per chain
   if (k < 1) k = 1;
@@ -784,7 +789,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   ctx->K = K;
   DevParams &P = ctx->P;
   P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
-  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2;  // reorder.h:750
+  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2; P.first_shifts = first_shifts_knob(); P.seed_wide = getenv("SPRING_SEED_WIDE") ? atoi(getenv("SPRING_SEED_WIDE")) : 1;  // reorder.h:750
   P.uniform_len = ctx->uniform ? 1 : 0;
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
@@ -891,7 +896,7 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   ctx->K = K;
   DevParams &P = ctx->P;
   P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
-  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2;
+  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2; P.first_shifts = first_shifts_knob(); P.seed_wide = getenv("SPRING_SEED_WIDE") ? atoi(getenv("SPRING_SEED_WIDE")) : 1;
   P.uniform_len = ctx->uniform ? 1 : 0;
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
