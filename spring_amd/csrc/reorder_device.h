@@ -36,7 +36,7 @@ struct __attribute__((aligned(16))) ChainHot {
   uint32_t n_emit, n_single, s_slot;     // s_slot: next free slot in the singleton chunk
   uint8_t done, prev_unmatched, left_search, stop_searching;
   uint8_t mode, retrying, prop_kind, prop_rev;
-  uint8_t cnt_buf, finishing, cursor_writer, pad1;
+  uint8_t cnt_buf, finishing, cursor_writer, cnt_wide;   // cnt_wide: the committed count buffer is in cnt (else cnt8)
 };
 static_assert(sizeof(ChainHot) == 64, "ChainHot must be one 64-byte line");
 
@@ -81,7 +81,8 @@ struct DevParams {
   unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
   uint32_t *alive_round;      // [1] chains not done, recounted from prop every round (multi-GPU mode)
   Chain *chains;
-  int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong
+  int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong: wide format (some count > 255)
+  uint32_t *cnt8;     // same, one byte per count: the format of almost every update (4x fewer bytes moved)
   // append-order emission buffers (+ chain, seq for the final scatter)
   uint32_t *e_order; char *e_rc; char *e_flag; long long *e_pos; uint16_t *e_len; uint32_t *e_chain; uint32_t *e_seq;
   uint32_t *s_order; uint32_t *s_chain; uint32_t *s_seq;

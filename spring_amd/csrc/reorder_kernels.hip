@@ -426,13 +426,26 @@ __device__ void update_literal_lane0(WaveLds *ws, WaveLdsLiteral *wl, bool reset
 // ws->code; nothing chain-visible is modified (commit = pack_consensus + header
 // write by the caller).  NP = positions per lane (ceil(Lpad/64) <= NP).
 // Returns the new ref_len.
+// Count columns travel as one byte per count (cnt8) whenever every count of the new state fits, else as int4
+// (cnt): the caller first asks for bytes (out_wide = false) and repeats the update in the wide format if
+// `overflow` comes back set -- seen in practice only on very deep coverage.  cur_wide = format of the committed
+// buffer.  4x fewer bytes on the dominant traffic of k_apply.
+__device__ __forceinline__ int4 unpack8(uint32_t u) {
+  return make_int4((int)(u & 255u), (int)((u >> 8) & 255u), (int)((u >> 16) & 255u), (int)(u >> 24));
+}
+__device__ __forceinline__ uint32_t pack8(const int4 &t) {
+  return (uint32_t)t.x | ((uint32_t)t.y << 8) | ((uint32_t)t.z << 16) | ((uint32_t)t.w << 24);
+}
 template <int NP, bool LITERAL>
 __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t cid, WaveLds *ws, WaveLdsLiteral *wl,
                                                    uint32_t rid, int n, bool reset, bool rev, int shift, int R,
-                                                   int cb, int lane) {
+                                                   int cb, bool cur_wide, bool out_wide, bool &overflow, int lane) {
   const int M = P.L, W = P.W;
   const int4 *__restrict__ cur = P.cnt + ((uint64_t)cid * 2 + cb) * P.Lpad;
   int4 *__restrict__ nxt = P.cnt + ((uint64_t)cid * 2 + (cb ^ 1)) * P.Lpad;
+  const uint32_t *__restrict__ cur8 = P.cnt8 + ((uint64_t)cid * 2 + cb) * P.Lpad;
+  uint32_t *__restrict__ nxt8 = P.cnt8 + ((uint64_t)cid * 2 + (cb ^ 1)) * P.Lpad;
+#define LOAD_CNT(I) (cur_wide ? cur[(I)] : unpack8(cur8[(I)]))
   // case parameters: out position p < hiP gets (p<cpy_hi ? cur[p+src_off] : 0) + (add_lo<=p<add_hi ? onehot(base[p-add_lo]) : 0)
   int hiP, cpy_hi, src_off, add_lo, add_hi, Rn, d = 0;
   bool alias = false;
@@ -451,8 +464,8 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
     for (int k = 0; k < NP; k++) {
       const int p = k * 64 + lane;
       v[k] = make_int4(0, 0, 0, 0);
-      if (!alias) { if (p < cpy_hi) v[k] = cur[p + src_off]; }
-      else if (p >= d && p < n - shift) v[k] = cur[p % d];
+      if (!alias) { if (p < cpy_hi) v[k] = LOAD_CNT(p + src_off); }
+      else if (p >= d && p < n - shift) v[k] = LOAD_CNT(p % d);
     }
   }
   if (lane < 16) ws->rd[lane] = myl;
@@ -460,7 +473,7 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
 
   if (LITERAL) {
     for (int p = lane; p < M; p += 64) {
-      int4 t = reset ? make_int4(0, 0, 0, 0) : cur[p];
+      int4 t = reset ? make_int4(0, 0, 0, 0) : LOAD_CNT(p);
       wl->cnt[0][p] = t.x; wl->cnt[1][p] = t.y; wl->cnt[2][p] = t.z; wl->cnt[3][p] = t.w;
     }
     wave_sync();
@@ -468,9 +481,16 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
     if (lane == 0) update_literal_lane0(ws, wl, reset, rev, shift, n, Rl, M);
     Rl = __shfl(Rl, 0, 64);
     wave_sync();
-    for (int p = lane; p < M; p += 64) nxt[p] = make_int4(wl->cnt[0][p], wl->cnt[1][p], wl->cnt[2][p], wl->cnt[3][p]);
+    int mxl = 0;
+    for (int p = lane; p < M; p += 64) mxl = max(max(mxl, max(wl->cnt[0][p], wl->cnt[1][p])), max(wl->cnt[2][p], wl->cnt[3][p]));
+    overflow = __any(mxl > 255);
+    for (int p = lane; p < M; p += 64) {
+      const int4 t = make_int4(wl->cnt[0][p], wl->cnt[1][p], wl->cnt[2][p], wl->cnt[3][p]);
+      if (out_wide) nxt[p] = t; else nxt8[p] = pack8(t);
+    }
     return Rl;
   }
+  int mx = 0;
 #pragma unroll
   for (int k = 0; k < NP; k++) {
     const int p = k * 64 + lane;
@@ -491,11 +511,14 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
           add_hot(t, cidx_of_code(cur_base(ws->rd, p, n, rev)));
         }
       }
-      nxt[p] = t;
+      if (out_wide) nxt[p] = t; else nxt8[p] = pack8(t);
+      mx = max(max(mx, max(t.x, t.y)), max(t.z, t.w));
       if (p < Rn) ws->code[p] = (uint8_t)(reset ? code : argmax_code(t));  // reset: consensus = the read itself
     }
   }
+  overflow = __any(mx > 255);
   return Rn;
+#undef LOAD_CNT
 }
 
 __device__ __forceinline__ void load_hot(const Chain *c, ChainHot &h) {
@@ -534,12 +557,13 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
     return;
   }
   const int n = P.uniform_len ? P.L : (int)P.lens[seed];
-  const int Rn = wave_update_compute<NP, false>(P, li, ws, nullptr, seed, n, true, false, 0, 0, 0, lane);
+  bool ovf0;  // a fresh seed's counts are 0 / 1: bytes
+  const int Rn = wave_update_compute<NP, false>(P, li, ws, nullptr, seed, n, true, false, 0, 0, 0, false, false, ovf0, lane);
   pack_consensus(ws, Rn, lane, c);
   if (lane == 0) {
     h.prev = seed; h.first_rid = seed; h.prev_unmatched = 1;
     h.e_slot = li * CHUNK; h.s_slot = li * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
-    h.ref_len = Rn; h.cnt_buf = 1;
+    h.ref_len = Rn; h.cnt_buf = 1; h.cnt_wide = 0;
     store_hot(c, h);
     c->n_unmatched = 1;
     if (P.prop) P.prop[cid] = (unsigned long long)PK_NONE << 32;
@@ -843,7 +867,8 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   __shared__ WaveLds lds[4];
   __shared__ WaveLdsLiteral ldsl[LITERAL ? 4 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t li = blockIdx.x * 4 + wave;  // local chain index (state arrays, emission tags)
+  // local chain index (state arrays, emission tags); wave-uniform -> chain pointers live in SGPRs
+  const uint32_t li = blockIdx.x * 4 + wave;
   if (li >= P.K) return;
   const uint32_t cid = P.c0 + li;             // global chain id (conflict priority)
   Chain *c = &P.chains[li];
@@ -886,9 +911,17 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   else if (fail_path && !h.left_search) { do_upd = true; urid = h.first_rid; ureset = true; urev = true; }  // reorder.h:567
   int n = P.L, R_new = h.ref_len;
   const int R_old = h.ref_len;
+  bool nw = false;
   if (do_upd) {
     if (!P.uniform_len) n = (int)P.lens[urid];
-    R_new = wave_update_compute<NP, LITERAL>(P, li, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf, lane);
+    // bytes first; the rare update that would push a count past 255 is redone in the wide format
+    R_new = wave_update_compute<NP, LITERAL>(P, li, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf,
+                                             h.cnt_wide != 0, false, nw, lane);
+    if (nw) {
+      bool o2;
+      R_new = wave_update_compute<NP, LITERAL>(P, li, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf,
+                                               h.cnt_wide != 0, true, o2, lane);
+    }
   }
   if (!MG && kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
     if (lane == 0) P.glob->cursor = (long long)h.prop_rid - 1;
@@ -906,6 +939,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
     pack_consensus(ws, R_new, lane, c);
     h.ref_len = R_new;
     h.cnt_buf ^= 1;
+    h.cnt_wide = nw;
   }
   if (lane != 0) return;
   if (kind == PROP_MATCH) {

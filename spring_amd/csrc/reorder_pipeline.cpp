@@ -804,6 +804,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   DMALLOC(P.glob, sizeof(Globals));
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
+  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t));
   // append buffers: n records + one partly filled CHUNK per chain
   const size_t cap = (size_t)n + (size_t)K * CHUNK;
   if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
@@ -912,6 +913,7 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   DMALLOC(P.alive_round, 16);
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
+  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t));
   if (d_prop) P.prop = (unsigned long long *)d_prop;
   else DMALLOC(P.prop, (size_t)Ktot * 8);
   const size_t cap = (size_t)n + (size_t)K * CHUNK;
