@@ -3,7 +3,8 @@
 SPRING compresses one FASTQ (pair) per invocation and a sequencing run is many lanes/samples, so the
 natural multi-GPU unit today is "one read set per GPU".  torch.distributed is used only for the
 start/stop barriers and the max-over-ranks timing (backend "nccl" = RCCL on the GPU box, "gloo" in
-the CPU tests).  DESIGN.md section 7 describes the single-pool design that is not built yet."""
+the CPU tests).  The other multi-GPU mode, one read pool shared by all GPUs, is spring_amd/pool.py
+(DESIGN.md section 7)."""
 import os
 import time
 
