@@ -52,7 +52,9 @@ void spring_encoder_destroy(spring_encoder_ctx *ctx);
 
 /* Encode straight from a finalized reorder context: reads and streams never leave HBM.
  * dnaN / order_N: image of input_N.dna (util.cpp:322-348 records) and read_order_N.bin
- * (preprocess.cpp:186-214), host pointers, may be NULL/0. */
+ * (preprocess.cpp:186-214), host pointers, may be NULL/0.  With NULL/0 and a reorder context that was loaded
+ * through spring_reorder_load_fastq, the N reads the front end kept on the device are used (both files, merged as
+ * preprocess.cpp:362-383 merges them): FASTQ text -> encoder streams without a host round trip. */
 int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *reorder, const uint8_t *dnaN,
                                   uint64_t dnaN_bytes, const uint32_t *order_N, uint32_t numreads_N,
                                   spring_encoder_info *info);

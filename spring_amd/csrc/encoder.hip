@@ -669,6 +669,13 @@ __global__ __launch_bounds__(256) void k_noise(NoiseP N) {
 }
 
 // ------------------------------------------------------------------ order correction (correct_order, encoder.cpp:177-222)
+__global__ void k_shift_N(const uint64_t *__restrict__ off, const uint32_t *__restrict__ order, uint32_t n, uint64_t byte_base,
+                          uint32_t read_base, uint64_t *__restrict__ off_out, uint32_t *__restrict__ order_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  off_out[i] = off[i] + byte_base;
+  order_out[i] = order[i] + read_base;
+}
 __global__ void k_mark_N(const uint32_t *__restrict__ order_N, uint32_t nN, uint32_t *__restrict__ flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nN) flag[order_N[i]] = 1u;
@@ -814,12 +821,15 @@ struct EncSrc {
   bool oriented;          // stream reads are stored already reverse-complemented (temp.dna.<tid> image)
   const uint32_t *oid;    // clean-read id of stream record i (null: the gather index is the id)
   const uint32_t *oid_s;  // clean-read id of singleton q (null: V.f_order_s)
+  bool n_from_view;       // the reads with N are the ones the FASTQ front end left on the device (V.N_*)
 };
 
 static int encode_core(spring_encoder_ctx *ctx, const EncSrc &E, const uint8_t *dnaN, uint64_t dnaN_bytes,
                        const uint32_t *order_N, uint32_t nN, spring_encoder_info *info_out) {
   const sr::ReorderView &V = E.V;
-  if (nN && (!dnaN || !order_N)) return fail(SPRING_REORDER_E_ARG, "numreads_N > 0 but dnaN / order_N is NULL");
+  const bool ndev = E.n_from_view;
+  if (ndev) { nN = V.N_count[0] + V.N_count[1]; dnaN_bytes = V.N_bytes[0] + V.N_bytes[1]; }
+  else if (nN && (!dnaN || !order_N)) return fail(SPRING_REORDER_E_ARG, "numreads_N > 0 but dnaN / order_N is NULL");
   const int dev = ctx->dev;
   HIPCHK(hipSetDevice(dev));
   hipStream_t st = V.st;
@@ -844,7 +854,7 @@ static int encode_core(spring_encoder_ctx *ctx, const EncSrc &E, const uint8_t *
 
   // host-side scan of the N records (u16 length prefixes; a sequential dependency of nN steps)
   std::vector<uint64_t> offN(nN ? nN : 1);
-  {
+  if (!ndev) {
     uint64_t o = 0;
     for (uint32_t i = 0; i < nN; i++) {
       if (o + 2 > dnaN_bytes) return fail(SPRING_REORDER_E_ARG, "input_N.dna image is truncated");
@@ -880,9 +890,23 @@ static int encode_core(spring_encoder_ctx *ctx, const EncSrc &E, const uint8_t *
     DBuf flagN, nb;
     DALLOC(flagN, (size_t)total * 4); DALLOC(nb, (size_t)total * 4); DALLOC(cumN, (size_t)(V.n ? V.n : 1) * 4);
     DALLOC(dN, dnaN_bytes); DALLOC(dorderN, (size_t)nN * 4); DALLOC(doffN, (size_t)nN * 8);
-    HIPCHK(hipMemcpyAsync(dN.p, dnaN, dnaN_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(dorderN.p, order_N, (size_t)nN * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(doffN.p, offN.data(), (size_t)nN * 8, hipMemcpyHostToDevice, st));
+    if (!ndev) {
+      HIPCHK(hipMemcpyAsync(dN.p, dnaN, dnaN_bytes, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(dorderN.p, order_N, (size_t)nN * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(doffN.p, offN.data(), (size_t)nN * 8, hipMemcpyHostToDevice, st));
+    } else {  // the two files' N reads one after the other, file-2 positions offset by the reads of file 1
+      uint64_t bo = 0;     // (the merge of input_N.dna.2 / read_order_N.bin.2, preprocess.cpp:362-383)
+      uint32_t ro = 0;
+      for (int j = 0; j < 2; j++) {
+        const uint32_t c = V.N_count[j];
+        if (!c) continue;
+        HIPCHK(hipMemcpyAsync(dN.as<uint8_t>() + bo, V.N_dna[j], V.N_bytes[j], hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_shift_N, grid(c), dim3(256), 0, st, V.N_off[j], V.N_order[j], c, bo,
+                           j ? V.fq_num_reads_0 : 0u, doffN.as<uint64_t>() + ro, dorderN.as<uint32_t>() + ro);
+        bo += V.N_bytes[j];
+        ro += c;
+      }
+    }
     HIPCHK(hipMemsetAsync(flagN.p, 0, (size_t)total * 4, st));
     hipLaunchKernelGGL(k_mark_N, grid(nN), dim3(256), 0, st, dorderN.as<uint32_t>(), nN, flagN.as<uint32_t>());
     t2 = tb;
@@ -1247,6 +1271,8 @@ int spring_encoder_encode_reorder(spring_encoder_ctx *ctx, spring_reorder_ctx *r
   E.oriented = false;
   E.oid = nullptr;
   E.oid_s = nullptr;
+  // no N reads handed over: take the ones the FASTQ front end kept on the device, if the context came from it
+  E.n_from_view = !dnaN && !nN && (E.V.N_count[0] + E.V.N_count[1]) > 0;
   return encode_core(ctx, E, dnaN, dnaN_bytes, order_N, nN, info_out);
 }
 
@@ -1316,6 +1342,9 @@ int spring_encoder_encode_host(spring_encoder_ctx *ctx, uint32_t max_readlen, in
   E.V.f_flag = d_flag.as<char>(); E.V.f_pos = d_pos.as<long long>(); E.V.f_len = d_len.as<uint16_t>();
   E.V.tid_off = tid_off.data(); E.V.num_thr = num_thr;
   E.oriented = true;
+  E.n_from_view = false;
+  for (int j = 0; j < 2; j++) { E.V.N_dna[j] = nullptr; E.V.N_off[j] = nullptr; E.V.N_order[j] = nullptr; E.V.N_count[j] = 0; E.V.N_bytes[j] = 0; }
+  E.V.fq_num_reads_0 = 0;
   E.oid = d_oid.as<uint32_t>();
   E.oid_s = d_oids.as<uint32_t>();
   const int r = encode_core(ctx, E, dnaN, dnaN_bytes, order_N, nN, info_out);

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
                                                     const uint64_t *__restrict__ noff, uint32_t cidx_base,
                                                     uint64_t coff_base, uint32_t file_read_base,
                                                     uint8_t *__restrict__ out_clean, uint64_t *__restrict__ out_off,
-                                                    uint8_t *__restrict__ out_N, uint32_t *__restrict__ out_orderN) {
+                                                    uint8_t *__restrict__ out_N, uint32_t *__restrict__ out_orderN,
+                                                    uint64_t *__restrict__ out_offN) {
   const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int l16 = threadIdx.x & 15;
   if (i >= nreads) return;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
     if (l16 == 0) {
       dst[0] = (uint8_t)(L & 0xff); dst[1] = (uint8_t)(L >> 8);
       out_orderN[nidx[i]] = file_read_base + (uint32_t)i;  // pos_N = num_reads[j] + i (preprocess.cpp:299)
+      out_offN[nidx[i]] = noff[i];                         // record offsets, for consumers that stay on the device
     }
     const uint32_t nb = (L + 1) / 2;
     for (uint32_t b = l16; b < nb; b += 16) {
@@ -168,10 +170,10 @@ void launch_read_info(hipStream_t st, const uint8_t *t, const uint64_t *line_end
 void launch_pack_reads(hipStream_t st, const uint8_t *t, const uint64_t *line_end, uint64_t nreads, const uint32_t *len,
                        const uint32_t *fclean, const uint32_t *cidx, const uint64_t *coff, const uint32_t *nidx,
                        const uint64_t *noff, uint32_t cidx_base, uint64_t coff_base, uint32_t file_read_base,
-                       uint8_t *out_clean, uint64_t *out_off, uint8_t *out_N, uint32_t *out_orderN) {
+                       uint8_t *out_clean, uint64_t *out_off, uint8_t *out_N, uint32_t *out_orderN, uint64_t *out_offN) {
   if (nreads)
     hipLaunchKernelGGL(k_pack_reads, GRIDN(nreads, 16), dim3(256), 0, st, t, line_end, nreads, len, fclean, cidx, coff, nidx,
-                       noff, cidx_base, coff_base, file_read_base, out_clean, out_off, out_N, out_orderN);
+                       noff, cidx_base, coff_base, file_read_base, out_clean, out_off, out_N, out_orderN, out_offN);
 }
 hipError_t reduce_max_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n) {
   return rocprim::reduce(tmp, tmp_bytes, in, out, 0u, n, rocprim::maximum<uint32_t>(), st);

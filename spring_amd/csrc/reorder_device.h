@@ -129,7 +129,7 @@ void launch_read_info(hipStream_t st, const uint8_t *t, const uint64_t *line_end
 void launch_pack_reads(hipStream_t st, const uint8_t *t, const uint64_t *line_end, uint64_t nreads, const uint32_t *len,
                        const uint32_t *fclean, const uint32_t *cidx, const uint64_t *coff, const uint32_t *nidx,
                        const uint64_t *noff, uint32_t cidx_base, uint64_t coff_base, uint32_t file_read_base,
-                       uint8_t *out_clean, uint64_t *out_off, uint8_t *out_N, uint32_t *out_orderN);
+                       uint8_t *out_clean, uint64_t *out_off, uint8_t *out_N, uint32_t *out_orderN, uint64_t *out_offN);
 hipError_t reduce_max_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n);
 hipError_t reduce_min_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n);
 

@@ -25,6 +25,13 @@ struct ReorderView {
   const uint16_t *f_len;
   const uint64_t *tid_off;   // host, num_thr + 1
   int num_thr;
+  // reads with N of the two input files when the context was loaded through the FASTQ front end (device)
+  const uint8_t *N_dna[2];
+  const uint64_t *N_off[2];
+  const uint32_t *N_order[2];
+  uint32_t N_count[2];
+  uint64_t N_bytes[2];
+  uint32_t fq_num_reads_0;   // reads of file 1 (file-2 positions in read_order_N.bin are offset by it)
 };
 int reorder_view(spring_reorder_ctx *ctx, ReorderView *v);   // fails unless the context is finalized
 

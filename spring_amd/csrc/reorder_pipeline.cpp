@@ -138,6 +138,7 @@ struct spring_reorder_ctx {
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
   uint32_t *d_orderN[2] = {nullptr, nullptr};
+  uint64_t *d_offN[2] = {nullptr, nullptr};   // byte offset of every N record inside d_N
   uint64_t N_bytes[2] = {0, 0};
   spring_fastq_info fq;
   double fq_ms = 0;
@@ -179,6 +180,11 @@ int reorder_view(spring_reorder_ctx *ctx, ReorderView *v) {
   v->reads = ctx->d_reads; v->lens = ctx->d_lens; v->nrec = ctx->nrec; v->nsing = ctx->nsing;
   v->f_order = ctx->P.f_order; v->f_order_s = ctx->P.f_order_s; v->f_rc = ctx->P.f_rc; v->f_flag = ctx->P.f_flag;
   v->f_pos = ctx->P.f_pos; v->f_len = ctx->P.f_len; v->tid_off = ctx->tid_off.data(); v->num_thr = ctx->o.num_thr;
+  for (int j = 0; j < 2; j++) {  // reads with N kept by the FASTQ front end (none when the reads came as .dna records)
+    v->N_dna[j] = ctx->d_N[j]; v->N_off[j] = ctx->d_offN[j]; v->N_order[j] = ctx->d_orderN[j];
+    v->N_count[j] = ctx->fq.num_reads_N[j]; v->N_bytes[j] = ctx->N_bytes[j];
+  }
+  v->fq_num_reads_0 = ctx->fq.num_reads[0];
   return 0;
 }
 hipError_t dev_alloc(int dev, size_t bytes, void **out) {
@@ -485,10 +491,11 @@ int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, s
     if (!f[j].nreads) continue;
     DMALLOC(ctx->d_N[j], f[j].N_bytes + 16);
     DMALLOC(ctx->d_orderN[j], (size_t)std::max<uint32_t>(f[j].n_N, 1) * 4);
+    DMALLOC(ctx->d_offN[j], (size_t)std::max<uint32_t>(f[j].n_N, 1) * 8);
     ctx->N_bytes[j] = f[j].N_bytes;
     // pos_N counts from the start of its own file (preprocess.cpp:299: num_reads[j] + i)
     launch_pack_reads(st, f[j].d_txt, f[j].line_end, f[j].nreads, f[j].len, f[j].fclean, f[j].cidx, f[j].coff, f[j].nidx,
-                      f[j].noff, cbase, obase, 0u, ctx->d_dna, ctx->d_off, ctx->d_N[j], ctx->d_orderN[j]);
+                      f[j].noff, cbase, obase, 0u, ctx->d_dna, ctx->d_off, ctx->d_N[j], ctx->d_orderN[j], ctx->d_offN[j]);
     HIPCHK(hipGetLastError());
     cbase += f[j].n_clean; obase += f[j].clean_bytes; rbase += (uint32_t)f[j].nreads;
   }

@@ -222,6 +222,11 @@ def test_fastq_to_encoder_streams_end_to_end(paired):
         with EncoderStage() as enc:
             ei = enc.encode(st, dnaN, order_N)
             e = enc.streams()
+            # without N images the encoder takes the N reads the front end left on the device: same streams
+            ei2 = enc.encode(st)
+            e2 = enc.streams()
+    assert ei2["matched_N"] == ei["matched_N"] and ei2["n_total"] == ei["n_total"]
+    same_encoding(e2, e, "device-resident N reads")
     allreads = [s.decode() for f in files for s in f]
     assert ei["n_total"] == len(allreads) and ei["matched_s"] > 0 and ei["matched_N"] > 0
     dec = decode_reads(e)
