@@ -38,6 +38,15 @@ typedef struct {
   int32_t force_literal_update; /* 1: consensus update always through the literal lane-0 path (tests) */
   int32_t rounds_per_sync;      /* rounds enqueued between host termination checks; 0 = auto      */
   int32_t reserved;
+  /* ---- tuning / experiments (0 = default).  The output does not depend on any of them; each non-default
+   * setting is covered by a parity test (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results). */
+  int32_t first_shifts;   /* shifts a search's first batch of probes covers, 1..16 (default 8)             */
+  int32_t seed_wide;      /* -1: off; else a chain whose seed is still unmatched probes 16 shifts first    */
+  int32_t tab_scale;      /* dictionary table size multiplier 1 / 2 / 4 (default 2: load <= 0.2)           */
+  int32_t search_wpb;     /* chains (wavefronts) per block of the search kernel: 1 / 2 / 4                 */
+  int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per search block  */
+  int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
+  int32_t reserved2[2];
 } spring_reorder_opts;
 
 typedef struct {

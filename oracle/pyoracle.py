@@ -92,6 +92,29 @@ def ref_lib():
     return _REF
 
 
+def ref_order_bin():
+    """oracle/_ref/ref_order: the real pe_encode.cpp + generate_order_se/pe behind a command line, or None."""
+    path = os.path.join(_HERE, "_ref", "ref_order")
+    return path if os.path.exists(path) else None
+
+
+def ref_order(mode, order):
+    """Runs the REAL reference function on a read_order.bin image: mode 'se' / 'pe' -> order_array,
+    'pe_encode' -> the rewritten read_order.bin (pe_encode.cpp:24-84, reorder_compress_quality_id.cpp:101-125)."""
+    import tempfile
+    order = np.ascontiguousarray(order, dtype=np.uint32)
+    with tempfile.TemporaryDirectory() as d:
+        order.tofile(os.path.join(d, "read_order.bin"))
+        subprocess.run([ref_order_bin(), mode, d, str(len(order))], check=True)
+        out = os.path.join(d, "read_order.bin" if mode == "pe_encode" else "order_array.bin")
+        return np.fromfile(out, dtype=np.uint32)
+
+
+def ref_bsc_bin():
+    path = os.path.join(_HERE, "_ref", "ref_bsc")
+    return path if os.path.exists(path) else None
+
+
 def limbs(L):
     return (2 * L - 1) // 64 + 1
 

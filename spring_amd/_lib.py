@@ -25,7 +25,10 @@ EXPORTS = [
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_chains", C.c_uint32), ("num_thr", C.c_int32),
                 ("collect_stats", C.c_int32), ("time_search", C.c_int32), ("force_literal_update", C.c_int32),
-                ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32)]
+                ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32),
+                ("first_shifts", C.c_int32), ("seed_wide", C.c_int32), ("tab_scale", C.c_int32),
+                ("search_wpb", C.c_int32), ("dbg_search_lds", C.c_int32), ("dbg_apply_lds", C.c_int32),
+                ("reserved2", C.c_int32 * 2)]
 
 
 class FastqInfo(C.Structure):

@@ -27,15 +27,24 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                os.path.getmtime(os.path.join(CSRC, f)) for f in [src] + HEADERS) and os.path.getmtime(obj) > max(
+                os.path.getmtime(os.path.join(ROOT, "include", h)) for h in ("spring_reorder.h", "spring_encoder.h")):
+            continue  # object newer than its source and every header
+        cmds.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+                     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj])
+    procs = []
+    for cmd in cmds:  # the translation units are independent: compile them side by side
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     subprocess.run(cmd, check=True)
     return LIB

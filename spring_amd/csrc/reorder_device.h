@@ -62,14 +62,17 @@ struct DevParams {
   const uint16_t *lens;
   uint32_t n;
   int L, W, S, Lpad, maxshift, uniform_len;
-  int first_shifts;   // shifts probed by the first batch of a search (1..16); later batches cover 16 each
+  int first_shifts;   // shifts probed by the first batch of a search (1..16); the second covers 16, the tail the rest
   int seed_wide;      // 1: a chain whose seed has no match yet probes all 16 shifts in its first batch
+  int search_wpb;     // chains (wavefronts) per block of k_search: 1, 2 or 4
+  int dbg_search_lds, dbg_apply_lds;   // occupancy experiments: dummy dynamic LDS bytes per block
+  int wl;             // length of both dictionary windows in bases (dend - dstart + 1)
   // dictionaries (reorder.h:751-759)
   int dstart[2], dend[2];
   uint32_t numkeys[2];
-  const uint4 *fpt[2];        // buckets [tag x4 | payload x4], 32 B each
+  const uint4 *fpt;           // ONE table for both dictionaries: buckets [tag x4 | payload x4], 32 B each
+  int bshift;                 // bucket = hash >> bshift (the table has 2^(64-bshift) buckets, at least 2)
   const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key (multi-read bins)
-  int bshift[2];              // bucket = hash >> bshift (tables have 2^(64-bshift) buckets, at least 2)
   const uint32_t *ids[2];
   // shared mutable state
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
@@ -96,12 +99,20 @@ void launch_unpack(hipStream_t st, const uint8_t *dna, const uint64_t *off, uint
 void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int dend, uint32_t *flag);
 void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
                  int S, int dstart, int dend, uint64_t *keys, uint32_t *vals);
-void launch_tab_insert(hipStream_t st, const uint64_t *uhash /* sorted unique mix64(key) */, const uint32_t *ustart, const uint32_t *ucount,
-                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, int bshift,
-                       uint32_t *deep, uint32_t *ndeep);
+// unique keys of both dictionaries merged by hash (mval = dict << 63 | index of the key in its dictionary)
+struct DictBuild {
+  const uint32_t *ustart, *ucount, *ids;
+  ulonglong2 *urec;
+  uint32_t *deep, *ndeep;
+};
+void launch_tab_insert(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
+                       DictBuild d1, uint4 *fpt, int bshift);
+hipError_t merge_by_hash(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *k0, const uint64_t *k1,
+                         const uint64_t *v0, const uint64_t *v1, uint64_t *kout, uint64_t *vout, size_t n0, size_t n1);
+void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag);
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
                       ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken);
-void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift,
+void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count);
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);

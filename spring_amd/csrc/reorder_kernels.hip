@@ -78,19 +78,24 @@ __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uin
 }
 
 // exact key -> bin map in two levels (replaces boomphf lookup + findpos + key re-check,
-// reorder.h:271-285):
-//   fpt : 32-byte buckets [tag0..3 | pay0..3]; tag = (31-bit hash fingerprint << 1) | single,
+// reorder.h:271-285), ONE table for both dictionaries:
+//   fpt : 32-byte buckets [tag0..3 | pay0..3]; tag = (30-bit hash fingerprint << 2) | dict << 1 | single,
 //         tag 0 = empty slot.  One bucket = one 32-byte HBM fetch, the granularity random reads
 //         actually cost on MI355X (tools/random_gather_bench.hip: 64 B/lane random reads run at
 //         20 G/s, <= 32 B/lane at 48 G/s).  98 % of probes are absent keys and end here.
+//   The two dictionary windows are adjacent and equally long (reorder.h:751-759: start1 = end0 + 1), so the
+//   window dictionary 1 looks up at shift s is the window dictionary 0 looks up at shift s + wl (forward;
+//   reverse: dict 0 at s == dict 1 at s + wl).  A key of both dictionaries sits in the same bucket (same
+//   hash), so ONE bucket fetch answers both probes: a failing search of a 150-base consensus needs 151
+//   fetches instead of 237 (k_search, tail).
 //   single = 1: the bin holds exactly one read and pay IS that read id; the key is verified
 //         against the read's own window (as the reference does with the first read of a bin,
 //         reorder.h:282-285), so the hot path is bucket -> read: no offsets/ids hops.
-//   single = 0: pay indexes urec, a 16-byte record {key, start | count << 32}.
-// bucket = top bits of the hash (the dictionary is built in hash order, so unique keys arrive at
-// k_tab_insert in bucket order and their writes stream), fingerprint = low 31 bits
-__device__ __forceinline__ uint32_t fp31_of(uint64_t h) {
-  const uint32_t f = (uint32_t)h & 0x7fffffffu;
+//   single = 0: pay indexes urec[dict], a 16-byte record {key, start | count << 32}.
+// bucket = top bits of the hash (the table is built in hash order, so unique keys arrive at
+// k_tab_insert in bucket order and their writes stream), fingerprint = low 30 bits
+__device__ __forceinline__ uint32_t fp30_of(uint64_t h) {
+  const uint32_t f = (uint32_t)h & 0x3fffffffu;
   return f ? f : 1u;
 }
 __device__ __forceinline__ uint64_t bucket_of(uint64_t h, int bshift) { return h >> bshift; }
@@ -100,17 +105,21 @@ __device__ __forceinline__ uint64_t unmix64(uint64_t x) {
   x ^= x >> 33; x *= 0x9cb4b2f8129337dbull; x ^= x >> 33; x *= 0x4f74430c22a54005ull; x ^= x >> 33;
   return x;
 }
-// kind of the (skip+1)-th slot whose fingerprint matches: 0 = none (key absent), 1 = multi, 2 = single
-__device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshift, uint64_t h, int skip,
-                                        uint32_t &pay) {
-  const uint32_t fp = fp31_of(h);
+// kind of the (skip+1)-th slot of dictionary l whose fingerprint matches: 0 = none (key absent), 1 = multi,
+// 2 = single.  `other` is set when the other dictionary may hold the key too: a slot of it with the same
+// fingerprint in a bucket this call looked at, or a full bucket (its slots may continue in the next one);
+// other == false proves the key absent from the other dictionary.
+__device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshift, uint64_t h, int l, int skip,
+                                        uint32_t &pay, bool &other) {
+  const uint32_t mine = (fp30_of(h) << 2) | ((uint32_t)l << 1), theirs = mine ^ 2u;
   const uint64_t bmask = bucket_mask(bshift);
   uint64_t b = bucket_of(h, bshift);
   for (;;) {
     const uint4 t = fpt[b * 2], x = fpt[b * 2 + 1];
+    other = other || (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || t.w != 0;
 #define SLOT(T, X)                                              \
     if ((T) == 0) return 0;                                     \
-    if (((T) >> 1) == fp && skip-- == 0) { pay = (X); return 1 + (int)((T) & 1u); }
+    if (((T) & ~1u) == mine && skip-- == 0) { pay = (X); return 1 + (int)((T) & 1u); }
     SLOT(t.x, x.x) SLOT(t.y, x.y) SLOT(t.z, x.z) SLOT(t.w, x.w)
 #undef SLOT
     b = (b + 1) & bmask;
@@ -174,37 +183,37 @@ __global__ void k_keys(const uint64_t *__restrict__ reads, const uint16_t *__res
 }
 
 // ------------------------------------------------ K3 table insert (bitset_util.h:122-217)
-// one thread per unique key, keys sorted by hash = by bucket.  Pass 0 (OVERFLOW = false): the first four keys
-// of a bucket take its slots 0..3 directly (rank = number of predecessors with the same bucket, found by
-// looking back at most 4 entries) -- no atomics, streaming writes; every key writes its {key,start,count}
-// record.  Pass 1 (OVERFLOW = true): the few keys of rank >= 4 (about 1 % at load 0.4) claim the next free
-// slot further on with CAS, after pass 0 has placed all native keys.  A lookup scans slots in order and
-// stops at the first empty one, so which free slot an overflow key gets does not matter.
+// one thread per unique (key, dictionary) pair; the pairs of both dictionaries arrive merged by hash = by
+// bucket.  Pass 0 (OVERFLOW = false): the first four pairs of a bucket take its slots 0..3 directly (rank =
+// number of predecessors with the same bucket, found by looking back at most 4 entries) -- no atomics,
+// streaming writes; every pair writes its {key,start,count} record.  Pass 1 (OVERFLOW = true): the few pairs
+// of rank >= 4 (under 1 % at load 0.2) claim the next free slot further on with CAS, after pass 0 has placed
+// all native pairs.  A lookup scans slots in order and stops at the first empty one, so which free slot an
+// overflow pair gets does not matter.
 template <bool OVERFLOW>
-__global__ void k_tab_insert(const uint64_t *__restrict__ uhash, const uint32_t *__restrict__ ustart,
-                             const uint32_t *__restrict__ ucount, const uint32_t *__restrict__ ids,
-                             uint32_t numkeys, uint32_t *fpt, ulonglong2 *__restrict__ urec, int bshift,
-                             uint32_t *__restrict__ deep, uint32_t *__restrict__ ndeep) {
-  uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= numkeys) return;
-  const uint64_t h = uhash[u];
+__global__ void k_tab_insert(const uint64_t *__restrict__ mhash, const uint64_t *__restrict__ mval, uint64_t nm,
+                             DictBuild d0, DictBuild d1, uint32_t *fpt, int bshift) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nm) return;
+  const uint64_t h = mhash[i];
   const uint64_t b0 = bucket_of(h, bshift);
   int rank = 0;
-  while (rank < 4 && u > (uint32_t)rank && bucket_of(uhash[u - 1 - rank], bshift) == b0) rank++;
+  while (rank < 4 && i > (uint64_t)rank && bucket_of(mhash[i - 1 - rank], bshift) == b0) rank++;
   if (OVERFLOW != (rank >= 4)) return;
-  const uint32_t st = ustart[u], cn = ucount[u];
+  const uint64_t mv = mval[i];
+  const uint32_t l = (uint32_t)(mv >> 63), u = (uint32_t)mv;
+  const DictBuild &d = l ? d1 : d0;
+  const uint32_t st = d.ustart[u], cn = d.ucount[u];
   const bool single = cn == 1;
-  const uint32_t tag = (fp31_of(h) << 1) | (single ? 1u : 0u);
-  const uint32_t pay = single ? ids[st] : u;
+  const uint32_t tag = (fp30_of(h) << 2) | (l << 1) | (single ? 1u : 0u);
+  const uint32_t pay = single ? d.ids[st] : u;
+  if (cn >= DEEP_BIN) d.deep[atomicAdd(d.ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
+  d.urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
   if (!OVERFLOW) {
-    if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
-    urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
     fpt[b0 * 8 + rank] = tag;
     fpt[b0 * 8 + 4 + rank] = pay;
     return;
   }
-  if (cn >= DEEP_BIN) deep[atomicAdd(ndeep, 1u)] = u;
-  urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
   const uint64_t bmask = bucket_mask(bshift);
   uint64_t b = (b0 + 1) & bmask;  // the home bucket is full by construction
   for (;;) {
@@ -217,6 +226,10 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ uhash, const uint32_t 
     }
     b = (b + 1) & bmask;
   }
+}
+__global__ void k_iota_tag(uint64_t *v, uint64_t n, uint64_t tag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i | tag;
 }
 
 // Dead-tail trim of deep bins.  Chains consume a bin from its tail (highest read ids first), so on very
@@ -240,7 +253,7 @@ __global__ void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *_
 
 // test hook: start/count of the bin of each key; single-read bins report count = 1 | 0x80000000
 // and the read id in start[]
-__global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, int bshift,
+__global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, int bshift, int which,
                               const uint64_t *__restrict__ reads, int S, int dstart, int klen2,
                               const uint64_t *__restrict__ keys, uint32_t nkeys, uint32_t *__restrict__ start,
                               uint32_t *__restrict__ count) {
@@ -250,7 +263,8 @@ __global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *_
   uint32_t s = 0, c = 0xffffffffu;
   for (int skip = 0;; skip++) {
     uint32_t pay;
-    const int kind = tab_find(fpt, bshift, h, skip, pay);
+    bool other = false;
+    const int kind = tab_find(fpt, bshift, h, which, skip, pay, other);
     if (kind == 0) break;
     if (kind == 1) {
       const ulonglong2 r = urec[pay];
@@ -625,95 +639,106 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   return seed;
 }
 
-// ---- one batch of 64 probes of search_match (reorder.h:246-318) by one wavefront.
-// lane = 4*(shift%16) + 2*rev + dict: lane order == the reference's priority order inside the
-// batch (shift, forward before reverse, dict 0 before 1), so the first set bit of the hit
-// ballot is the reference's winner.  STATS counts what the reference would have executed:
-// every valid probe up to and including the winner.
+// ---- one probe of search_match (reorder.h:262-316): dictionary l, direction rev, at `shift`.  The window's
+// key and hash come from the caller because one consensus window is the probe key of both dictionaries
+// (at shifts wl apart).  sx = ref (forward) or revref (reverse) in LDS.
+__device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
+                                           int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
+                                           bool &keyok, uint32_t &ncand, bool &other) {
+  const int W = P.W;
+  const int ds = P.dstart[l];
+  const int klen2 = 2 * P.wl;
+  const ulonglong2 *__restrict__ urec = P.urec[l];
+  const uint32_t *__restrict__ ids = P.ids[l];
+  const int bitshift = rev ? -2 * shift : 2 * shift;
+  const int lo = rev ? shift : 0;
+  const int mref = rev ? ref_len + shift : ref_len - shift;
+  // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
+  // (mask[0][..] / mask[shift][..] of reorder.h:291-301)
+  auto within_thresh = [&](uint32_t r) -> bool {
+    const int clen = P.uniform_len ? P.L : (int)P.lens[r];
+    const int m = clen < mref ? clen : mref;
+    const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
+    const int blo = 2 * lo, bhi = 2 * m;
+    int hd = 0;
+    for (int i = 0; i < W; i++) {
+      const int s0 = i * 64;
+      if (s0 >= bhi) break;
+      if (s0 + 64 <= blo) continue;
+      uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
+      if (blo > s0) x &= ~0ull << (blo - s0);
+      if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
+      hd += __popcll(x);
+    }
+    return hd <= THRESH;
+  };
+  for (int skip = 0;; skip++) {
+    uint32_t pay;
+    const int kind = tab_find(P.fpt, P.bshift, hsh, l, skip, pay, other);
+    if (kind == 0) break;  // key absent
+    if (kind == 2) {       // single-read bin: pay is the read id
+      // a taken read contributes nothing whether this slot is the key's bin or a fingerprint collision:
+      // test the bitmap (12.5 MB, cache-resident) before spending a random 64-byte read on the key check
+      if (is_taken(P.taken, pay)) continue;
+      if (read_window(P.reads + (uint64_t)pay * P.S, P.S, ds, klen2) != key) continue;  // fingerprint collision
+      keyok = true; ncand = 1;
+      if (within_thresh(pay)) { hit = true; rid = pay; }
+      break;
+    }
+    const ulonglong2 rec = urec[pay];
+    if (rec.x != key) continue;  // fingerprint collision
+    const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
+    int live = 0;
+    for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
+      const uint32_t r = ids[start + j];
+      if (is_taken(P.taken, r)) continue;
+      live++; keyok = true; ncand++;
+      if (within_thresh(r)) { hit = true; rid = r; break; }
+    }
+    break;
+  }
+}
+
+// priority code of a probe: the reference tries shift ascending, forward before reverse, dictionary 0
+// before 1 (reorder.h:479-558, :262-316); the lowest code that hits is the reference's winner
+__device__ __forceinline__ int probe_code(int shift, int rev, int l) { return (shift << 2) | (rev << 1) | l; }
+__device__ __forceinline__ bool probe_valid(const DevParams &P, int l, int rev, int shift, int ref_len) {
+  if (shift >= P.maxshift) return false;
+  return rev ? (P.dend[l] < ref_len + shift && P.dstart[l] > shift) : (P.dend[l] + shift < ref_len);
+}
+
 struct BatchOut {
-  uint32_t found, rid, win, pad;
+  uint32_t found, rid;
+  int code;          // probe_code of the winner
+  uint64_t pm;       // lanes whose bucket fetch did not prove the key absent from the OTHER dictionary
   uint64_t st_p, st_k, st_c;
 };
 
+// ---- shifts [sh_base, sh_base + nsh), nsh <= 16, in lane order: lane = 4*(shift - sh_base) + 2*rev + dict,
+// so lane order == priority order and the first set bit of the hit ballot is the reference's winner.
+// STATS counts what the reference would have executed: every valid probe up to and including the winner.
 template <bool STATS>
-__device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev, int b,
-                                            int lane, int ref_len, int fs, BatchOut &out) {
-  const int W = P.W;
+__device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
+                                            int sh_base, int nsh, int lane, int ref_len, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
-  const int ds = P.dstart[l], de = P.dend[l];
-  const int klen2 = 2 * (de - ds + 1);
+  const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
-  const uint4 *__restrict__ fpt = P.fpt[l];
-  const ulonglong2 *__restrict__ urec = P.urec[l];
-  const int bshift = P.bshift[l];
-  const uint32_t *__restrict__ ids = P.ids[l];
-  const bool have_keys = P.numkeys[l] > 0;
   const uint64_t *sx = rev ? srev : sref;
-  // batch 0 covers only the first P.first_shifts shifts (its upper lanes stay idle): most searches that succeed do
-  // so within a few shifts, and every lane past the winner is a wasted 64-byte request
-  const int shift = b == 0 ? (lane >> 2) : fs + (b - 1) * 16 + (lane >> 2);
-  bool valid = shift < P.maxshift && (b != 0 || (lane >> 2) < fs);
-  if (!rev) valid = valid && (de + shift < ref_len);
-  else valid = valid && (de < ref_len + shift) && (ds > shift);
-  bool hit = false, keyok = false;
+  const int shift = sh_base + (lane >> 2);
+  const bool valid = (lane >> 2) < nsh && probe_valid(P, l, rev, shift, ref_len);
+  bool hit = false, keyok = false, other = false;
   uint32_t rid = 0, ncand = 0;
-  if (valid && have_keys) {
-    const int kb = rev ? 2 * (ds - shift) : 2 * (ds + shift);
-    const uint64_t key = lds_window(sx, kb) & kmask;
-    const uint64_t hsh = mix64(key);
-    const int bitshift = rev ? -2 * shift : 2 * shift;
-    const int lo = rev ? shift : 0;
-    const int mref = rev ? ref_len + shift : ref_len - shift;
-    // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
-    // (mask[0][..] / mask[shift][..] of reorder.h:291-301)
-    auto within_thresh = [&](uint32_t r) -> bool {
-      const int clen = P.uniform_len ? P.L : (int)P.lens[r];
-      const int m = clen < mref ? clen : mref;
-      const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
-      const int blo = 2 * lo, bhi = 2 * m;
-      int hd = 0;
-      for (int i = 0; i < W; i++) {
-        const int s0 = i * 64;
-        if (s0 >= bhi) break;
-        if (s0 + 64 <= blo) continue;
-        uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
-        if (blo > s0) x &= ~0ull << (blo - s0);
-        if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
-        hd += __popcll(x);
-      }
-      return hd <= THRESH;
-    };
-    for (int skip = 0;; skip++) {
-      uint32_t pay;
-      const int kind = tab_find(fpt, bshift, hsh, skip, pay);
-      if (kind == 0) break;  // key absent
-      if (kind == 2) {       // single-read bin: pay is the read id
-        // a taken read contributes nothing whether this slot is the key's bin or a fingerprint collision:
-        // test the bitmap (12.5 MB, cache-resident) before spending a random 64-byte read on the key check
-        if (is_taken(P.taken, pay)) continue;
-        if (read_window(P.reads + (uint64_t)pay * P.S, P.S, ds, klen2) != key) continue;  // fingerprint collision
-        keyok = true; ncand = 1;
-        if (within_thresh(pay)) { hit = true; rid = pay; }
-        break;
-      }
-      const ulonglong2 rec = urec[pay];
-      if (rec.x != key) continue;  // fingerprint collision
-      const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
-      int live = 0;
-      for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
-        const uint32_t r = ids[start + j];
-        if (is_taken(P.taken, r)) continue;
-        live++; keyok = true; ncand++;
-        if (within_thresh(r)) { hit = true; rid = r; break; }
-      }
-      break;
-    }
+  if (valid) {
+    const int ds = P.dstart[l];
+    const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
+    eval_probe(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other);
   }
   const uint64_t hm = __ballot(hit);
   const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
   out.found = hm != 0;
-  out.win = (uint32_t)win;
+  out.code = probe_code(sh_base + (win >> 2), (win >> 1) & 1, win & 1);
   out.rid = (uint32_t)__shfl((int)rid, win, 64);
+  out.pm = __ballot(other);
   out.st_p = out.st_k = out.st_c = 0;
   if (STATS) {
     const uint64_t le = win == 63 ? ~0ull : ((1ull << (win + 1)) - 1);
@@ -723,19 +748,134 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   }
 }
 
+// ---- every remaining probe (shifts [t0, maxshift)) at once, one bucket fetch per distinct consensus window.
+// A forward window at consensus offset off is the key of dictionary 0 at shift off - start0 and of dictionary
+// 1 at shift off - start1 = (off - start0) - wl; a reverse window of dictionary 0 at start0 - off and of
+// dictionary 1 at start1 - off.  Windows already fetched by the ordered batches (as the dict-1 probe of a
+// forward shift < t0, or the dict-0 probe of a reverse shift < t0) are skipped unless that fetch saw a slot
+// of the other dictionary (pm0 / pm1).  The needed windows are compacted into `list` (LDS) so that a
+// failing search of a 150-base consensus costs 32 + 64 + 55 fetches in three dependent steps (was 237 in
+// six).  Lanes no longer run in priority order: the winner is the hit with the lowest probe_code.
+constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
+template <bool STATS>
+__device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
+                                           uint16_t *list, uint16_t *stat, int t0, int fs, uint64_t pm0,
+                                           uint64_t pm1, int lane, int ref_len, BatchOut &out) {
+  const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
+  const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
+  // did the ordered batches' fetch for shift sp (lane slot x: 1 = forward dict 1, 2 = reverse dict 0) leave
+  // the other dictionary's presence open?
+  auto present = [&](int sp, int x) -> bool {
+    const uint64_t m = sp < fs ? pm0 : pm1;
+    return (m >> (4 * (sp < fs ? sp : sp - fs) + x)) & 1ull;
+  };
+  const int nF = wl + ms - t0;
+  int T = 0;
+  for (int base = 0; base < 2 * nF; base += 64) {
+    const int idx = base + lane;
+    bool v0 = false, v1 = false;
+    int rev = 0, i = 0;
+    if (idx < 2 * nF) {
+      rev = idx >= nF;
+      i = rev ? idx - nF : idx;
+      if (!rev) {
+        const int sh0 = t0 + i, sh1 = sh0 - wl;
+        v0 = probe_valid(P, 0, 0, sh0, ref_len);
+        v1 = sh1 >= t0 && probe_valid(P, 1, 0, sh1, ref_len);
+        if (v0 && sh1 >= 0 && sh1 < t0) v0 = present(sh1, 1);
+      } else {
+        const int sh1 = t0 + i, sh0 = sh1 - wl;
+        v1 = probe_valid(P, 1, 1, sh1, ref_len);
+        v0 = sh0 >= t0 && probe_valid(P, 0, 1, sh0, ref_len);
+        if (v1 && sh0 >= 0 && sh0 < t0) v1 = present(sh0, 2);
+      }
+    }
+    const bool need = v0 || v1;
+    const uint64_t m = __ballot(need);
+    if (need) {
+      const int at = T + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      list[at] = (uint16_t)((rev << 15) | ((int)v1 << 14) | ((int)v0 << 13) | i);
+      if (STATS) { stat[2 * at] = 0; stat[2 * at + 1] = 0; }
+    }
+    T += __popcll(m);
+  }
+  wave_sync();
+  int best = 0x7fffffff;
+  uint32_t brid = 0;
+  for (int base = 0; base < T; base += 64) {
+    const int j = base + lane;
+    if (j < T) {
+      const uint32_t e = list[j];
+      const int rev = (int)(e >> 15), i = (int)(e & 0x1ffu);
+      int sh0, sh1, off;
+      if (!rev) { sh0 = t0 + i; sh1 = sh0 - wl; off = s0 + sh0; }
+      else { sh1 = t0 + i; sh0 = sh1 - wl; off = s1 - sh1; }
+      const uint64_t *sx = rev ? srev : sref;
+      const uint64_t key = lds_window(sx, 2 * off) & kmask;
+      const uint64_t hsh = mix64(key);
+      // the probe with the lower priority code first: forward dictionary 1 (its shift is wl lower), reverse dictionary 0
+#pragma nounroll
+      for (int k = 0; k < 2; k++) {
+        const int l = rev ? k : 1 - k;
+        if (!((e >> (13 + l)) & 1u)) continue;
+        const int sh = l ? sh1 : sh0;
+        bool hit = false, keyok = false, other = false;
+        uint32_t rid = 0, ncand = 0;
+        eval_probe(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other);
+        if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
+        if (hit) {
+          const int code = probe_code(sh, rev, l);
+          if (code < best) { best = code; brid = rid; }
+          break;
+        }
+      }
+    }
+  }
+  int wmin = best;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o, 64));
+  out.found = wmin != 0x7fffffff;
+  out.code = wmin;
+  const uint64_t wm = __ballot(best == wmin);
+  out.rid = (uint32_t)__shfl((int)brid, __ffsll((unsigned long long)wm) - 1, 64);
+  out.pm = 0;
+  out.st_p = out.st_k = out.st_c = 0;
+  if (STATS) {  // what the reference would have executed: every valid probe of the tail up to the winner
+    int cp = 0, ck = 0, cc = 0;
+    for (int idx = lane; idx < (ms - t0) * 4; idx += 64) {
+      const int sh = t0 + (idx >> 2), rev = (idx >> 1) & 1, l = idx & 1;
+      if (probe_valid(P, l, rev, sh, ref_len) && probe_code(sh, rev, l) <= wmin) cp++;
+    }
+    wave_sync();
+    for (int j = lane; j < T; j += 64) {
+      const uint32_t e = list[j];
+      const int rev = (int)(e >> 15), i = (int)(e & 0x1ffu);
+      const int sh0 = rev ? t0 + i - wl : t0 + i, sh1 = rev ? t0 + i : t0 + i - wl;
+      for (int l = 0; l < 2; l++) {
+        if (!((e >> (13 + l)) & 1u)) continue;
+        if (probe_code(l ? sh1 : sh0, rev, l) > wmin) continue;
+        const uint32_t sv = stat[2 * j + l];
+        ck += (int)(sv >> 15); cc += (int)(sv & 0x7fffu);
+      }
+    }
+    out.st_p = (uint64_t)wave_sum_i(cp); out.st_k = (uint64_t)wave_sum_i(ck); out.st_c = (uint64_t)wave_sum_i(cc);
+  }
+}
+
 // ------------------------------------------------------------ K4 search (phase A)
 //
-// One wavefront per chain.  search_match + shift loop (reorder.h:246-318,
-// :479-558): 64 probes per batch, lane = 4*(shift%16) + 2*rev + dict, so lane
-// order == the reference's priority order (shift, fwd before rev, dict 0
-// before 1) and the first set bit of the hit ballot is the reference's winner.
-// Chains that need a new contig seed instead pick the (rank+1)-th highest
-// untaken read at or below the global cursor (reorder.h:576-592).
-template <bool STATS, bool MG>
-__global__ __launch_bounds__(256) void k_search(DevParams P) {
-  __shared__ uint64_t s_refs[4][2][LDS_LIMBS];
+// One wavefront per chain.  search_match + shift loop (reorder.h:246-318, :479-558): two ordered batches
+// (shifts [0, fs) and [fs, fs + 16): lane order == the reference's priority order, the first set bit of the
+// hit ballot is the reference's winner), then the tail (every remaining window at once, winner = lowest
+// priority code).  Chains that need a new contig seed instead pick the (rank+1)-th highest untaken read at
+// or below the global cursor (reorder.h:576-592).  WPB = chains (wavefronts) per block.
+template <bool STATS, bool MG, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_search(DevParams P) {
+  __shared__ uint64_t s_refs[WPB][2][LDS_LIMBS];
+  __shared__ uint16_t s_list[WPB][TAIL_CAP];
+  __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t li = blockIdx.x * 4 + wave;
+  const uint32_t li = blockIdx.x * WPB + wave;
   if (li >= P.K) return;
   const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
   Chain *c = &P.chains[li];
@@ -801,23 +941,29 @@ __global__ __launch_bounds__(256) void k_search(DevParams P) {
   }
   const uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
   wave_sync();
-  // batches of 16 shifts in priority order; most chains match in batch 0
-  // a fresh seed (nothing matched to it yet) fails about every second search: it gets the full first batch
+  // most chains match within the first few shifts: the first batch covers only fs of them (every lane past the
+  // winner is a wasted 64-byte request).  A fresh seed (nothing matched to it yet) fails about every second
+  // search: it gets a full first batch.
   const int fs = (h.prev_unmatched && P.seed_wide) ? 16 : P.first_shifts;
-  const int nbatch = P.maxshift <= fs ? 1 : 1 + ((P.maxshift - fs + 15) >> 4);
   BatchOut o;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
-  int wb = 0;
-  for (int b = 0; b < nbatch; b++) {
-    probe_batch<STATS>(P, sref, srev, b, lane, ref_len, fs, o);
+  probe_batch<STATS>(P, sref, srev, 0, fs, lane, ref_len, o);
+  st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
+  if (!o.found && fs < P.maxshift) {
+    const uint64_t pm0 = o.pm;
+    probe_batch<STATS>(P, sref, srev, fs, 16, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
-    if (o.found) { wb = b; break; }
+    if (!o.found && fs + 16 < P.maxshift) {
+      const uint64_t pm1 = o.pm;
+      probe_tail<STATS>(P, sref, srev, s_list[wave], s_stat[STATS ? wave : 0], fs + 16, fs, pm0, pm1, lane, ref_len, o);
+      st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
+    }
   }
   if (lane == 0) {
     if (o.found) {
       c->h.prop_rid = o.rid;
-      c->h.prop_shift = (wb == 0 ? 0 : fs + (wb - 1) * 16) + (int)(o.win >> 2);
-      c->h.prop_rev = (uint8_t)((o.win >> 1) & 1);
+      c->h.prop_shift = o.code >> 2;
+      c->h.prop_rev = (uint8_t)((o.code >> 1) & 1);
       c->h.prop_kind = PROP_MATCH;
       if (MG) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;  // resolved after the exchange
       else atomicMin(&P.resv[o.rid], cid);
@@ -1127,25 +1273,28 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
                  int S, int dstart, int dend, uint64_t *keys, uint32_t *vals) {
   hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
 }
-void launch_tab_insert(hipStream_t st, const uint64_t *ukeys, const uint32_t *ustart, const uint32_t *ucount,
-                       const uint32_t *ids, uint32_t numkeys, uint4 *fpt, ulonglong2 *urec, int bshift,
-                       uint32_t *deep, uint32_t *ndeep) {
-  if (!numkeys) return;
-  hipLaunchKernelGGL(k_tab_insert<false>, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
-                     reinterpret_cast<uint32_t *>(fpt), urec, bshift, deep, ndeep);
-  hipLaunchKernelGGL(k_tab_insert<true>, GRID1(numkeys, 256), dim3(256), 0, st, ukeys, ustart, ucount, ids, numkeys,
-                     reinterpret_cast<uint32_t *>(fpt), urec, bshift, deep, ndeep);
+void launch_tab_insert(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
+                       DictBuild d1, uint4 *fpt, int bshift) {
+  if (!nmerged) return;
+  hipLaunchKernelGGL(k_tab_insert<false>, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1,
+                     reinterpret_cast<uint32_t *>(fpt), bshift);
+  hipLaunchKernelGGL(k_tab_insert<true>, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1,
+                     reinterpret_cast<uint32_t *>(fpt), bshift);
+}
+void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_iota_tag, GRID1(n, 256), dim3(256), 0, st, v, n, tag);
 }
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
                       ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken) {
   if (!ndeep_host) return;
   hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 256), dim3(256), 0, st, deep, ndeep, urec, ids, taken);
 }
-void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift,
+void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count) {
   if (!nkeys) return;
-  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bshift, reads, S, dstart,
+  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bshift, which, reads, S, dstart,
                      2 * (dend - dstart + 1), keys, nkeys, start, count);
 }
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
@@ -1170,22 +1319,23 @@ void launch_init_chains(hipStream_t st, const DevParams &P) {
   NP_DISPATCH(CALL);
 #undef CALL
 }
+template <int WPB>
+static void launch_search_wpb(hipStream_t st, const DevParams &P, bool stats) {
+  const dim3 g((P.K + WPB - 1) / WPB), b(64 * WPB);
+  const size_t dyn = (size_t)P.dbg_search_lds;  // occupancy experiment: dummy dynamic LDS per block
+  if (P.prop) {
+    if (stats) hipLaunchKernelGGL((k_search<true, true, WPB>), g, b, dyn, st, P);
+    else hipLaunchKernelGGL((k_search<false, true, WPB>), g, b, dyn, st, P);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_search<true, false, WPB>), g, b, dyn, st, P);
+    else hipLaunchKernelGGL((k_search<false, false, WPB>), g, b, dyn, st, P);
+  }
+}
 void launch_search(hipStream_t st, const DevParams &P, bool stats) {
   if (!P.K) return;
-  const dim3 g((P.K + 3) / 4), b(256);
-  // occupancy experiment: SPRING_DBG_SEARCH_LDS=<bytes> adds dummy dynamic LDS per block
-  static const int dbg_lds = getenv("SPRING_DBG_SEARCH_LDS") ? atoi(getenv("SPRING_DBG_SEARCH_LDS")) : 0;
-  if (dbg_lds && !P.prop && !stats) {
-    hipLaunchKernelGGL((k_search<false, false>), g, b, (size_t)dbg_lds, st, P);
-    return;
-  }
-  if (P.prop) {
-    if (stats) hipLaunchKernelGGL((k_search<true, true>), g, b, 0, st, P);
-    else hipLaunchKernelGGL((k_search<false, true>), g, b, 0, st, P);
-  } else {
-    if (stats) hipLaunchKernelGGL((k_search<true, false>), g, b, 0, st, P);
-    else hipLaunchKernelGGL((k_search<false, false>), g, b, 0, st, P);
-  }
+  if (P.search_wpb == 1) launch_search_wpb<1>(st, P, stats);
+  else if (P.search_wpb == 2) launch_search_wpb<2>(st, P, stats);
+  else launch_search_wpb<4>(st, P, stats);
 }
 void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
   if (!P.K) return;
@@ -1198,8 +1348,7 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
     return;
   }
   if (literal) { hipLaunchKernelGGL((k_apply<8, true, false>), g, b, 0, st, P); return; }
-  static const int dbg_lds = getenv("SPRING_DBG_APPLY_LDS") ? atoi(getenv("SPRING_DBG_APPLY_LDS")) : 0;  // occupancy experiment
-#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, false>), g, b, (size_t)dbg_lds, st, P)
+#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, false>), g, b, (size_t)P.dbg_apply_lds, st, P)  // dbg: occupancy experiment
   NP_DISPATCH(CALL);
 #undef CALL
 }
@@ -1240,6 +1389,10 @@ hipError_t sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64
 hipError_t rle(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *in, size_t n, uint64_t *uniq,
                uint32_t *counts, uint32_t *nruns) {
   return rocprim::run_length_encode(tmp, tmp_bytes, in, n, uniq, counts, nruns, st);
+}
+hipError_t merge_by_hash(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *k0, const uint64_t *k1,
+                         const uint64_t *v0, const uint64_t *v1, uint64_t *kout, uint64_t *vout, size_t n0, size_t n1) {
+  return rocprim::merge(tmp, tmp_bytes, k0, k1, kout, v0, v1, vout, n0, n1, rocprim::less<uint64_t>(), st);
 }
 hipError_t excl_scan_u32(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *in, uint32_t *out, size_t n) {
   return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), st);

@@ -105,8 +105,6 @@ enum { ST_CREATED = 0, ST_LOADED = 1, ST_DICT = 2, ST_CHAINS = 3, ST_FINAL = 4 }
 struct DictDev {
   int start = 0, end = 0;
   uint32_t numkeys = 0, numreads = 0;
-  int bshift = 63;  // bucket = hash >> bshift
-  uint4 *fpt = nullptr;
   ulonglong2 *urec = nullptr;
   uint32_t *ids = nullptr;
   uint32_t *deep = nullptr, *d_ndeep = nullptr;  // bins with >= DEEP_BIN reads (k_trim_bins)
@@ -131,6 +129,8 @@ struct spring_reorder_ctx {
   uint64_t *d_reads = nullptr;
   uint16_t *d_lens = nullptr;
   DictDev dict[2];
+  uint4 *fpt = nullptr;   // one bucket table for both dictionaries (reorder_kernels.hip, tab_find)
+  int bshift = 63;        // bucket = hash >> bshift
   DevParams P;
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
@@ -619,7 +619,7 @@ static double now_ms() {
   } while (0)
 
 int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
-  const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;
+  const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;  // stage timings on stderr, no effect on results
   double t_last = now_ms();
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage != ST_LOADED) return fail(SPRING_REORDER_E_STATE, "build_dict: load reads first");
@@ -627,6 +627,8 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
   hipStream_t st = ctx->st;
   const uint32_t n = ctx->n;
   HIPCHK(hipEventRecord(ctx->ev[2], st));
+  uint64_t *uhash[2] = {nullptr, nullptr};          // sorted unique mix64(key) per dictionary
+  uint32_t *ustart[2] = {nullptr, nullptr}, *ucount[2] = {nullptr, nullptr};
   for (int l = 0; l < 2; l++) {
     DictDev &d = ctx->dict[l];
     uint32_t m = 0;
@@ -653,17 +655,18 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     }
     d.numreads = m;
     d.numkeys = 0;
+    d.ndeep = 0;
     if (m == 0) {
-      d.bshift = 63;
-      DMALLOC(d.fpt, 64);
-      HIPCHK(hipMemsetAsync(d.fpt, 0, 64, st));
       DMALLOC(d.urec, 16);
       DMALLOC(d.ids, 16);
+      DMALLOC(d.deep, 16);
+      DMALLOC(d.d_ndeep, 16);
+      HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 4, st));
       if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
       continue;
     }
     uint64_t *k_in = nullptr, *k_out = nullptr;
-    uint32_t *v_in = nullptr, *cnt = nullptr, *ustart = nullptr, *d_nruns = nullptr;
+    uint32_t *v_in = nullptr, *cnt = nullptr, *d_nruns = nullptr;
     DMALLOC(k_in, (size_t)m * 8);
     DMALLOC(k_out, (size_t)m * 8);
     DMALLOC(v_in, (size_t)m * 4);
@@ -678,11 +681,10 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     tmp_bytes = 0;
     HIPCHK(sort_pairs(st, nullptr, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
     DMALLOC(d_tmp, tmp_bytes);
-    DBG_T("alloc sorttmp");
     HIPCHK(sort_pairs(st, d_tmp, tmp_bytes, k_in, k_out, v_in, d.ids, m, end_bit));
     DBG_T("sort");
     ctx->dfree(d_tmp); d_tmp = nullptr;
-    DBG_T("free sorttmp");
+    ctx->dfree(v_in);
     // unique keys + run lengths (bitset_util.h:122-127), reuse k_in for the unique keys
     DMALLOC(cnt, (size_t)m * 4);
     DMALLOC(d_nruns, 16);
@@ -694,42 +696,78 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     HIPCHK(hipMemcpyAsync(&numkeys, d_nruns, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     ctx->dfree(d_tmp); d_tmp = nullptr;
+    ctx->dfree(k_out); ctx->dfree(d_nruns);
     d.numkeys = numkeys;
     DBG_T("rle");
-    DMALLOC(ustart, (size_t)numkeys * 4);
+    DMALLOC(ustart[l], (size_t)numkeys * 4);
     tmp_bytes = 0;
-    HIPCHK(excl_scan_u32(st, nullptr, tmp_bytes, cnt, ustart, numkeys));
+    HIPCHK(excl_scan_u32(st, nullptr, tmp_bytes, cnt, ustart[l], numkeys));
     DMALLOC(d_tmp, tmp_bytes);
-    HIPCHK(excl_scan_u32(st, d_tmp, tmp_bytes, cnt, ustart, numkeys));
-    // exact map: 4-slot 32-byte fingerprint buckets + 16-byte records
-    // load <= 0.2: 98 % of the probes are absent keys and stop at the first empty slot of their home bucket; a
-    // full bucket (4 keys) sends them on to the next one.  Halving the load from 0.4 cuts full buckets from 5.6 %
-    // to 0.7 % and the chains stage by 2.2 % (a further halving: another 1.5 %, for 2 x 8.6 GB more at 100 M reads).
-    // SPRING_TAB_SCALE = 1 / 2 / 4 overrides (1 = the smallest table, load <= 0.4).
-    static const int tab_scale = getenv("SPRING_TAB_SCALE") ? std::max(1, atoi(getenv("SPRING_TAB_SCALE"))) : 2;
-    const uint64_t nb = pow2ceil(std::max<uint64_t>(2, ((uint64_t)numkeys * 10 + 15) / 16)) * (uint64_t)pow2ceil(tab_scale);
-    d.bshift = 64;
-    for (uint64_t v = nb; v > 1; v >>= 1) d.bshift--;
+    HIPCHK(excl_scan_u32(st, d_tmp, tmp_bytes, cnt, ustart[l], numkeys));
     DBG_T("scan");
-    DMALLOC(d.fpt, nb * 32);
+    uhash[l] = k_in;
+    ucount[l] = cnt;
     DMALLOC(d.urec, (size_t)numkeys * 16);
-    DBG_T("alloc tab");
-    HIPCHK(hipMemsetAsync(d.fpt, 0, nb * 32, st));
-    DBG_T("memset tab");
     // deep-bin list: at most one entry per DEEP_BIN reads of the dictionary
     DMALLOC(d.deep, ((size_t)m / DEEP_BIN + 1) * 4);
     DMALLOC(d.d_ndeep, 16);
     HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 4, st));
-    launch_tab_insert(st, k_in, ustart, cnt, d.ids, numkeys, d.fpt, d.urec, d.bshift, d.deep, d.d_ndeep);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&d.ndeep, d.d_ndeep, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    DBG_T("insert");
-    ctx->dfree(d_tmp); ctx->dfree(k_in); ctx->dfree(k_out); ctx->dfree(v_in); ctx->dfree(cnt);
-    ctx->dfree(ustart); ctx->dfree(d_nruns);
-    DBG_T("free temps");
+    ctx->dfree(d_tmp);
     if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
   }
+  // ---- one bucket table for both dictionaries.  The (key, dictionary) pairs are merged by hash = by bucket,
+  // so k_tab_insert streams; a key of both dictionaries lands in the same bucket and one bucket fetch serves
+  // the probes of both (k_search).  Exact map: 4-slot 32-byte fingerprint buckets + 16-byte records.
+  // Load <= 0.2: 98 % of the probes are absent keys and stop at the first empty slot of their home bucket; a
+  // full bucket (4 pairs) sends them on to the next one.  Halving the load from 0.4 cut full buckets from 5.6 %
+  // to 0.7 % and the chains stage by 2.2 % (a further halving: another 1.5 %, for 17 GB more at 100 M reads).
+  // opts.tab_scale = 1 / 2 / 4 overrides (1 = the smallest table, load <= 0.4).
+  const uint64_t nk0 = ctx->dict[0].numkeys, nk1 = ctx->dict[1].numkeys, nm = nk0 + nk1;
+  const int tab_scale = ctx->o.tab_scale > 0 ? ctx->o.tab_scale : 2;
+  const uint64_t nb = pow2ceil(std::max<uint64_t>(2, (nm * 10 + 15) / 16)) * (uint64_t)pow2ceil(tab_scale);
+  ctx->bshift = 64;
+  for (uint64_t v = nb; v > 1; v >>= 1) ctx->bshift--;
+  DMALLOC(ctx->fpt, nb * 32);
+  HIPCHK(hipMemsetAsync(ctx->fpt, 0, nb * 32, st));
+  DBG_T("alloc+memset tab");
+  if (nm) {
+    uint64_t *mv0 = nullptr, *mv1 = nullptr, *mh = nullptr, *mv = nullptr;
+    void *d_tmp = nullptr;
+    DMALLOC(mv0, std::max<uint64_t>(nk0, 1) * 8);
+    DMALLOC(mv1, std::max<uint64_t>(nk1, 1) * 8);
+    launch_iota_tag(st, mv0, nk0, 0ull);
+    launch_iota_tag(st, mv1, nk1, 1ull << 63);
+    const uint64_t *h_in = nullptr, *v_in = nullptr;
+    if (nk0 && nk1) {
+      DMALLOC(mh, nm * 8);
+      DMALLOC(mv, nm * 8);
+      size_t tb = 0;
+      HIPCHK(merge_by_hash(st, nullptr, tb, uhash[0], uhash[1], mv0, mv1, mh, mv, nk0, nk1));
+      DMALLOC(d_tmp, tb);
+      HIPCHK(merge_by_hash(st, d_tmp, tb, uhash[0], uhash[1], mv0, mv1, mh, mv, nk0, nk1));
+      h_in = mh; v_in = mv;
+    } else {
+      h_in = nk0 ? uhash[0] : uhash[1];
+      v_in = nk0 ? mv0 : mv1;
+    }
+    DBG_T("merge");
+    DictBuild db[2];
+    for (int l = 0; l < 2; l++) {
+      DictDev &d = ctx->dict[l];
+      db[l].ustart = ustart[l]; db[l].ucount = ucount[l]; db[l].ids = d.ids; db[l].urec = d.urec;
+      db[l].deep = d.deep; db[l].ndeep = d.d_ndeep;
+    }
+    launch_tab_insert(st, h_in, v_in, nm, db[0], db[1], ctx->fpt, ctx->bshift);
+    HIPCHK(hipGetLastError());
+    for (int l = 0; l < 2; l++)
+      HIPCHK(hipMemcpyAsync(&ctx->dict[l].ndeep, ctx->dict[l].d_ndeep, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    DBG_T("insert");
+    ctx->dfree(mv0); ctx->dfree(mv1); ctx->dfree(mh); ctx->dfree(mv); ctx->dfree(d_tmp);
+  }
+  for (int l = 0; l < 2; l++) { ctx->dfree(uhash[l]); ctx->dfree(ustart[l]); ctx->dfree(ucount[l]); }
+  DBG_T("free temps");
   HIPCHK(hipEventRecord(ctx->ev[3], st));
   ctx->stage = ST_DICT;
   return 0;
@@ -749,7 +787,7 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
   std::vector<uint32_t> hs(nkeys), hc(nkeys), hids(d.numreads);
   if (nkeys) {
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)nkeys * 8, hipMemcpyHostToDevice, ctx->st));
-    launch_dict_lookup(ctx->st, d.fpt, d.urec, d.bshift, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
+    launch_dict_lookup(ctx->st, ctx->fpt, d.urec, ctx->bshift, which, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
     HIPCHK(hipMemcpyAsync(hs.data(), ds, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(hc.data(), dc, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
   }
@@ -774,10 +812,25 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
 }
 
 // ------------------------------------------------------------------ chains
-// width of a search's first batch: 8 of the 16 shift slots; SPRING_FIRST_SHIFTS overrides
-static int first_shifts_knob() {
-  static const int v = getenv("SPRING_FIRST_SHIFTS") ? std::min(16, std::max(1, atoi(getenv("SPRING_FIRST_SHIFTS")))) : 8;
-  return v;
+// fields of DevParams shared by run_chains and mg_begin; the tuning values come from spring_reorder_opts (results
+// do not depend on them) -- DESIGN.md section 6
+static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
+  const spring_reorder_opts &o = ctx->o;
+  P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = ctx->n;
+  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad;
+  P.maxshift = ctx->L / 2;  // reorder.h:750
+  P.first_shifts = o.first_shifts > 0 ? std::min(16, o.first_shifts) : 8;
+  P.seed_wide = o.seed_wide < 0 ? 0 : 1;
+  P.search_wpb = (o.search_wpb == 1 || o.search_wpb == 2 || o.search_wpb == 4) ? o.search_wpb : 4;
+  P.dbg_search_lds = std::max(0, o.dbg_search_lds);
+  P.dbg_apply_lds = std::max(0, o.dbg_apply_lds);
+  P.uniform_len = ctx->uniform ? 1 : 0;
+  P.wl = ctx->dict[0].end - ctx->dict[0].start + 1;  // == dict[1].end - dict[1].start + 1 (reorder.h:751-759)
+  for (int l = 0; l < 2; l++) {
+    P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
+    P.urec[l] = ctx->dict[l].urec; P.ids[l] = ctx->dict[l].ids;
+  }
+  P.fpt = ctx->fpt; P.bshift = ctx->bshift;
 }
 static uint32_t auto_chains(uint32_t n) {
   uint64_t k = n >> 10;  // ~1000 reads per chain
@@ -795,14 +848,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n);
   ctx->K = K;
   DevParams &P = ctx->P;
-  P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
-  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2; P.first_shifts = first_shifts_knob(); P.seed_wide = getenv("SPRING_SEED_WIDE") ? atoi(getenv("SPRING_SEED_WIDE")) : 1;  // reorder.h:750
-  P.uniform_len = ctx->uniform ? 1 : 0;
-  for (int l = 0; l < 2; l++) {
-    P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
-    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bshift[l] = ctx->dict[l].bshift;
-    P.ids[l] = ctx->dict[l].ids;
-  }
+  fill_params(ctx, P);
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
   const size_t nn = std::max<uint32_t>(n, 1);
   DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
@@ -903,14 +949,7 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   const uint32_t n = ctx->n, Ktot = total_chains, K = Ktot / world;
   ctx->K = K;
   DevParams &P = ctx->P;
-  P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = n;
-  P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad; P.maxshift = ctx->L / 2; P.first_shifts = first_shifts_knob(); P.seed_wide = getenv("SPRING_SEED_WIDE") ? atoi(getenv("SPRING_SEED_WIDE")) : 1;
-  P.uniform_len = ctx->uniform ? 1 : 0;
-  for (int l = 0; l < 2; l++) {
-    P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
-    P.fpt[l] = ctx->dict[l].fpt; P.urec[l] = ctx->dict[l].urec; P.bshift[l] = ctx->dict[l].bshift;
-    P.ids[l] = ctx->dict[l].ids;
-  }
+  fill_params(ctx, P);
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
   const size_t nn = std::max<uint32_t>(n, 1);
   DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);

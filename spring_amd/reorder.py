@@ -29,6 +29,13 @@ class ReorderOpts:
     time_search: bool = False
     force_literal_update: bool = False
     rounds_per_sync: int = 0
+    # tuning / experiments (0 = default); the output does not depend on them
+    first_shifts: int = 0
+    seed_wide: int = 0
+    tab_scale: int = 0
+    search_wpb: int = 0
+    dbg_search_lds: int = 0
+    dbg_apply_lds: int = 0
 
     def to_c(self):
         o = _lib.Opts()
@@ -36,6 +43,8 @@ class ReorderOpts:
         o.device, o.num_chains, o.num_thr = self.device, self.num_chains, self.num_thr
         o.collect_stats, o.time_search = int(self.collect_stats), int(self.time_search)
         o.force_literal_update, o.rounds_per_sync = int(self.force_literal_update), self.rounds_per_sync
+        o.first_shifts, o.seed_wide, o.tab_scale = self.first_shifts, self.seed_wide, self.tab_scale
+        o.search_wpb, o.dbg_search_lds, o.dbg_apply_lds = self.search_wpb, self.dbg_search_lds, self.dbg_apply_lds
         return o
 
 

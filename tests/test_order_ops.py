@@ -27,6 +27,31 @@ def test_oracle_order_ops_known_answers():
     assert po.pe_encode(np.array([4, 1, 5, 0, 3, 2], np.uint32)).tolist() == [3, 0, 5, 1, 4, 2]
 
 
+needs_ref = pytest.mark.skipif(po.ref_order_bin() is None, reason="oracle/_ref/ref_order not built (needs /root/reference)")
+
+
+@needs_ref
+@pytest.mark.parametrize("n", [2, 6, 1000, 100_002, 2_000_000])
+def test_oracle_twins_equal_the_real_reference(n):
+    """The oracle's literal twins against the reference's own pe_encode.cpp and generate_order_se/pe, compiled
+    in place (oracle/_ref/ref_order): this pins row f3's oracle."""
+    order, _ = _data(n, 0, 7 * n + 1)
+    assert np.array_equal(po.ref_order("se", order), po.generate_order_se(order))
+    assert np.array_equal(po.ref_order("pe", order), po.generate_order_pe(order))
+    assert np.array_equal(po.ref_order("pe_encode", order), po.pe_encode(order))
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 1000, 3_000_000])
+def test_gpu_order_ops_equal_the_real_reference(n):
+    from spring_amd import order_ops as oo
+    order, _ = _data(n, 0, 3 * n + 5)
+    assert np.array_equal(oo.generate_order_se(order)[0], po.ref_order("se", order))
+    assert np.array_equal(oo.generate_order_pe(order)[0], po.ref_order("pe", order))
+    assert np.array_equal(oo.pe_encode(order)[0], po.ref_order("pe_encode", order))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,nN", [(1, 0), (2, 1), (1000, 37), (100_001, 5000), (100_002, 1), (3_000_000, 250_000)])
 def test_order_ops_bit_exact(n, nN):
