@@ -153,6 +153,28 @@ int spring_reorder_mg_end(spring_reorder_ctx *ctx);
 /* all-gather between `world` contexts living in ONE process on one device (tests). */
 int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world);
 
+/* ---- the same pool with the exchange INSIDE the library (no host round trip per round).
+ * spring_reorder_mg_run = mg_begin + rounds until no chain is running + mg_end; the per-round all-gather of the
+ * proposal words is done by the transport chosen before the call:
+ *   spring_reorder_mg_use_rccl          ncclAllGather (in place) on the library's own stream.  RCCL is loaded at
+ *                                       run time (librccl.so.1), so single-GPU users never pay for it.  Rank 0 makes
+ *                                       the 128-byte id with spring_reorder_rccl_unique_id and the caller hands it
+ *                                       to every rank (bench.py: one torch.distributed broadcast; an MPI or file
+ *                                       exchange works as well); ncclCommInitRank is collective over the ranks.
+ *   spring_reorder_mg_use_host_exchange a caller-supplied all-gather on a host staging buffer: `fn` receives the
+ *                                       whole buffer with this rank's slice filled in and must fill the others
+ *                                       (tests: gloo between two processes that share one GPU; any transport).
+ * Termination needs no extra collective: every rank recounts the running chains from the gathered words.
+ * The reference has no counterpart (its chains are OpenMP threads sharing remainingreads[], reorder.h:343-344,
+ * :402-421); the contract is the one of mg_begin: output == run_chains() with num_chains = total_chains. */
+#define SPRING_RCCL_ID_BYTES 128
+int spring_reorder_rccl_unique_id(void *id128);
+int spring_reorder_mg_use_rccl(spring_reorder_ctx *ctx, const void *id128, uint32_t rank, uint32_t world);
+typedef int (*spring_mg_allgather_fn)(void *host_buf, size_t slice_off, size_t slice_bytes, size_t total_bytes,
+                                      void *user);
+int spring_reorder_mg_use_host_exchange(spring_reorder_ctx *ctx, spring_mg_allgather_fn fn, void *user);
+int spring_reorder_mg_run(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains);
+
 /* Gathers the per-chain emissions into the per-tid streams (the replay side of
  * writetofile, reorder.h:643-730). */
 int spring_reorder_finalize(spring_reorder_ctx *ctx);

@@ -11,6 +11,7 @@ EXPORTS = [
     "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
     "spring_reorder_mg_begin", "spring_reorder_mg_search", "spring_reorder_mg_slice", "spring_reorder_mg_apply",
     "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
+    "spring_reorder_rccl_unique_id", "spring_reorder_mg_use_rccl", "spring_reorder_mg_use_host_exchange", "spring_reorder_mg_run",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
     "spring_reorder_load_fastq", "spring_reorder_fastq_N",
@@ -66,6 +67,9 @@ class Stats(C.Structure):
         return d
 
 
+# spring_mg_allgather_fn (include/spring_reorder.h): host_buf, slice_off, slice_bytes, total_bytes, user -> 0 on success
+MG_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p)
+
 _lib = None
 
 
@@ -99,6 +103,10 @@ def lib():
     L.spring_reorder_mg_apply.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint32)]
     L.spring_reorder_mg_end.argtypes = [vp]
     L.spring_reorder_mg_exchange_virtual.argtypes = [C.POINTER(vp), C.c_uint32]
+    L.spring_reorder_rccl_unique_id.argtypes = [vp]
+    L.spring_reorder_mg_use_rccl.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.spring_reorder_mg_use_host_exchange.argtypes = [vp, MG_ALLGATHER_FN, vp]
+    L.spring_reorder_mg_run.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.spring_reorder_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.spring_reorder_download.argtypes = [vp] + [vp] * 8
     L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -77,10 +77,12 @@ struct DevParams {
   // shared mutable state
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
   uint32_t *resv;     // lowest chain id that proposed read r this round (0xffffffff = none)
-  uint32_t *needy;    // bitmap over chains waiting for a seed
+  uint32_t *needy;    // bitmap over chains waiting for a seed (padded with zero words to a multiple of 256 words)
+  uint32_t *needy_cnt; // multi-GPU pools only (else null): set bits per 64 words of needy (2048 chains), by k_mg_bits
   Globals *glob;
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;
+  unsigned long long *dbg;    // [64] wave-lifetime counters by category (builds with -DSPRING_DBG_WAVETIME only)
   unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
   uint32_t *alive_round;      // [1] chains not done, recounted from prop every round (multi-GPU mode)
   Chain *chains;

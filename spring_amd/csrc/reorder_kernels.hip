@@ -29,6 +29,22 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// experiment builds (-DSPRING_DBG_WAVETIME): per-category wave count and summed lifetime in 10 ns ticks
+#ifdef SPRING_DBG_WAVETIME
+#define WT_BEGIN() const unsigned long long wt_t0_ = wall_clock64()
+#define WT_END(P, lane, cat)                                                           \
+  do {                                                                                 \
+    if ((lane) == 0) {  /* 4096 counter sets: same-address atomics would serialise */  \
+      unsigned long long *d_ = (P).dbg + (size_t)(li & 4095u) * 32;                    \
+      d_[2 * (cat)] += 1ull;                                                           \
+      d_[2 * (cat) + 1] += wall_clock64() - wt_t0_;                                    \
+    }                                                                                  \
+  } while (0)
+#else
+#define WT_BEGIN() do {} while (0)
+#define WT_END(P, lane, cat) do {} while (0)
+#endif
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -115,12 +131,18 @@ __device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshif
   const uint64_t bmask = bucket_mask(bshift);
   uint64_t b = bucket_of(h, bshift);
   for (;;) {
-    const uint4 t = fpt[b * 2], x = fpt[b * 2 + 1];
+    // tags only (16 of the bucket's 32 bytes): 98 % of the probes end here.  The payload word is fetched on a
+    // fingerprint match alone -- a second 16-byte load of every bucket doubles the L1 traffic of a 64-lane
+    // gather and the line is often evicted again before it is read (tools/wave_hop_bench.hip)
+    const uint4 t = fpt[b * 2];
     other = other || (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || t.w != 0;
-#define SLOT(T, X)                                              \
+#define SLOT(T, I)                                              \
     if ((T) == 0) return 0;                                     \
-    if (((T) & ~1u) == mine && skip-- == 0) { pay = (X); return 1 + (int)((T) & 1u); }
-    SLOT(t.x, x.x) SLOT(t.y, x.y) SLOT(t.z, x.z) SLOT(t.w, x.w)
+    if (((T) & ~1u) == mine && skip-- == 0) {                   \
+      pay = reinterpret_cast<const uint32_t *>(fpt)[b * 8 + 4 + (I)]; \
+      return 1 + (int)((T) & 1u);                               \
+    }
+    SLOT(t.x, 0) SLOT(t.y, 1) SLOT(t.z, 2) SLOT(t.w, 3)
 #undef SLOT
     b = (b + 1) & bmask;
   }
@@ -598,17 +620,47 @@ __global__ void k_init_seeds(DevParams P) {
 // the pool is exhausted; *is_last = this chain proposes the lowest seed of the round.
 __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid, int lane, bool *is_last) {
   int r = 0, tot = 0;
+  long long top = P.glob->cursor;  // issued together with the loads below
   const uint32_t nw = (P.Ktot + 31) / 32;
-  for (uint32_t w = lane; w < nw; w += 64) {
-    uint32_t v = P.needy[w];
-    tot += __popc(v);
-    if (w * 32 + 32 <= cid) r += __popc(v);
-    else if (w * 32 <= cid) r += __popc(v & ((1u << (cid - w * 32)) - 1u));
+  const uint32_t myw = cid >> 5;
+  if (P.needy_cnt) {
+    // multi-GPU pools (k_mg_bits fills needy_cnt): needy_cnt[b] = seed-needing chains among chains
+    // [2048 b, 2048 b + 2048), then the 64 bitmap words of this chain's own block -- two independent loads per
+    // lane, whatever the total number of chains
+    const uint32_t nblk = (nw + 63) / 64, myblk = myw >> 6;
+    {
+      const uint32_t w = myblk * 64 + lane;
+      const uint32_t v = w < nw ? P.needy[w] : 0u;
+      if (w < myw) r += __popc(v);
+      else if (w == myw) r += __popc(v & ((1u << (cid & 31)) - 1u));
+    }
+    for (uint32_t b = lane; b < nblk; b += 64) {
+      const uint32_t v = P.needy_cnt[b];
+      tot += (int)v;
+      if (b < myblk) r += (int)v;
+    }
+  } else {
+    // one GPU: every lane takes a contiguous run of the bitmap (padded to 64 x 4 words) as independent 16-byte
+    // loads -- one round trip instead of a word-at-a-time walk
+    const uint32_t wpl = ((nw + 255) / 256) * 4;  // words per lane, multiple of 4
+    const uint4 *nv = reinterpret_cast<const uint4 *>(P.needy) + (size_t)lane * (wpl / 4);
+    const uint32_t w0 = lane * wpl;
+#pragma unroll 8
+    for (uint32_t j = 0; j < wpl / 4; j++) {
+      const uint4 q = nv[j];
+      const uint32_t vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w = w0 + 4 * j + k, v = vv[k];
+        tot += __popc(v);
+        if (w < myw) r += __popc(v);
+        else if (w == myw) r += __popc(v & ((1u << (cid & 31)) - 1u));
+      }
+    }
   }
   const uint32_t rank = (uint32_t)wave_sum_i(r), nneedy = (uint32_t)wave_sum_i(tot);
   *is_last = rank + 1 == nneedy;
   uint32_t need = rank + 1;
-  long long top = P.glob->cursor;
   long long seed = -1;
   while (top >= 0) {
     const long long wtop = top >> 6, w = wtop - lane;
@@ -654,11 +706,13 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
   const int lo = rev ? shift : 0;
   const int mref = rev ? ref_len + shift : ref_len - shift;
   // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
-  // (mask[0][..] / mask[shift][..] of reorder.h:291-301)
-  auto within_thresh = [&](uint32_t r) -> bool {
+  // (mask[0][..] / mask[shift][..] of reorder.h:291-301); with check_key also the reference's key re-check of
+  // a single-read bin (reorder.h:282-285): -1 = the read's window is not `key` (fingerprint collision), else 0 / 1.
+  auto within_thresh = [&](uint32_t r, bool check_key) -> int {
     const int clen = P.uniform_len ? P.L : (int)P.lens[r];
     const int m = clen < mref ? clen : mref;
     const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
+    if (check_key && read_window(rdp, P.S, ds, klen2) != key) return -1;
     const int blo = 2 * lo, bhi = 2 * m;
     int hd = 0;
     for (int i = 0; i < W; i++) {
@@ -676,25 +730,29 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     uint32_t pay;
     const int kind = tab_find(P.fpt, P.bshift, hsh, l, skip, pay, other);
     if (kind == 0) break;  // key absent
-    if (kind == 2) {       // single-read bin: pay is the read id
-      // a taken read contributes nothing whether this slot is the key's bin or a fingerprint collision:
-      // test the bitmap (12.5 MB, cache-resident) before spending a random 64-byte read on the key check
-      if (is_taken(P.taken, pay)) continue;
-      if (read_window(P.reads + (uint64_t)pay * P.S, P.S, ds, klen2) != key) continue;  // fingerprint collision
-      keyok = true; ncand = 1;
-      if (within_thresh(pay)) { hit = true; rid = pay; }
-      break;
+    // a single-read bin (kind 2: pay is the read id) runs through the same scan as a bin of one entry; its key is
+    // verified on the read itself, and only once the read is known to be untaken: a taken read contributes
+    // nothing whether this slot is the key's bin or a fingerprint collision, and the bitmap (12.5 MB, cache-
+    // resident) is tested before a random 64-byte read is spent on it
+    const bool single = kind == 2;
+    uint32_t start = 0, count = 1;
+    if (!single) {
+      const ulonglong2 rec = urec[pay];
+      if (rec.x != key) continue;  // fingerprint collision
+      start = (uint32_t)rec.y; count = (uint32_t)(rec.y >> 32);
     }
-    const ulonglong2 rec = urec[pay];
-    if (rec.x != key) continue;  // fingerprint collision
-    const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
+    bool verified = !single;
     int live = 0;
     for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
-      const uint32_t r = ids[start + j];
+      const uint32_t r = single ? pay : ids[start + j];
       if (is_taken(P.taken, r)) continue;
+      const int wt = within_thresh(r, single);
+      if (wt < 0) break;  // fingerprint collision (single-read bin)
+      verified = true;
       live++; keyok = true; ncand++;
-      if (within_thresh(r)) { hit = true; rid = r; break; }
+      if (wt) { hit = true; rid = r; break; }
     }
+    if (!verified) continue;  // taken or colliding single-read slot: the key's own bin may sit in a later slot
     break;
   }
 }
@@ -877,6 +935,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t li = blockIdx.x * WPB + wave;
   if (li >= P.K) return;
+  WT_BEGIN();
   const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
   Chain *c = &P.chains[li];
   ChainHot h;
@@ -888,7 +947,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
     s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
   }
-  if (h.done) return;
+  if (h.done) { WT_END(P, lane, 0); return; }
 
   if (h.mode == MODE_NEED_SEED) {
     if (MG) {  // seeds are assigned after the exchange (k_mg_seed), when every rank knows who needs one
@@ -910,6 +969,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
       }
       store_hot(c, h);
     }
+    WT_END(P, lane, 1);
     return;
   }
 
@@ -929,6 +989,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
       if (MG) P.prop[cid] = (unsigned long long)PK_NONE << 32;
       if (STATS && new_iter) c->st_iter++;
     }
+    WT_END(P, lane, 2);
     return;
   }
 
@@ -947,17 +1008,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   const int fs = (h.prev_unmatched && P.seed_wide) ? 16 : P.first_shifts;
   BatchOut o;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
-  probe_batch<STATS>(P, sref, srev, 0, fs, lane, ref_len, o);
-  st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
-  if (!o.found && fs < P.maxshift) {
-    const uint64_t pm0 = o.pm;
-    probe_batch<STATS>(P, sref, srev, fs, 16, lane, ref_len, o);
+  int wt_cat = 3;
+  uint64_t pm0 = 0, pm1 = 0;
+#pragma nounroll
+  for (int ph = 0; ph < 2; ph++) {  // the two ordered batches: shifts [0, fs) and [fs, fs + 16)
+    probe_batch<STATS>(P, sref, srev, ph ? fs : 0, ph ? 16 : fs, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
-    if (!o.found && fs + 16 < P.maxshift) {
-      const uint64_t pm1 = o.pm;
-      probe_tail<STATS>(P, sref, srev, s_list[wave], s_stat[STATS ? wave : 0], fs + 16, fs, pm0, pm1, lane, ref_len, o);
-      st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
-    }
+    if (ph) pm1 = o.pm; else pm0 = o.pm;
+    wt_cat = 3 + ph;
+    if (o.found || fs >= P.maxshift) break;
+  }
+  if (!o.found && fs + 16 < P.maxshift) {
+    wt_cat = 5;
+    probe_tail<STATS>(P, sref, srev, s_list[wave], s_stat[STATS ? wave : 0], fs + 16, fs, pm0, pm1, lane, ref_len, o);
+    st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
   }
   if (lane == 0) {
     if (o.found) {
@@ -977,6 +1041,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
       if (new_iter) c->st_iter++;
     }
   }
+  WT_END(P, lane, o.found ? wt_cat : 6 + (h.prev_unmatched ? 1 : 0));
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1016,11 +1081,12 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
   // local chain index (state arrays, emission tags); wave-uniform -> chain pointers live in SGPRs
   const uint32_t li = blockIdx.x * 4 + wave;
   if (li >= P.K) return;
+  WT_BEGIN();
   const uint32_t cid = P.c0 + li;             // global chain id (conflict priority)
   Chain *c = &P.chains[li];
   ChainHot h;
   load_hot(c, h);
-  if (h.done) return;
+  if (h.done) { WT_END(P, lane, 8); return; }
   WaveLds *ws = &lds[wave];
   WaveLdsLiteral *wl = &ldsl[LITERAL ? wave : 0];
   int kind = h.prop_kind;
@@ -1044,6 +1110,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
       }
       store_hot(c, h);
     }
+    WT_END(P, lane, 9);
     return;
   }
   // who holds the read we proposed (load in flight while the update is computed)
@@ -1079,6 +1146,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
       store_hot(c, h);
       c->st_lost++;
     }
+    WT_END(P, lane, 10);
     return;
   }
   if (do_upd) {
@@ -1088,6 +1156,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
     h.cnt_wide = nw;
   }
   if (lane != 0) return;
+  WT_END(P, lane, kind == PROP_MATCH ? 11 : kind == PROP_SEED ? 12 : fail_path ? 13 : 14);
   if (kind == PROP_MATCH) {
     const uint32_t rid = h.prop_rid;
     const int shift = ushift;
@@ -1148,6 +1217,8 @@ __global__ void k_mg_bits(DevParams P) {
     }
     P.needy[w] = bits;
   }
+  const uint32_t nb = (uint32_t)wave_sum_i(__popc(bits));  // a wavefront covers exactly one 64-word block
+  if ((threadIdx.x & 63) == 0 && w < nw) P.needy_cnt[w >> 6] = nb;
   alive = (uint32_t)wave_sum_i((int)alive);
   if ((threadIdx.x & 63) == 0 && alive) atomicAdd(P.alive_round, alive);
 }

@@ -7,6 +7,7 @@
 // chains -> streams.  There is no CPU fallback anywhere in this file: every
 // stage runs on the GPU or the call fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -135,6 +136,10 @@ struct spring_reorder_ctx {
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
   bool mg = false;
+  // exchange transport of mg_run: RCCL communicator (loaded at run time) or a caller-supplied host all-gather
+  void *rccl_comm = nullptr;
+  spring_mg_allgather_fn host_xchg = nullptr;
+  void *host_xchg_user = nullptr;
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
   uint32_t *d_orderN[2] = {nullptr, nullptr};
@@ -194,6 +199,45 @@ hipError_t dev_alloc(int dev, size_t bytes, void **out) {
 void dev_free(int dev, void *p) { if (p) pool_free(dev, p); }
 }  // namespace sr
 
+// ---------------------------------------------------------------- RCCL, loaded on first use
+// The four entry points the pool needs, resolved from librccl.so.1 at run time: a process that already holds RCCL
+// (torch.distributed's nccl backend) shares that copy, a single-GPU user never loads it.
+namespace {
+struct RcclId128 { char b[128]; };  // ncclUniqueId, passed by value
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, RcclId128, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+int rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl.h) return 0;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(SPRING_REORDER_E_HIP, "cannot load librccl.so.1: %s", dlerror());
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
+    return fail(SPRING_REORDER_E_HIP, "librccl lacks an expected entry point");
+  g_rccl.h = h;
+  return 0;
+}
+const char *rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error"; }
+void rccl_release(spring_reorder_ctx *ctx) {
+  if (ctx->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
+  ctx->rccl_comm = nullptr;
+}
+constexpr int RCCL_UINT64 = 5;  // ncclUint64 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5)
+}  // namespace
+
 #define DMALLOC(ptr, bytes)                                   \
   do {                                                        \
     int r_ = ctx->dmalloc((void **)&(ptr), (bytes));          \
@@ -251,6 +295,7 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+  rccl_release(ctx);
   for (void *p : ctx->allocs) pool_free(ctx->dev, p);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
@@ -821,7 +866,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.maxshift = ctx->L / 2;  // reorder.h:750
   P.first_shifts = o.first_shifts > 0 ? std::min(16, o.first_shifts) : 8;
   P.seed_wide = o.seed_wide < 0 ? 0 : 1;
-  P.search_wpb = (o.search_wpb == 1 || o.search_wpb == 2 || o.search_wpb == 4) ? o.search_wpb : 4;
+  P.search_wpb = (o.search_wpb == 1 || o.search_wpb == 2 || o.search_wpb == 4) ? o.search_wpb : 1;  // 1: a block is a chain; its slot frees when that chain is done
   P.dbg_search_lds = std::max(0, o.dbg_search_lds);
   P.dbg_apply_lds = std::max(0, o.dbg_apply_lds);
   P.uniform_len = ctx->uniform ? 1 : 0;
@@ -853,7 +898,9 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   const size_t nn = std::max<uint32_t>(n, 1);
   DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
   DMALLOC(P.resv, nn * 4);
-  DMALLOC(P.needy, ((size_t)K + 31) / 32 * 4);
+  const size_t needy_bytes = (((size_t)K + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
+  DMALLOC(P.needy, needy_bytes);
+  P.needy_cnt = nullptr;
   DMALLOC(P.glob, sizeof(Globals));
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
@@ -866,11 +913,13 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
   DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
   P.K = K; P.c0 = 0; P.Ktot = K; P.prop = nullptr; P.alive_round = nullptr;
+  DMALLOC(P.dbg, 4096 * 32 * 8);
+  HIPCHK(hipMemsetAsync(P.dbg, 0, 4096 * 32 * 8, st));
 
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   launch_init_taken(st, P.taken, nwords, n);
   launch_fill_u32(st, P.resv, n, 0xffffffffu);
-  HIPCHK(hipMemsetAsync(P.needy, 0, ((size_t)K + 31) / 32 * 4, st));
+  HIPCHK(hipMemsetAsync(P.needy, 0, needy_bytes, st));
   HIPCHK(hipMemsetAsync(P.chains, 0, (size_t)K * sizeof(Chain), st));
   Globals g;
   memset(&g, 0, sizeof(g));
@@ -923,6 +972,19 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   }
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   HIPCHK(hipStreamSynchronize(st));
+#ifdef SPRING_DBG_WAVETIME
+  {
+    std::vector<unsigned long long> all(4096 * 32);
+    HIPCHK(hipMemcpy(all.data(), P.dbg, all.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long d[32] = {0};
+    for (size_t i = 0; i < all.size(); i++) d[i & 31] += all[i];
+    static const char *nm[16] = {"S done", "S seed", "S stopped", "S hit batch0", "S hit batch1", "S hit tail", "S fail", "S fail (fresh seed)",
+                                 "A done", "A finishing", "A lost", "A match", "A seed", "A failpath", "A none", ""};
+    for (int i = 0; i < 15; i++)
+      if (d[2 * i]) fprintf(stderr, "[wavetime] %-20s waves %12llu  avg %8.2f us  total %10.1f wave-ms\n", nm[i], d[2 * i],
+                            d[2 * i + 1] * 0.01 / d[2 * i], d[2 * i + 1] * 1e-5);
+  }
+#endif
   (void)hipHostFree(h_alive);
   for (auto &e : tev) (void)hipEventDestroy(e);
   ctx->stats.rounds = rounds;
@@ -955,11 +1017,15 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
   DMALLOC(P.resv, nn * 4);
   DMALLOC(P.needy, ((size_t)Ktot + 31) / 32 * 4);
+  DMALLOC(P.needy_cnt, ((size_t)Ktot / 2048 + 1) * 4);
+  HIPCHK(hipMemsetAsync(P.needy_cnt, 0, ((size_t)Ktot / 2048 + 1) * 4, st));
   DMALLOC(P.glob, sizeof(Globals));
   DMALLOC(P.alive_round, 16);
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
   DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t));
+  DMALLOC(P.dbg, 4096 * 32 * 8);
+  HIPCHK(hipMemsetAsync(P.dbg, 0, 4096 * 32 * 8, st));
   if (d_prop) P.prop = (unsigned long long *)d_prop;
   else DMALLOC(P.prop, (size_t)Ktot * 8);
   const size_t cap = (size_t)n + (size_t)K * CHUNK;
@@ -1054,6 +1120,93 @@ int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world
   }
   for (uint32_t d = 0; d < world; d++) HIPCHK(hipStreamSynchronize(ctxs[d]->st));
   return 0;
+}
+
+int spring_reorder_rccl_unique_id(void *id128) {
+  if (!id128) return fail(SPRING_REORDER_E_ARG, "id buffer is NULL");
+  int r = rccl_load();
+  if (r) return r;
+  const int e = g_rccl.GetUniqueId(id128);
+  if (e) return fail(SPRING_REORDER_E_HIP, "ncclGetUniqueId: %s", rccl_err(e));
+  return 0;
+}
+
+int spring_reorder_mg_use_rccl(spring_reorder_ctx *ctx, const void *id128, uint32_t rank, uint32_t world) {
+  if (!ctx || !id128 || !world || rank >= world) return fail(SPRING_REORDER_E_ARG, "mg_use_rccl: bad arguments");
+  int r = rccl_load();
+  if (r) return r;
+  HIPCHK(hipSetDevice(ctx->dev));
+  rccl_release(ctx);
+  RcclId128 id;
+  memcpy(id.b, id128, sizeof(id.b));
+  const int e = g_rccl.CommInitRank(&ctx->rccl_comm, (int)world, id, (int)rank);
+  if (e) { ctx->rccl_comm = nullptr; return fail(SPRING_REORDER_E_HIP, "ncclCommInitRank: %s", rccl_err(e)); }
+  ctx->host_xchg = nullptr;
+  return 0;
+}
+
+int spring_reorder_mg_use_host_exchange(spring_reorder_ctx *ctx, spring_mg_allgather_fn fn, void *user) {
+  if (!ctx || !fn) return fail(SPRING_REORDER_E_ARG, "mg_use_host_exchange: bad arguments");
+  rccl_release(ctx);
+  ctx->host_xchg = fn;
+  ctx->host_xchg_user = user;
+  return 0;
+}
+
+// one pool over `world` ranks with the exchange inside the library; see include/spring_reorder.h
+int spring_reorder_mg_run(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (!ctx->rccl_comm && !ctx->host_xchg && world > 1)
+    return fail(SPRING_REORDER_E_STATE, "mg_run: choose a transport first (mg_use_rccl / mg_use_host_exchange)");
+  int r = spring_reorder_mg_begin(ctx, rank, world, total_chains, nullptr);
+  if (r) return r;
+  hipStream_t st = ctx->st;
+  DevParams &P = ctx->P;
+  const bool stats = ctx->o.collect_stats != 0, literal = ctx->o.force_literal_update != 0;
+  const int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : 8;
+  const size_t slice = (size_t)P.K * 8, total = (size_t)P.Ktot * 8;
+  uint32_t *h_alive = nullptr;
+  void *h_stage = nullptr;
+  HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
+  if (ctx->host_xchg) HIPCHK(hipHostMalloc(&h_stage, total, hipHostMallocDefault));
+  int ret = 0;
+  *h_alive = 1;
+  while (*h_alive && !ret) {
+    for (int i = 0; i < R && !ret; i++) {
+      launch_search(st, P, stats);
+      if (ctx->rccl_comm) {  // in place: this rank's words already sit at their offset of the receive buffer
+        const int e = g_rccl.AllGather(P.prop + P.c0, P.prop, P.K, RCCL_UINT64, ctx->rccl_comm, st);
+        if (e) ret = fail(SPRING_REORDER_E_HIP, "ncclAllGather: %s", rccl_err(e));
+      } else if (ctx->host_xchg) {
+        hipError_t he = hipMemcpyAsync((char *)h_stage + (size_t)P.c0 * 8, P.prop + P.c0, slice, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he != hipSuccess) { ret = fail(SPRING_REORDER_E_HIP, "staging copy failed: %s", hipGetErrorString(he)); break; }
+        if (ctx->host_xchg(h_stage, (size_t)P.c0 * 8, slice, total, ctx->host_xchg_user)) {
+          ret = fail(SPRING_REORDER_E_IO, "mg_run: the caller's all-gather reported an error");
+          break;
+        }
+        he = hipMemcpyAsync(P.prop, h_stage, total, hipMemcpyHostToDevice, st);
+        if (he != hipSuccess) { ret = fail(SPRING_REORDER_E_HIP, "staging copy failed: %s", hipGetErrorString(he)); break; }
+      }
+      launch_mg_post_exchange(st, P);
+      launch_apply(st, P, literal);
+      launch_mg_mark(st, P);
+      ctx->stats.rounds++;
+      if (ctx->stats.rounds % 16 == 0)
+        for (int l = 0; l < 2; l++)
+          launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
+    }
+    if (ret) break;
+    // every rank recounted the running chains from the same gathered words: the same decision everywhere
+    hipError_t he = hipMemcpyAsync(h_alive, P.alive_round, 4, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hipGetLastError();
+    if (he != hipSuccess) ret = fail(SPRING_REORDER_E_HIP, "mg_run: %s", hipGetErrorString(he));
+  }
+  (void)hipHostFree(h_alive);
+  if (h_stage) (void)hipHostFree(h_stage);
+  if (ret) return ret;
+  return spring_reorder_mg_end(ctx);
 }
 
 int spring_reorder_finalize(spring_reorder_ctx *ctx) {

@@ -5,8 +5,9 @@ bit-identical to one GPU running the same total number of chains, whatever the r
 
 VirtualPool : G "ranks" as G contexts on one device, in-process exchange (how the G-independence is
               tested on a single GPU).
-DistPool    : one process per GPU, exchange = torch.distributed.all_gather_into_tensor (backend
-              "nccl" = RCCL over xGMI on the GPU box).
+DistPool    : one process per GPU, the round loop and the exchange inside the library
+              (spring_reorder_mg_run: ncclAllGather on the library's stream, or a host-staged all-gather
+              for ranks that share a GPU).
 """
 import ctypes as C
 
@@ -101,42 +102,68 @@ class VirtualPool:
             s.close()
 
 
-class DistPool:
-    """One process per GPU.  `dist` is an initialised torch.distributed module; the proposal buffer
-    is a torch tensor so the collective can run on it directly."""
+def host_allgather(dist):
+    """spring_mg_allgather_fn over a torch.distributed group working on HOST memory (gloo): the library hands
+    over its staging buffer with this rank's slice filled in; the other slices are filled here.  Used where RCCL
+    cannot be (tests: two processes sharing one GPU) -- and by any caller with its own transport."""
+    import torch
 
-    def __init__(self, dist, device, total_chains, num_thr=1, check_every=16, **opt_kw):
+    def fn(buf, off, nbytes, total, user):
+        try:
+            arr = np.ctypeslib.as_array((C.c_uint8 * total).from_address(buf))
+            t = torch.from_numpy(arr)
+            mine = t[off:off + nbytes].clone()
+            dist.all_gather(list(t.split(nbytes)), mine)  # the chunks are views of the staging buffer
+            return 0
+        except Exception:  # never unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    return _lib.MG_ALLGATHER_FN(fn)
+
+
+class DistPool:
+    """One process per GPU, ONE read pool: the whole round loop runs inside the library (spring_reorder_mg_run).
+    transport "rccl": ncclAllGather on the library's stream; the 128-byte communicator id is made by rank 0 and
+    broadcast through `dist` (an initialised torch.distributed module).  transport "host": all-gather on a host
+    staging buffer through `dist` (gloo) -- for ranks that share a GPU."""
+
+    def __init__(self, dist, device, total_chains, num_thr=1, transport="rccl", **opt_kw):
         import torch
         self.torch, self.dist, self.device = torch, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.K, self.T, self.check_every = total_chains, num_thr, check_every
+        self.K, self.T, self.transport = total_chains, num_thr, transport
         self.stage = _MgStage(ReorderOpts(device=device.index if device.type == "cuda" else -1,
                                           num_chains=total_chains, num_thr=num_thr, **opt_kw))
-        self.prop = torch.zeros(total_chains, dtype=torch.int64, device=device)
+        self._cb = None
+        L_ = _lib.lib()
+        if transport == "rccl":
+            idbuf = np.zeros(128, np.uint8)
+            if self.rank == 0:
+                _chk(L_.spring_reorder_rccl_unique_id(idbuf.ctypes.data))
+            on_gpu = dist.get_backend() == "nccl"
+            t = torch.from_numpy(idbuf).to(device) if on_gpu else torch.from_numpy(idbuf)
+            dist.broadcast(t, src=0)
+            idbuf = t.cpu().numpy().copy()
+            _chk(L_.spring_reorder_mg_use_rccl(self.stage._h, idbuf.ctypes.data, self.rank, self.world))
+        elif transport == "host":
+            self._cb = host_allgather(dist)  # keep the trampoline alive as long as the stage
+            _chk(L_.spring_reorder_mg_use_host_exchange(self.stage._h, self._cb, None))
+        else:
+            raise ValueError("transport must be 'rccl' or 'host'")
 
     def run(self, load):
-        torch, dist, s = self.torch, self.dist, self.stage
+        s = self.stage
         load(s)
         s.build_dict()
-        s.mg_begin(self.rank, self.world, self.K, self.prop.data_ptr())
-        per = self.K // self.world
-        mine = self.prop[self.rank * per:(self.rank + 1) * per]
-        send = torch.empty_like(mine)
-        rounds = 0
-        while True:
-            s.mg_search()                       # library stream, synchronised on return
-            send.copy_(mine)
-            dist.all_gather_into_tensor(self.prop, send)
-            torch.cuda.synchronize(self.device)  # the library's stream reads prop next
-            rounds += 1
-            check = rounds % self.check_every == 0
-            alive = s.mg_apply(check)
-            if check and alive == 0:
-                break
-        s.mg_end()
+        _chk(s._L.spring_reorder_mg_run(s._h, self.rank, self.world, self.K))
         s.finalize()
-        self.rounds = rounds
-        return s.stats()
+        st = s.stats()
+        self.rounds = st["rounds"]
+        return st
+
+    def streams(self):
+        return self.stage.streams()
 
     def close(self):
         self.stage.close()
