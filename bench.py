@@ -3,9 +3,11 @@
 
 One "step" = one pass of the whole stage (unpack -> dictionaries -> chains -> streams) over one
 batch of synthetic reads that is already resident in HBM as a .dna record stream when the timed
-region starts.  N=1 workload = BASELINE configs[2]: 100 M x 150 bp single-end.  For N>1 every
-rank runs the stage on its own independent read set (lane) -- no data-path collective -- so the
-job is weak-scaled; see DESIGN.md "Multi-GPU".
+region starts.  N=1 workload = BASELINE configs[2]: 100 M x 150 bp single-end.  For N>1 the job is ONE
+shared read pool of 50 M x N reads (N=8: BASELINE configs[4], 400 M x 150 bp) with 65536 x N chains sharded
+over the GPUs and one RCCL all-gather of the proposal words per round, issued by the library on its own stream
+(spring_reorder_mg_run); `value` = pool reads / wall-clock; see DESIGN.md "Multi-GPU".  --lanes switches the
+N>1 run to independent lanes (one read set per GPU, no data-path collective).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
 search kernel and `cpu_baseline` (the C oracle timed on a bounded sample of the same workload).
@@ -35,13 +37,18 @@ def parse():
     ap.add_argument("--err-ppm", type=int, default=10000)
     ap.add_argument("--chains", type=int, default=0, help="0 = library default")
     ap.add_argument("--num-thr", type=int, default=8, help="per-tid output sets (reference default -t 8)")
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32_000_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(32, cpus))")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--single-pool", choices=["auto", "on", "off"], default="auto",
-                    help="after the main JSON line, also time the single-pool mode (one shared read pool, chains "
-                         "sharded over the GPUs, all-gather of proposals per round); auto = only when --gpus > 1")
-    ap.add_argument("--pool-reads-per-gpu", type=int, default=50_000_000)
+    ap.add_argument("--lanes", action="store_true",
+                    help="N>1: independent lanes (every rank its own read set) instead of one shared pool")
+    ap.add_argument("--pool-reads-per-gpu", type=int, default=50_000_000,
+                    help="N>1: the shared pool holds this many reads per GPU (N=8: 400 M, BASELINE configs[4])")
+    ap.add_argument("--force-pool", action="store_true",
+                    help="run the shared-pool path even at N=1 (a 1-rank RCCL communicator): exercises the in-library "
+                         "ncclAllGather on a single-GPU box")
+    ap.add_argument("--files-sample", type=int, default=20_000_000,
+                    help="reads in the file-contract leg (stage_incl_files); 0 = skip")
     return ap.parse_args()
 
 
@@ -50,6 +57,74 @@ def algorithmic_bytes_search(st, W):
     P*(8+8) [table slot + bin offsets] + Kv*(4+B) [first id + first read] + C*(4+B+2+1) [id, read, len, flag]."""
     B = 8 * W
     return st["probes"] * 16 + st["keyok"] * (4 + B) + st["cands"] * (7 + B)
+
+
+def kernels_sha():
+    """Identity of the kernels a PMC summary belongs to (profiles/pmc_latest.json carries the same stamp)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("reorder_kernels.hip", "reorder_device.h"):
+        h.update(open(os.path.join(ROOT, "spring_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pool_main(a, lanes, torch, spring_amd, L_):
+    """N>1: one shared read pool, chains sharded over the GPUs, the exchange inside the library (RCCL)."""
+    from spring_amd.pool import DistPool, PoolComm
+    world, rank = lanes.world, lanes.rank
+    dev = torch.cuda.current_device()
+    L = a.readlen
+    n = a.pool_reads_per_gpu * world
+    G = max(n * L // a.coverage, 2 * L)
+    Ktot = (a.chains or 65536) * world
+    nb = L_.spring_synth_dna_bytes(n, L)
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")     # every rank holds the whole pool (replicated)
+    assert L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 13, a.err_ppm) == 0, L_.spring_reorder_last_error()
+    torch.cuda.synchronize()
+    dist = lanes.dist
+    if dist is None:  # --force-pool at N=1
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+    comm = PoolComm(dist, torch.device("cuda", dev), transport="rccl")
+
+    def one_pass():
+        dp = DistPool(comm, Ktot, num_thr=a.num_thr)
+        st = dp.run(lambda s: s.load_dna_device(buf.data_ptr(), nb, n, L, True))
+        st["local_matched"], st["local_single"] = st["n_matched"], st["n_single"]
+        dp.close()
+        return st
+
+    el, st = lanes.timed_steps(one_pass, a.steps, a.warmup)
+    tot_matched = lanes.sum_over_ranks(st["local_matched"])
+    tot_single = lanes.sum_over_ranks(st["local_single"])
+    out = {
+        "metric": "Mreads/s through reorder stage", "value": round(n * a.steps / el / 1e6, 3), "unit": "Mreads/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "ONE shared pool of %d x %d bp single-end synthetic reads (%d per GPU; uniform genome %d bp, %dx "
+                        "coverage, %.1f%% substitutions, 50%% reverse-complemented), resident in HBM on every GPU as .dna "
+                        "records; %d chains sharded over %d GPUs, one RCCL all-gather of %d proposal bytes per round "
+                        "issued by the library on its stream"
+                        % (n, L, a.pool_reads_per_gpu, G, a.coverage, a.err_ppm / 1e4, Ktot, world, Ktot * 8),
+            "pool_reads": n, "reads_per_gpu": a.pool_reads_per_gpu, "read_len": L, "chains": Ktot, "num_thr": a.num_thr,
+            "parallelism": "1 process per GPU, single shared pool: reads + dictionaries replicated, chains sharded, "
+                           "all-gather per round (DESIGN.md section 7)",
+            "stage_ms_rank0": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},
+            "rounds": st["rounds"], "reads_emitted_all_ranks": int(tot_matched + tot_single),
+            "note": "weak scaling: the pool and the chain count grow with N, the per-GPU share is fixed; at N=1 the "
+                    "bench runs BASELINE configs[2] (100 M reads) instead",
+        },
+    }
+    if rank == 0:
+        assert int(tot_matched + tot_single) == n, "the ranks' streams do not add up to the pool"
+        print(json.dumps(out), flush=True)
+    comm.close()
+    if lanes.dist is None:
+        dist.destroy_process_group()
+    lanes.close()
 
 
 def main():
@@ -65,6 +140,8 @@ def main():
     if world == 1:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
+    if (world > 1 and not a.lanes) or a.force_pool:
+        return pool_main(a, lanes, torch, spring_amd, L_)
 
     n, L = a.reads, a.readlen
     G = max(n * L // a.coverage, 2 * L)
@@ -120,8 +197,9 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pmc.get("reads") == n and pmc.get("read_len") == L:
-                ks = pmc["kernels"]["sr::k_search<false>"]
+            # only a summary taken from THESE kernels counts (the stamp is the hash of the kernel sources)
+            if pmc.get("reads") == n and pmc.get("read_len") == L and pmc.get("kernels_sha") == kernels_sha():
+                ks = pmc["kernels"]["sr::k_search"]
                 traffic = round(ks["fetch_bytes_per_launch"] + ks["write_bytes_per_launch"], 1)
         except Exception:
             traffic = None
@@ -130,7 +208,7 @@ def main():
         # (tools/random_gather_bench.hip, profiles/r01_pmc_calibration_random_gather.csv), not 8 TB/s / 64 B
         req = None
         try:
-            fetch = pmc["kernels"]["sr::k_search<false>"]["fetch_bytes_per_launch"] if traffic is not None else None
+            fetch = pmc["kernels"]["sr::k_search"]["fetch_bytes_per_launch"] if traffic is not None else None
             if fetch:
                 rate = fetch / 64.0 / (ms * 1e-3 / launches) / 1e9
                 req = {"achieved": round(rate, 2), "peak": RANDOM_REQ_PEAK_G, "unit": "G random 64-byte requests/s",
@@ -139,7 +217,7 @@ def main():
             req = None
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_kernels_sha": kernels_sha(),
             "kernel": "sr::k_search", "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
             "algorithmic_bytes_per_launch": round(alg / launches, 1),
             "algorithmic_bytes_per_read": round(alg / n, 1),
@@ -168,6 +246,58 @@ def main():
             }
         except Exception as e:  # the widened row must never break the headline line
             out["encoder_stage"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_roofline:
+        # SURVEY 8(d) legs (ii) and (iii), reported beside `value` (never part of it):
+        # (ii) stage incl. PCIe: the .dna record stream starts in HOST memory and every output stream ends there
+        try:
+            host = buf.cpu().numpy()
+            t0 = time.perf_counter()
+            s = spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=a.chains, num_thr=a.num_thr))
+            s.load_dna(host, n, L)
+            s.run()
+            res = s.streams()
+            s.close()
+            t_pcie = time.perf_counter() - t0
+            out["stage_incl_pcie"] = {"value": round(n / t_pcie / 1e6, 2), "unit": "Mreads/s", "seconds": round(t_pcie, 3),
+                                      "what": "host .dna buffer (%.1f GB, pageable) -> HBM -> stage -> every output stream back "
+                                              "in host arrays (%.1f GB)" % (nb / 1e9, sum(v.nbytes for v in res.values() if hasattr(v, "nbytes")) / 1e9)}
+            del res, host
+        except Exception as e:
+            out["stage_incl_pcie"] = {"error": repr(e)}
+        # (iii) stage incl. file I/O = what the reference's "Time for this step" covers (spring.cpp:152-160): the drop-in
+        # spring_reorder_run on a temp dir (reads + deletes input_clean_1.dna, writes the per-tid and singleton files)
+        if a.files_sample > 0:
+            try:
+                import shutil
+                import tempfile
+                nf = min(a.files_sample, n)
+                td = tempfile.mkdtemp(prefix="spring_bench_")
+                recb = L_.spring_synth_dna_bytes(nf, L)
+                with open(os.path.join(td, "input_clean_1.dna"), "wb") as f:
+                    f.write(buf[:recb].cpu().numpy().tobytes())   # the first nf reads of the workload
+                os.sync()
+                # the drop-in prints the reference's "Reordering done, N were unmatched" on stdout (reorder.h:638);
+                # this process must print exactly one line there: route fd 1 to stderr for the duration of the call
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    t0 = time.perf_counter()
+                    spring_amd.call_reorder(td, spring_amd.CompressionParams(L, [nf, 0], num_thr=a.num_thr),
+                                            spring_amd.ReorderOpts(device=dev, num_chains=a.chains, num_thr=a.num_thr))
+                    t_files = time.perf_counter() - t0
+                finally:
+                    C.CDLL(None).fflush(None)  # the library's printf sits in the C stdio buffer
+                    os.dup2(saved, 1)
+                    os.close(saved)
+                out_bytes = sum(os.path.getsize(os.path.join(td, f)) for f in os.listdir(td))
+                shutil.rmtree(td, ignore_errors=True)
+                out["stage_incl_files"] = {"value": round(nf / t_files / 1e6, 2), "unit": "Mreads/s", "seconds": round(t_files, 3),
+                                           "sample": "%d reads (the first of the workload), temp dir %s" % (nf, os.path.dirname(td)),
+                                           "what": "spring_reorder_run: read + delete input_clean_1.dna (%.2f GB), stage, write "
+                                                   "the %d per-tid file sets + singleton files (%.2f GB)" % (recb / 1e9, a.num_thr, out_bytes / 1e9)}
+            except Exception as e:
+                out["stage_incl_files"] = {"error": repr(e)}
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         # CPU baseline on the GPU box's host cores: the C port of the reference algorithm
         # (oracle/reorder_oracle.c).  Multi-thread leg = free-running OpenMP chains like the
@@ -191,14 +321,14 @@ def main():
         tm = time.perf_counter() - t0
         ph_dict, ph_chains = po.last_omp_phases()
         # the reference's default thread count (-t 8, main.cpp:70) on a quarter of the sample
-        ns8 = min(max(ns // 4, 200_000), ns)
+        ns8 = min(max(ns // 8, 200_000), ns)
         dna8 = sample(ns8)
         t0 = time.perf_counter()
         read8, ln8 = po.load_dna(dna8, ns8, L)
         po.reorder_omp(read8, ln8, L, 8)
         t8 = time.perf_counter() - t0
         del read8, ln8, dna8
-        ns1 = min(max(ns // 8, 200_000), ns)
+        ns1 = min(max(ns // 16, 200_000), ns)
         dna1 = sample(ns1)
         t0 = time.perf_counter()
         read1, ln1 = po.load_dna(dna1, ns1, L)
@@ -216,44 +346,6 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out), flush=True)
-    # ---- experimental: single shared read pool across the GPUs.  Runs AFTER the main
-    # line is printed, under a watchdog, and reports on stderr, so it can never invalidate the main result.
-    want_pool = a.single_pool == "on" or (a.single_pool == "auto" and world > 1)
-    if want_pool:
-        import signal
-        signal.signal(signal.SIGALRM, lambda *_: os._exit(0))
-        signal.alarm(240)
-        try:
-            del buf
-            torch.cuda.empty_cache()
-            L_.spring_reorder_trim_pool()
-            from spring_amd.pool import DistPool
-            dist = lanes.dist
-            if dist is None:  # world == 1: a 1-rank process group still exercises the RCCL all-gather path
-                import torch.distributed as dist
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29533")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
-            npool = a.pool_reads_per_gpu * world
-            Ktot = 65536 * world
-            res = None
-            for it in range(2):  # first pass warms the allocator pool
-                dp = DistPool(dist, torch.device("cuda", dev), Ktot, num_thr=a.num_thr)
-                lanes.barrier()
-                t0 = time.perf_counter()
-                stp = dp.run(lambda s: s.load_synth(npool, L, max(npool * L // a.coverage, 2 * L), 13, a.err_ppm))
-                lanes.barrier()
-                elp = lanes.max_over_ranks(time.perf_counter() - t0)
-                res = {"mode": "single-pool", "n_gpus": world, "pool_reads": npool, "chains": Ktot, "seconds": round(elp, 4),
-                       "Mreads_per_s_incl_synth": round(npool / elp / 1e6, 3), "rounds": dp.rounds,
-                       "stage_ms": {k: round(stp[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")}}
-                dp.close()
-            if rank == 0:
-                print("#single-pool " + json.dumps(res), file=sys.stderr, flush=True)
-        except Exception as e:  # never fail the bench because of the experimental leg
-            if rank == 0:
-                print("#single-pool failed: %r" % (e,), file=sys.stderr, flush=True)
-        signal.alarm(0)
     lanes.close()
 
 

@@ -46,7 +46,8 @@ typedef struct {
   int32_t search_wpb;     /* chains (wavefronts) per block of the search kernel: 1 / 2 / 4                 */
   int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per search block  */
   int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
-  int32_t reserved2[2];
+  int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (k_round: apply + search) + mark  */
+  int32_t reserved2;
 } spring_reorder_opts;
 
 typedef struct {
@@ -155,25 +156,28 @@ int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world
 
 /* ---- the same pool with the exchange INSIDE the library (no host round trip per round).
  * spring_reorder_mg_run = mg_begin + rounds until no chain is running + mg_end; the per-round all-gather of the
- * proposal words is done by the transport chosen before the call:
- *   spring_reorder_mg_use_rccl          ncclAllGather (in place) on the library's own stream.  RCCL is loaded at
- *                                       run time (librccl.so.1), so single-GPU users never pay for it.  Rank 0 makes
- *                                       the 128-byte id with spring_reorder_rccl_unique_id and the caller hands it
- *                                       to every rank (bench.py: one torch.distributed broadcast; an MPI or file
- *                                       exchange works as well); ncclCommInitRank is collective over the ranks.
- *   spring_reorder_mg_use_host_exchange a caller-supplied all-gather on a host staging buffer: `fn` receives the
- *                                       whole buffer with this rank's slice filled in and must fill the others
- *                                       (tests: gloo between two processes that share one GPU; any transport).
+ * proposal words goes through a communicator made once per process and reused by any number of runs:
+ *   spring_mg_comm_create_rccl  ncclAllGather (in place) on the library's own stream.  RCCL is loaded at run time
+ *                               (librccl.so.1), so single-GPU users never pay for it.  Rank 0 makes the 128-byte
+ *                               id with spring_mg_rccl_unique_id and the caller hands it to every rank (bench.py:
+ *                               one torch.distributed broadcast; MPI or a file work as well); the call is
+ *                               collective over the ranks (ncclCommInitRank).
+ *   spring_mg_comm_create_host  a caller-supplied all-gather on a host staging buffer: `fn` receives the whole
+ *                               buffer with this rank's slice filled in and must fill the others (tests: gloo
+ *                               between two processes that share one GPU; any transport the caller has).
  * Termination needs no extra collective: every rank recounts the running chains from the gathered words.
  * The reference has no counterpart (its chains are OpenMP threads sharing remainingreads[], reorder.h:343-344,
  * :402-421); the contract is the one of mg_begin: output == run_chains() with num_chains = total_chains. */
 #define SPRING_RCCL_ID_BYTES 128
-int spring_reorder_rccl_unique_id(void *id128);
-int spring_reorder_mg_use_rccl(spring_reorder_ctx *ctx, const void *id128, uint32_t rank, uint32_t world);
+typedef struct spring_mg_comm spring_mg_comm;
 typedef int (*spring_mg_allgather_fn)(void *host_buf, size_t slice_off, size_t slice_bytes, size_t total_bytes,
                                       void *user);
-int spring_reorder_mg_use_host_exchange(spring_reorder_ctx *ctx, spring_mg_allgather_fn fn, void *user);
-int spring_reorder_mg_run(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains);
+int spring_mg_rccl_unique_id(void *id128);
+int spring_mg_comm_create_rccl(spring_mg_comm **comm, int32_t device, const void *id128, uint32_t rank, uint32_t world);
+int spring_mg_comm_create_host(spring_mg_comm **comm, spring_mg_allgather_fn fn, void *user, uint32_t rank,
+                               uint32_t world);
+void spring_mg_comm_destroy(spring_mg_comm *comm);
+int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_t total_chains);
 
 /* Gathers the per-chain emissions into the per-tid streams (the replay side of
  * writetofile, reorder.h:643-730). */
@@ -242,8 +246,14 @@ int spring_fastq_reorder(const uint8_t *fastq, size_t nbytes, const uint32_t *or
  */
 #define SPRING_SYNTH_REPEATS 0x80000000u /* OR into err_ppm: genome whose eighths 0,2,4,6 are exact copies
                                             (the repeat-rich "hard" distribution of SURVEY.md 8(d)) */
+#define SPRING_SYNTH_PAIRED 0x40000000u  /* OR into err_ppm: paired-end pool (n even).  Read i < n/2 is read i of file 1,
+                                            read n/2 + i its mate: the two ends of a fragment of ~N(400, 50) bases, on
+                                            opposite strands (BASELINE config 4; reorder.h:233-242 lays a paired pool
+                                            out as file-1 reads followed by file-2 reads) */
 size_t spring_synth_dna_bytes(uint32_t n, uint32_t L);
 int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
+/* the genome the reads are drawn from, as G letters (tests of the generator itself); flags = SPRING_SYNTH_REPEATS or 0 */
+int spring_synth_genome_host(uint8_t *dst, uint64_t G, uint64_t seed, uint32_t flags);
 /* generates into a device buffer the caller owns (e.g. a torch uint8 tensor); stream = 0. */
 int spring_synth_dna_device(void *d_dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
 /* generates straight into HBM owned by the context and loads it (fixed_len). */

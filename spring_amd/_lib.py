@@ -11,13 +11,14 @@ EXPORTS = [
     "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
     "spring_reorder_mg_begin", "spring_reorder_mg_search", "spring_reorder_mg_slice", "spring_reorder_mg_apply",
     "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
-    "spring_reorder_rccl_unique_id", "spring_reorder_mg_use_rccl", "spring_reorder_mg_use_host_exchange", "spring_reorder_mg_run",
+    "spring_mg_rccl_unique_id", "spring_mg_comm_create_rccl", "spring_mg_comm_create_host", "spring_mg_comm_destroy",
+    "spring_reorder_mg_run",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
     "spring_reorder_load_fastq", "spring_reorder_fastq_N",
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct", "spring_order_pe_encode",
     "spring_fastq_reorder",
-    "spring_synth_dna_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
+    "spring_synth_dna_host", "spring_synth_genome_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
     "spring_encoder_create", "spring_encoder_destroy", "spring_encoder_encode_reorder", "spring_encoder_download",
     "spring_encoder_download_seq_packed", "spring_encoder_get_info", "spring_reorder_encode_run", "spring_encoder_encode_host", "spring_encoder_run",
 ]
@@ -29,7 +30,7 @@ class Opts(C.Structure):
                 ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32),
                 ("first_shifts", C.c_int32), ("seed_wide", C.c_int32), ("tab_scale", C.c_int32),
                 ("search_wpb", C.c_int32), ("dbg_search_lds", C.c_int32), ("dbg_apply_lds", C.c_int32),
-                ("reserved2", C.c_int32 * 2)]
+                ("fused", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class FastqInfo(C.Structure):
@@ -103,10 +104,12 @@ def lib():
     L.spring_reorder_mg_apply.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint32)]
     L.spring_reorder_mg_end.argtypes = [vp]
     L.spring_reorder_mg_exchange_virtual.argtypes = [C.POINTER(vp), C.c_uint32]
-    L.spring_reorder_rccl_unique_id.argtypes = [vp]
-    L.spring_reorder_mg_use_rccl.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
-    L.spring_reorder_mg_use_host_exchange.argtypes = [vp, MG_ALLGATHER_FN, vp]
-    L.spring_reorder_mg_run.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.spring_mg_rccl_unique_id.argtypes = [vp]
+    L.spring_mg_comm_create_rccl.argtypes = [C.POINTER(vp), C.c_int32, vp, C.c_uint32, C.c_uint32]
+    L.spring_mg_comm_create_host.argtypes = [C.POINTER(vp), MG_ALLGATHER_FN, vp, C.c_uint32, C.c_uint32]
+    L.spring_mg_comm_destroy.argtypes = [vp]
+    L.spring_mg_comm_destroy.restype = None
+    L.spring_reorder_mg_run.argtypes = [vp, vp, C.c_uint32]
     L.spring_reorder_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.spring_reorder_download.argtypes = [vp] + [vp] * 8
     L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -123,6 +126,7 @@ def lib():
     L.spring_synth_dna_bytes.restype = C.c_size_t
     L.spring_synth_dna_bytes.argtypes = [C.c_uint32, C.c_uint32]
     L.spring_synth_dna_host.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.spring_synth_genome_host.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_synth_dna_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_reorder_load_synth.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32]
     L.spring_reorder_download_dna.argtypes = [vp, u8p, C.c_size_t]
@@ -142,7 +146,8 @@ def lib():
                                             C.c_uint32, C.POINTER(Opts), C.POINTER(EncoderInfo)]
     for name in EXPORTS:
         if name not in ("spring_reorder_last_error", "spring_reorder_destroy", "spring_synth_dna_bytes",
-                        "spring_reorder_default_opts", "spring_reorder_trim_pool", "spring_encoder_destroy"):
+                        "spring_reorder_default_opts", "spring_reorder_trim_pool", "spring_encoder_destroy",
+                        "spring_mg_comm_destroy"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -777,8 +777,8 @@ struct DBuf {
 
 struct spring_encoder_ctx {
   int dev = 0;
-  hipStream_t st = nullptr;      // stream of the last encode (the reorder context's, or `own`)
-  hipStream_t own = nullptr;     // created on first use by spring_encoder_encode_host
+  hipStream_t st = nullptr;      // stream the download entry points use: always `own` once an encode has finished
+  hipStream_t own = nullptr;     // created on first use
   int T = 0;
   spring_encoder_info info;
   bool have = false;
@@ -1253,6 +1253,11 @@ static int encode_core(spring_encoder_ctx *ctx, const EncSrc &E, const uint8_t *
   }
   I.seq_len = seq_len;
   I.num_contigs = C;
+  // `st` is borrowed from the reorder context and dies with it: everything queued on it is finished here, and the
+  // download entry points use a stream this context owns
+  HIPCHK(hipStreamSynchronize(st));
+  if (!ctx->own) HIPCHK(hipStreamCreate(&ctx->own));
+  ctx->st = ctx->own;
   ctx->have = true;
   if (info_out) *info_out = I;
   return 0;

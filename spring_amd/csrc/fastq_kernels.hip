@@ -85,10 +85,17 @@ __global__ __launch_bounds__(256) void k_read_info(const uint8_t *__restrict__ t
     e = line_end[4 * i + 1];
     if (e > s && t[e - 1] == '\r') e--;  // remove_CR_from_end (util.cpp:391-394)
   }
-  bool hasN = false;
-  for (uint64_t p = s + l16; p < e; p += 16) hasN |= t[p] == 'N';
+  bool hasN = false, bad = false;
+  for (uint64_t p = s + l16; p < e; p += 16) {
+    const uint8_t c = t[p];
+    hasN |= c == 'N';
+    // the reference's tables are only defined for A C G T N (util.cpp:270-274, :328): anything else (lower case,
+    // IUPAC codes, '.') would be packed as garbage there; here it is an error
+    bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N');
+  }
   const uint64_t bal = __ballot(hasN);
   const bool anyN = (bal >> (16 * grp)) & 0xffffull;
+  if (__ballot(bad) && bad) atomicOr(err, 2u);
   if (i < nreads && l16 == 0) {
     const uint64_t L = e - s;
     if (L > (uint64_t)MAX_READ_LEN) atomicOr(err, 1u);  // "Too long read length" (preprocess.cpp:190-196)
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) {
         const uint32_t j = 4 * b + q;
-        if (j < L) v |= dna2int(t[s + j]) << (2 * q);
+        if (j < L) v |= (dna2int(t[s + j]) & 3u) << (2 * q);
       }
       dst[2 + b] = (uint8_t)v;
     }

@@ -116,6 +116,7 @@ extern "C" int spring_fastq_reorder(const uint8_t *fastq, size_t nbytes, const u
   if (unterminated) {
     const uint64_t e = nbytes;
     HIPCHK(hipMemcpyAsync(le.as<uint64_t>() + nl, &e, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // `e` lives on this block's stack
   }
   hipLaunchKernelGGL(k_rec_sizes, dim3((n + 1 + 255) / 256), dim3(256), 0, st, le.as<uint64_t>(), dorder.as<uint32_t>(), n,
                      nrec, (uint64_t)nbytes, sz.as<uint32_t>(), derr.as<uint32_t>());

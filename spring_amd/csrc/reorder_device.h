@@ -17,11 +17,12 @@ constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in L
 constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
 
 enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
-enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2 };
+enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2, PROP_FRESH = 3 /* fused rounds: nothing proposed yet */ };
 // per-chain proposal word exchanged between ranks in single-pool multi-GPU mode:
-// kind << 32 | rid, bit 40 = "this seed is the lowest of the round" (moves the cursor)
-enum { PK_NONE = 0, PK_MATCH = 1, PK_SEED = 2, PK_NEED = 3, PK_NOSEED = 4, PK_DONE = 5 };
+// kind << 32 | rid, bit 40 = "this seed is the lowest of the round" (moves the cursor), bit 41 below
+enum { PK_NONE = 0, PK_MATCH = 1, PK_SEED = 2, PK_NOSEED = 4, PK_DONE = 5 };
 constexpr unsigned long long PK_CURSOR_BIT = 1ull << 40;
+constexpr unsigned long long PK_WILLNEED_BIT = 1ull << 41;  // PK_NONE after a failed left search: the chain needs a seed next
 
 // Per-chain state (one greedy chain == one reference OpenMP thread, reorder.h:351-431).
 // The 64-byte header is one cache line: a wave loads it once (4 x 16 B, broadcast)
@@ -78,13 +79,16 @@ struct DevParams {
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
   uint32_t *resv;     // lowest chain id that proposed read r this round (0xffffffff = none)
   uint32_t *needy;    // bitmap over chains waiting for a seed (padded with zero words to a multiple of 256 words)
-  uint32_t *needy_cnt; // multi-GPU pools only (else null): set bits per 64 words of needy (2048 chains), by k_mg_bits
+  // rounds whose shared state is kept by k_mg_mark (fused rounds, multi-GPU pools; null in the two-kernel round):
+  uint32_t *needy_cnt;       // set bits per 64 words of needy (2048 chains) as k_mg_mark of the LAST round left them
+  uint32_t *needy_cnt_next;  // the buffer k_mg_mark of THIS round fills (zeroed by the previous k_mg_mark)
+  uint32_t *alive_next;      // the other alive counter: zeroed by this round's k_mg_mark for the next one
+  int fused;                 // 1: k_round (apply + search in one kernel)
   Globals *glob;
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;
-  unsigned long long *dbg;    // [64] wave-lifetime counters by category (builds with -DSPRING_DBG_WAVETIME only)
   unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
-  uint32_t *alive_round;      // [1] chains not done, recounted from prop every round (multi-GPU mode)
+  uint32_t *alive_round;      // [1] chains not done, recounted from prop every round by k_mg_mark
   Chain *chains;
   int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong: wide format (some count > 255)
   uint32_t *cnt8;     // same, one byte per count: the format of almost every update (4x fewer bytes moved)
@@ -120,10 +124,12 @@ void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
 void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n);
 void launch_init_chains(hipStream_t st, const DevParams &P);
+// two-kernel round (one GPU): search -> apply
 void launch_search(hipStream_t st, const DevParams &P, bool stats);
 void launch_apply(hipStream_t st, const DevParams &P, bool literal);
-// single-pool multi-GPU round: search (own chains) -> [exchange prop] -> post_exchange -> apply (own) -> mark (all)
-void launch_mg_post_exchange(hipStream_t st, const DevParams &P);
+// fused round: round (apply of the last proposals + search, own chains) -> [multi-GPU: all-gather of prop, resolve] -> mark
+void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg);
+void launch_mg_resolve(hipStream_t st, const DevParams &P);
 void launch_mg_mark(hipStream_t st, const DevParams &P);
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s);

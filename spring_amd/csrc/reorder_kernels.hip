@@ -29,22 +29,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// experiment builds (-DSPRING_DBG_WAVETIME): per-category wave count and summed lifetime in 10 ns ticks
-#ifdef SPRING_DBG_WAVETIME
-#define WT_BEGIN() const unsigned long long wt_t0_ = wall_clock64()
-#define WT_END(P, lane, cat)                                                           \
-  do {                                                                                 \
-    if ((lane) == 0) {  /* 4096 counter sets: same-address atomics would serialise */  \
-      unsigned long long *d_ = (P).dbg + (size_t)(li & 4095u) * 32;                    \
-      d_[2 * (cat)] += 1ull;                                                           \
-      d_[2 * (cat) + 1] += wall_clock64() - wt_t0_;                                    \
-    }                                                                                  \
-  } while (0)
-#else
-#define WT_BEGIN() do {} while (0)
-#define WT_END(P, lane, cat) do {} while (0)
-#endif
-
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -364,8 +348,9 @@ __device__ __forceinline__ int argmax_code(const int4 &v) {  // reorder.h:204-21
   return code_of_cidx(ind);
 }
 
-// packs LDS codes[0..R) into limbs (ballot based) and stores ref + revref
-__device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int lane, Chain *c) {
+// packs LDS codes[0..R) into limbs (ballot based) and stores ref + revref; with lds_refs (the fused round kernel)
+// the limbs also go to the search's LDS copy [2][LDS_LIMBS] (zero padded either side)
+__device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int lane, Chain *c, uint64_t *lds_refs = nullptr) {
   wave_sync();
   const int nblk = (R + 63) >> 6;
 #pragma unroll
@@ -388,6 +373,7 @@ __device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int lane, Cha
       const uint64_t limb = spread32((uint32_t)(hi ? a >> 32 : a)) | (spread32((uint32_t)(hi ? b >> 32 : b)) << 1);
       uint64_t *dst = isrev ? c->revref : c->ref;
       dst[2 * k + (hi ? 1 : 0)] = limb;
+      if (lds_refs) lds_refs[(isrev ? LDS_LIMBS : 0) + LDS_PAD + 2 * k + (hi ? 1 : 0)] = limb;
     }
   }
 }
@@ -600,6 +586,7 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
     h.prev = seed; h.first_rid = seed; h.prev_unmatched = 1;
     h.e_slot = li * CHUNK; h.s_slot = li * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
     h.ref_len = Rn; h.cnt_buf = 1; h.cnt_wide = 0;
+    if (P.fused) h.prop_kind = PROP_FRESH;
     store_hot(c, h);
     c->n_unmatched = 1;
     if (P.prop) P.prop[cid] = (unsigned long long)PK_NONE << 32;
@@ -926,34 +913,14 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 // (shifts [0, fs) and [fs, fs + 16): lane order == the reference's priority order, the first set bit of the
 // hit ballot is the reference's winner), then the tail (every remaining window at once, winner = lowest
 // priority code).  Chains that need a new contig seed instead pick the (rank+1)-th highest untaken read at
-// or below the global cursor (reorder.h:576-592).  WPB = chains (wavefronts) per block.
-template <bool STATS, bool MG, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_search(DevParams P) {
-  __shared__ uint64_t s_refs[WPB][2][LDS_LIMBS];
-  __shared__ uint16_t s_list[WPB][TAIL_CAP];
-  __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t li = blockIdx.x * WPB + wave;
-  if (li >= P.K) return;
-  WT_BEGIN();
-  const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
-  Chain *c = &P.chains[li];
-  ChainHot h;
-  load_hot(c, h);
-  // stage ref / revref in LDS right away (same dependency level as the header load)
-  if (lane < LDS_LIMBS) {
-    const int i = lane - LDS_PAD;
-    const bool in = i >= 0 && i < P.W;
-    s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
-    s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
-  }
-  if (h.done) { WT_END(P, lane, 0); return; }
-
+// or below the global cursor (reorder.h:576-592).
+// WORD: publish the proposal as a word of P.prop (multi-GPU pools: resolved after the all-gather; fused rounds:
+// read by k_mg_mark).  DIRECT: reserve the read at once (atomicMin on resv[]), everything is on this GPU.
+// `h` is the chain's header as it stands (all lanes hold the same copy); ref / revref are already in s_refs.
+template <bool STATS, bool WORD, bool DIRECT>
+__device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
+                                            uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat) {
   if (h.mode == MODE_NEED_SEED) {
-    if (MG) {  // seeds are assigned after the exchange (k_mg_seed), when every rank knows who needs one
-      if (lane == 0) P.prop[cid] = (unsigned long long)PK_NEED << 32;
-      return;
-    }
     bool is_last;
     const long long seed = find_seed(P, cid, lane, &is_last);
     if (lane == 0) {
@@ -962,14 +929,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
         h.prop_rid = (uint32_t)seed;
         // the last-ranked needy chain proposes the lowest seed of the round: it alone moves the cursor
         h.cursor_writer = is_last;
-        atomicMin(&P.resv[seed], cid);
+        if (WORD) P.prop[cid] = ((unsigned long long)PK_SEED << 32) | (uint32_t)seed | (is_last ? PK_CURSOR_BIT : 0ull);
+        if (DIRECT) atomicMin(&P.resv[seed], cid);
       } else {
         h.prop_kind = PROP_NONE;
         h.finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
+        if (WORD) P.prop[cid] = (unsigned long long)PK_NOSEED << 32;
       }
       store_hot(c, h);
     }
-    WT_END(P, lane, 1);
     return;
   }
 
@@ -986,21 +954,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (lane == 0) {
       h.prop_kind = PROP_NONE;
       store_hot(c, h);
-      if (MG) P.prop[cid] = (unsigned long long)PK_NONE << 32;
+      if (WORD) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
       if (STATS && new_iter) c->st_iter++;
     }
-    WT_END(P, lane, 2);
     return;
   }
 
   // the bookkeeping fields changed above go back now; the 64-byte header is not kept in registers across
   // the probe loop (the kernel is latency-bound at 8 waves/SIMD, i.e. 64 VGPRs, so every register counts)
   const int ref_len = h.ref_len;
+  const bool left_search = h.left_search;
   if (lane == 0 && new_iter) {
     c->h.num_reads_thr = h.num_reads_thr;
     c->h.num_unmatched_past = h.num_unmatched_past;
   }
-  const uint64_t *sref = &s_refs[wave][0][LDS_PAD], *srev = &s_refs[wave][1][LDS_PAD];
+  const uint64_t *sref = s_refs + LDS_PAD, *srev = s_refs + LDS_LIMBS + LDS_PAD;
   wave_sync();
   // most chains match within the first few shifts: the first batch covers only fs of them (every lane past the
   // winner is a wasted 64-byte request).  A fresh seed (nothing matched to it yet) fails about every second
@@ -1008,19 +976,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   const int fs = (h.prev_unmatched && P.seed_wide) ? 16 : P.first_shifts;
   BatchOut o;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
-  int wt_cat = 3;
   uint64_t pm0 = 0, pm1 = 0;
 #pragma nounroll
   for (int ph = 0; ph < 2; ph++) {  // the two ordered batches: shifts [0, fs) and [fs, fs + 16)
     probe_batch<STATS>(P, sref, srev, ph ? fs : 0, ph ? 16 : fs, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     if (ph) pm1 = o.pm; else pm0 = o.pm;
-    wt_cat = 3 + ph;
     if (o.found || fs >= P.maxshift) break;
   }
   if (!o.found && fs + 16 < P.maxshift) {
-    wt_cat = 5;
-    probe_tail<STATS>(P, sref, srev, s_list[wave], s_stat[STATS ? wave : 0], fs + 16, fs, pm0, pm1, lane, ref_len, o);
+    probe_tail<STATS>(P, sref, srev, s_list, s_stat, fs + 16, fs, pm0, pm1, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
   }
   if (lane == 0) {
@@ -1029,11 +994,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
       c->h.prop_shift = o.code >> 2;
       c->h.prop_rev = (uint8_t)((o.code >> 1) & 1);
       c->h.prop_kind = PROP_MATCH;
-      if (MG) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;  // resolved after the exchange
-      else atomicMin(&P.resv[o.rid], cid);
+      if (WORD) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;
+      if (DIRECT) atomicMin(&P.resv[o.rid], cid);
     } else {
       c->h.prop_kind = PROP_NONE;
-      if (MG) P.prop[cid] = (unsigned long long)PK_NONE << 32;
+      // a failed left search sends the chain for a new seed (apply step): k_mg_mark puts it on the needy bitmap
+      if (WORD) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (left_search ? PK_WILLNEED_BIT : 0ull);
     }
     if (STATS) {
       c->st_probes += st_p; c->st_keyok += st_k; c->st_cands += st_c;
@@ -1041,7 +1007,31 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
       if (new_iter) c->st_iter++;
     }
   }
-  WT_END(P, lane, o.found ? wt_cat : 6 + (h.prev_unmatched ? 1 : 0));
+}
+
+// ------------------------------------------------------------ K4 search (phase A of the two-kernel round)
+// WPB = chains (wavefronts) per block.
+template <bool STATS, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_search(DevParams P) {
+  __shared__ uint64_t s_refs[WPB][2][LDS_LIMBS];
+  __shared__ uint16_t s_list[WPB][TAIL_CAP];
+  __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t li = blockIdx.x * WPB + wave;
+  if (li >= P.K) return;
+  const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
+  Chain *c = &P.chains[li];
+  ChainHot h;
+  load_hot(c, h);
+  // stage ref / revref in LDS right away (same dependency level as the header load)
+  if (lane < LDS_LIMBS) {
+    const int i = lane - LDS_PAD;
+    const bool in = i >= 0 && i < P.W;
+    s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
+    s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
+  }
+  if (h.done) return;
+  search_step<STATS, false, true>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0]);
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1073,45 +1063,27 @@ __device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uin
   P.s_order[idx] = rid; P.s_chain[idx] = cid; P.s_seq[idx] = h.n_single++;
 }
 
-template <int NP, bool LITERAL, bool MG>
-__global__ __launch_bounds__(256) void k_apply(DevParams P) {
-  __shared__ WaveLds lds[4];
-  __shared__ WaveLdsLiteral ldsl[LITERAL ? 4 : 1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // local chain index (state arrays, emission tags); wave-uniform -> chain pointers live in SGPRs
-  const uint32_t li = blockIdx.x * 4 + wave;
-  if (li >= P.K) return;
-  WT_BEGIN();
-  const uint32_t cid = P.c0 + li;             // global chain id (conflict priority)
-  Chain *c = &P.chains[li];
-  ChainHot h;
-  load_hot(c, h);
-  if (h.done) { WT_END(P, lane, 8); return; }
-  WaveLds *ws = &lds[wave];
-  WaveLdsLiteral *wl = &ldsl[LITERAL ? wave : 0];
-  int kind = h.prop_kind;
-  if (MG) {  // seed decisions were taken after the exchange and live in prop[]
-    const unsigned long long pv = P.prop[cid];
-    const int pk = (int)(pv >> 32) & 7;
-    if (pk == PK_SEED) { kind = PROP_SEED; h.prop_rid = (uint32_t)pv; }
-    else if (pk == PK_NOSEED) { kind = PROP_NONE; h.finishing = 1; }
-    else if (pk == PK_MATCH) kind = PROP_MATCH;
-    else kind = PROP_NONE;
-  }
-
+// One chain's phase B.  Resolves the proposal the chain made in the last search (lowest chain id holds resv[rid])
+// and applies the winner's step.  Every lane ends up with the same updated header `h` (the fields of the emission
+// allocator excepted, which only lane 0 uses); lane 0 stores it.  DEFER: the shared state (taken[], needy[],
+// cursor, alive) is updated by k_mg_mark instead (multi-GPU pools, fused rounds).  lds_refs: see pack_consensus.
+// Returns false when the chain has nothing more to do this round (it is, or just became, done).
+template <int NP, bool LITERAL, bool DEFER>
+__device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, int lane,
+                                           WaveLds *ws, WaveLdsLiteral *wl, uint64_t *lds_refs) {
+  const int kind = h.prop_kind;
+  if (kind == PROP_FRESH) return true;  // first fused round: nothing proposed yet
   if (h.finishing) {  // seed-needing chain found the pool empty
     if (lane == 0) {
       if (h.prev_unmatched) emit_single(P, h, li, h.prev);
       h.done = 1; h.finishing = 0;
-      if (MG) P.prop[cid] = (unsigned long long)PK_DONE << 32;
-      else {
+      if (!DEFER) {  // DEFER: every rank reads PK_NOSEED in the gathered words (k_mg_mark); the chain says PK_DONE from now on
         atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
         atomicSub(&P.glob->alive, 1u);
       }
       store_hot(c, h);
     }
-    WT_END(P, lane, 9);
-    return;
+    return false;
   }
   // who holds the read we proposed (load in flight while the update is computed)
   const uint32_t owner = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;
@@ -1136,31 +1108,28 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
                                                h.cnt_wide != 0, true, o2, lane);
     }
   }
-  if (!MG && kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
+  if (!DEFER && kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
     if (lane == 0) P.glob->cursor = (long long)h.prop_rid - 1;
     h.cursor_writer = 0;
   }
-  if (owner != cid) {  // lost the read: retry next round, nothing committed
+  if (owner != cid) {  // lost the read: retry, nothing committed
+    if (h.mode == MODE_SEARCH) h.retrying = 1;
     if (lane == 0) {
-      if (h.mode == MODE_SEARCH) h.retrying = 1;
       store_hot(c, h);
       c->st_lost++;
     }
-    WT_END(P, lane, 10);
-    return;
+    return true;
   }
   if (do_upd) {
-    pack_consensus(ws, R_new, lane, c);
+    pack_consensus(ws, R_new, lane, c, lds_refs);
     h.ref_len = R_new;
     h.cnt_buf ^= 1;
     h.cnt_wide = nw;
   }
-  if (lane != 0) return;
-  WT_END(P, lane, kind == PROP_MATCH ? 11 : kind == PROP_SEED ? 12 : fail_path ? 13 : 14);
   if (kind == PROP_MATCH) {
     const uint32_t rid = h.prop_rid;
     const int shift = ushift;
-    if (!MG) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));  // MG: k_mg_mark on every rank
+    if (!DEFER && lane == 0) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
     const bool left = h.left_search;
     long long ref_pos = h.ref_pos, cur_pos;
     char rcch;
@@ -1173,17 +1142,21 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
       else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
       rcch = left ? 'd' : 'r';
     }
-    if (h.prev_unmatched) emit_rec(P, h, li, h.prev, 'd', '0', 0);
-    emit_rec(P, h, li, rid, rcch, '1', cur_pos);
+    if (lane == 0) {
+      if (h.prev_unmatched) emit_rec(P, h, li, h.prev, 'd', '0', 0);
+      emit_rec(P, h, li, rid, rcch, '1', cur_pos);
+    }
     h.prev_unmatched = 0; h.ref_pos = ref_pos; h.retrying = 0;
   } else if (kind == PROP_SEED) {  // reorder.h:580-587, :600-613
     const uint32_t rid = h.prop_rid;
-    if (!MG) {
-      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
-      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+    if (lane == 0) {
+      if (!DEFER) {
+        atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+        atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+      }
+      if (h.prev_unmatched) emit_single(P, h, li, h.prev);
+      c->n_unmatched++;
     }
-    if (h.prev_unmatched) emit_single(P, h, li, h.prev);
-    c->n_unmatched++;
     h.prev_unmatched = 1; h.first_rid = rid; h.prev = rid;
     h.ref_pos = 0; h.mode = MODE_SEARCH;
   } else if (fail_path) {  // search failed (reorder.h:559-575)
@@ -1192,48 +1165,75 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
     if (!h.left_search) { h.left_search = 1; h.ref_pos = 0; }
     else {
       h.left_search = 0; h.mode = MODE_NEED_SEED;
-      if (!MG) atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));  // MG: the chain says PK_NEED next round
+      if (!DEFER && lane == 0) atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));  // DEFER: k_mg_mark, from the PK_WILLNEED word
     }
   }
-  store_hot(c, h);
+  if (lane == 0) store_hot(c, h);
+  return true;
+}
+
+template <int NP, bool LITERAL>
+__global__ __launch_bounds__(256) void k_apply(DevParams P) {
+  __shared__ WaveLds lds[4];
+  __shared__ WaveLdsLiteral ldsl[LITERAL ? 4 : 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // local chain index (state arrays, emission tags); wave-uniform -> chain pointers live in SGPRs
+  const uint32_t li = blockIdx.x * 4 + wave;
+  if (li >= P.K) return;
+  const uint32_t cid = P.c0 + li;             // global chain id (conflict priority)
+  Chain *c = &P.chains[li];
+  ChainHot h;
+  load_hot(c, h);
+  if (h.done) return;
+  (void)apply_step<NP, LITERAL, false>(P, c, cid, li, h, lane, &lds[wave], &ldsl[LITERAL ? wave : 0], nullptr);
+}
+
+// ------------------------------------------------------------ fused round: apply(t-1) + search(t) in one kernel
+// The two phases of consecutive rounds for one chain, back to back: the chain's header and consensus are loaded
+// once, the new consensus goes from the update straight into the search's LDS copy, and a round is one chain
+// kernel + k_mg_mark instead of two chain kernels.  Same schedule as the two-kernel round (same oracle): every
+// search of round t sees taken[] with all claims of round t-1, because k_mg_mark(t-1) -- which sets the winners'
+// taken bits, the cursor and the needy bitmap from the proposal words -- runs between the two launches; the
+// resv[] entries the apply halves read belong to reads that are all taken by then, so the proposals of round t
+// never touch them.
+// MG (one pool over several GPUs): a rank runs its own chains only and publishes one word per chain; the lowest-
+// chain-id resolution (k_mg_resolve) runs after the all-gather on every rank, then k_mg_mark.  One GPU: the
+// proposals go straight to resv[] (atomicMin) and the words are only k_mg_mark's input.
+template <int NP, bool STATS, bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_round(DevParams P) {
+  __shared__ uint64_t s_refs[2][LDS_LIMBS];
+  __shared__ uint16_t s_list[TAIL_CAP];
+  __shared__ uint16_t s_stat[STATS ? 2 * TAIL_CAP : 2];
+  __shared__ WaveLds lds;
+  const int lane = threadIdx.x;
+  const uint32_t li = blockIdx.x;
+  const uint32_t cid = P.c0 + li;
+  Chain *c = &P.chains[li];
+  ChainHot h;
+  load_hot(c, h);
+  if (lane < LDS_LIMBS) {
+    const int i = lane - LDS_PAD;
+    const bool in = i >= 0 && i < P.W;
+    s_refs[0][lane] = in ? c->ref[i] : 0ull;
+    s_refs[1][lane] = in ? c->revref[i] : 0ull;
+  }
+  if (h.done) {
+    if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+    return;
+  }
+  wave_sync();  // the update below rewrites s_refs
+  if (!apply_step<NP, false, true>(P, c, cid, li, h, lane, &lds, nullptr, &s_refs[0][0])) {
+    if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+    return;
+  }
+  search_step<STATS, true, !MG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat);
 }
 
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
-// prop[] now holds every rank's proposals.  All ranks run these over ALL chains and therefore keep
-// identical taken[] / resv[] / cursor replicas; only k_apply is restricted to the chains a rank owns.
+// prop[] now holds every rank's proposals.  All ranks run these two kernels over ALL chains and therefore keep
+// identical taken[] / resv[] / needy[] / cursor replicas; k_search and k_apply only touch the chains a rank owns.
+// (Work per rank that grows with the number of GPUs: two thread-per-chain passes, a few microseconds.)
 
-// needy bitmap + number of chains still running, from the proposal kinds
-__global__ void k_mg_bits(DevParams P) {
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nw = (P.Ktot + 31) / 32;
-  uint32_t bits = 0, alive = 0;
-  if (w < nw) {
-    for (uint32_t j = 0; j < 32; j++) {
-      const uint32_t cid = w * 32 + j;
-      if (cid >= P.Ktot) break;
-      const int pk = (int)(P.prop[cid] >> 32) & 7;
-      if (pk == PK_NEED) bits |= 1u << j;
-      if (pk != PK_DONE) alive++;
-    }
-    P.needy[w] = bits;
-  }
-  const uint32_t nb = (uint32_t)wave_sum_i(__popc(bits));  // a wavefront covers exactly one 64-word block
-  if ((threadIdx.x & 63) == 0 && w < nw) P.needy_cnt[w >> 6] = nb;
-  alive = (uint32_t)wave_sum_i((int)alive);
-  if ((threadIdx.x & 63) == 0 && alive) atomicAdd(P.alive_round, alive);
-}
-// seed assignment for every chain that asked for one (one wavefront per chain, all ranks identically)
-__global__ __launch_bounds__(256) void k_mg_seed(DevParams P) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t cid = blockIdx.x * 4 + wave;
-  if (cid >= P.Ktot) return;
-  if (((int)(P.prop[cid] >> 32) & 7) != PK_NEED) return;
-  bool is_last;
-  const long long seed = find_seed(P, cid, lane, &is_last);
-  if (lane == 0)
-    P.prop[cid] = seed >= 0 ? (((unsigned long long)PK_SEED << 32) | (uint32_t)seed | (is_last ? PK_CURSOR_BIT : 0ull))
-                            : ((unsigned long long)PK_NOSEED << 32);
-}
 // lowest chain id wins a contested read
 __global__ void k_mg_resolve(DevParams P) {
   const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1242,16 +1242,39 @@ __global__ void k_mg_resolve(DevParams P) {
   const int pk = (int)(pv >> 32) & 7;
   if (pk == PK_MATCH || pk == PK_SEED) atomicMin(&P.resv[(uint32_t)pv], cid);
 }
-// winners claim their read on every replica; the lowest seed of the round moves the cursor
-__global__ void k_mg_mark(DevParams P) {
+// winners claim their read on every replica; the lowest seed of the round moves the cursor; the needy bitmap
+// (+ its per-2048-chain counts) for the seed ranking of the NEXT round's k_search: chains whose left search just
+// failed (k_apply sends them for a seed) and chains whose seed went to a lower chain id; chains still running
+__global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cid >= P.Ktot) return;
-  const unsigned long long pv = P.prop[cid];
-  const int pk = (int)(pv >> 32) & 7;
-  if (pk != PK_MATCH && pk != PK_SEED) return;
-  const uint32_t rid = (uint32_t)pv;
-  if (P.resv[rid] == cid) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
-  if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)rid - 1;
+  const int lane = threadIdx.x & 63;
+  bool needy = false, alive = false;
+  if (cid < P.Ktot) {
+    const unsigned long long pv = P.prop[cid];
+    const int pk = (int)(pv >> 32) & 7;
+    alive = pk != PK_DONE;
+    if (pk == PK_MATCH || pk == PK_SEED) {
+      const uint32_t rid = (uint32_t)pv;
+      const bool won = P.resv[rid] == cid;
+      if (won) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+      if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)rid - 1;  // every seed proposed this round ends up taken
+      needy = pk == PK_SEED && !won;
+    } else if (pk == PK_NONE) {
+      needy = (pv & PK_WILLNEED_BIT) != 0;
+    }
+  }
+  const uint64_t nb = __ballot(needy);
+  const uint32_t na = (uint32_t)__popcll(__ballot(alive));
+  const uint32_t w0 = (cid & ~63u) >> 5;  // a wavefront covers two bitmap words
+  if (lane == 0 && (cid & ~63u) < P.Ktot) {
+    P.needy[w0] = (uint32_t)nb;
+    if ((cid & ~63u) + 32 < ((P.Ktot + 31) & ~31u)) P.needy[w0 + 1] = (uint32_t)(nb >> 32);
+    if (nb) atomicAdd(&P.needy_cnt_next[cid >> 11], (uint32_t)__popcll(nb));
+    if (na) atomicAdd(P.alive_round, na);
+  }
+  // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
+  if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
+  if (cid == 0) *P.alive_next = 0;
 }
 
 // ------------------------------------------------------------ K7 finalize / emit
@@ -1316,7 +1339,7 @@ __global__ void k_synth(uint8_t *__restrict__ dst, uint32_t n, uint32_t L, uint6
   const uint32_t rec = 2u + (L + 3) / 4;
   uint8_t *o = dst + i * rec;
   uint64_t pos; uint32_t rc;
-  syn_read_params(seed, G, L, i, &pos, &rc);
+  syn_read_params(seed, G, L, i, (thr24 & SYN_PAIRED_FLAG) ? n / 2 : 0, &pos, &rc);
   o[0] = (uint8_t)(L & 0xff); o[1] = (uint8_t)(L >> 8);
   for (uint32_t b = 0; b < (L + 3) / 4; b++) {
     uint32_t v = 0;
@@ -1394,13 +1417,8 @@ template <int WPB>
 static void launch_search_wpb(hipStream_t st, const DevParams &P, bool stats) {
   const dim3 g((P.K + WPB - 1) / WPB), b(64 * WPB);
   const size_t dyn = (size_t)P.dbg_search_lds;  // occupancy experiment: dummy dynamic LDS per block
-  if (P.prop) {
-    if (stats) hipLaunchKernelGGL((k_search<true, true, WPB>), g, b, dyn, st, P);
-    else hipLaunchKernelGGL((k_search<false, true, WPB>), g, b, dyn, st, P);
-  } else {
-    if (stats) hipLaunchKernelGGL((k_search<true, false, WPB>), g, b, dyn, st, P);
-    else hipLaunchKernelGGL((k_search<false, false, WPB>), g, b, dyn, st, P);
-  }
+  if (stats) hipLaunchKernelGGL((k_search<true, WPB>), g, b, dyn, st, P);
+  else hipLaunchKernelGGL((k_search<false, WPB>), g, b, dyn, st, P);
 }
 void launch_search(hipStream_t st, const DevParams &P, bool stats) {
   if (!P.K) return;
@@ -1411,23 +1429,27 @@ void launch_search(hipStream_t st, const DevParams &P, bool stats) {
 void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
   if (!P.K) return;
   const dim3 g((P.K + 3) / 4), b(256);
-  if (P.prop) {
-    if (literal) { hipLaunchKernelGGL((k_apply<8, true, true>), g, b, 0, st, P); return; }
-#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, true>), g, b, 0, st, P)
-    NP_DISPATCH(CALL);
-#undef CALL
-    return;
-  }
-  if (literal) { hipLaunchKernelGGL((k_apply<8, true, false>), g, b, 0, st, P); return; }
-#define CALL(N) hipLaunchKernelGGL((k_apply<N, false, false>), g, b, (size_t)P.dbg_apply_lds, st, P)  // dbg: occupancy experiment
+  if (literal) { hipLaunchKernelGGL((k_apply<8, true>), g, b, 0, st, P); return; }
+#define CALL(N) hipLaunchKernelGGL((k_apply<N, false>), g, b, (size_t)P.dbg_apply_lds, st, P)  // dbg: occupancy experiment
   NP_DISPATCH(CALL);
 #undef CALL
 }
-void launch_mg_post_exchange(hipStream_t st, const DevParams &P) {
-  const uint32_t nw = (P.Ktot + 31) / 32;
-  (void)hipMemsetAsync(P.alive_round, 0, 4, st);
-  hipLaunchKernelGGL(k_mg_bits, GRID1(nw, 256), dim3(256), 0, st, P);
-  hipLaunchKernelGGL(k_mg_seed, dim3((P.Ktot + 3) / 4), dim3(256), 0, st, P);
+// fused round: one wavefront (= one block) per chain; NP = 3 covers reads up to 192 bases, 8 the rest
+void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
+  if (!P.K) return;
+  const dim3 g(P.K), b(64);
+  const size_t dyn = (size_t)P.dbg_search_lds;
+#define RCALL(N)                                                                          \
+  do {                                                                                    \
+    if (mg) { if (stats) hipLaunchKernelGGL((k_round<N, true, true>), g, b, dyn, st, P);  \
+              else hipLaunchKernelGGL((k_round<N, false, true>), g, b, dyn, st, P); }     \
+    else { if (stats) hipLaunchKernelGGL((k_round<N, true, false>), g, b, dyn, st, P);    \
+           else hipLaunchKernelGGL((k_round<N, false, false>), g, b, dyn, st, P); }       \
+  } while (0)
+  if (P.Lpad <= 192) RCALL(3); else RCALL(8);
+#undef RCALL
+}
+void launch_mg_resolve(hipStream_t st, const DevParams &P) {
   hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 }
 void launch_mg_mark(hipStream_t st, const DevParams &P) {

@@ -136,10 +136,9 @@ struct spring_reorder_ctx {
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
   bool mg = false;
-  // exchange transport of mg_run: RCCL communicator (loaded at run time) or a caller-supplied host all-gather
-  void *rccl_comm = nullptr;
-  spring_mg_allgather_fn host_xchg = nullptr;
-  void *host_xchg_user = nullptr;
+  uint32_t *cnt_buf[2] = {nullptr, nullptr};  // needy_cnt double buffer (reorder_device.h)
+  uint32_t *alive_buf = nullptr;              // [2] running-chain counters
+  uint64_t round_no = 0;
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
   uint32_t *d_orderN[2] = {nullptr, nullptr};
@@ -231,12 +230,17 @@ int rccl_load() {
   return 0;
 }
 const char *rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error"; }
-void rccl_release(spring_reorder_ctx *ctx) {
-  if (ctx->rccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->rccl_comm);
-  ctx->rccl_comm = nullptr;
-}
 constexpr int RCCL_UINT64 = 5;  // ncclUint64 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5)
 }  // namespace
+
+// exchange transport of mg_run: an RCCL communicator or a caller-supplied host all-gather
+struct spring_mg_comm {
+  uint32_t rank = 0, world = 1;
+  int dev = 0;
+  void *rccl = nullptr;
+  spring_mg_allgather_fn host_fn = nullptr;
+  void *host_user = nullptr;
+};
 
 #define DMALLOC(ptr, bytes)                                   \
   do {                                                        \
@@ -295,7 +299,6 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
-  rccl_release(ctx);
   for (void *p : ctx->allocs) pool_free(ctx->dev, p);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
@@ -512,7 +515,8 @@ int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, s
   if (paired && (r = fq_scan_file(ctx, fastq_2, nbytes_2, f[1], d_err))) return r;
   uint32_t err = 0;
   HIPCHK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
-  if (err) return fail(SPRING_REORDER_E_ARG, "Too long read length (please try --long/-l flag).");
+  if (err & 1u) return fail(SPRING_REORDER_E_ARG, "Too long read length (please try --long/-l flag).");
+  if (err & 2u) return fail(SPRING_REORDER_E_ARG, "Invalid character in a read (only A, C, G, T and N are supported).");
   if (paired && f[0].nreads != f[1].nreads) return fail(SPRING_REORDER_E_ARG, "Number of reads in paired files do not match.");
   if (f[0].nreads + f[1].nreads > 4294967290ull) return fail(SPRING_REORDER_E_ARG, "Too many reads.");
   const uint32_t n_clean = f[0].n_clean + f[1].n_clean;
@@ -585,11 +589,12 @@ size_t spring_synth_dna_bytes(uint32_t n, uint32_t L) { return (size_t)n * (2u +
 
 int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm) {
   if (L == 0 || L > (uint32_t)MAX_READ_LEN || G < L) return fail(SPRING_REORDER_E_ARG, "bad synth geometry");
+  if ((err_ppm & SYN_PAIRED_FLAG) && (n & 1)) return fail(SPRING_REORDER_E_ARG, "a paired pool holds an even number of reads");
   const uint32_t rec = 2u + (L + 3u) / 4u, thr = syn_err_thr24(err_ppm);
   for (uint64_t i = 0; i < n; i++) {
     uint8_t *o = dst + i * rec;
     uint64_t pos; uint32_t rc;
-    syn_read_params(seed, G, L, i, &pos, &rc);
+    syn_read_params(seed, G, L, i, (err_ppm & SYN_PAIRED_FLAG) ? n / 2 : 0, &pos, &rc);
     o[0] = (uint8_t)(L & 0xff); o[1] = (uint8_t)(L >> 8);
     for (uint32_t b = 0; b < (L + 3) / 4; b++) {
       uint32_t v = 0;
@@ -603,8 +608,22 @@ int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint
   return 0;
 }
 
+int spring_synth_genome_host(uint8_t *dst, uint64_t G, uint64_t seed, uint32_t flags) {
+  if (!dst) return fail(SPRING_REORDER_E_ARG, "dst is NULL");
+  for (uint64_t p = 0; p < G; p++) {
+    uint64_t gp = p;
+    if (flags & SYN_REPEAT_FLAG) {
+      const uint64_t seg = G / 8, k = seg ? gp / seg : 0;
+      if (seg && k < 8 && (k & 1) == 0) gp %= seg;
+    }
+    dst[p] = (uint8_t)"ACGT"[syn_genome_base(seed, gp)];
+  }
+  return 0;
+}
+
 int spring_synth_dna_device(void *d_dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm) {
   if (!d_dst || L == 0 || L > (uint32_t)MAX_READ_LEN || G < L) return fail(SPRING_REORDER_E_ARG, "bad synth arguments");
+  if ((err_ppm & SYN_PAIRED_FLAG) && (n & 1)) return fail(SPRING_REORDER_E_ARG, "a paired pool holds an even number of reads");
   launch_synth(nullptr, (uint8_t *)d_dst, n, L, G, seed, syn_err_thr24(err_ppm));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(nullptr));
@@ -616,6 +635,7 @@ int spring_reorder_load_synth(spring_reorder_ctx *ctx, uint32_t n, uint32_t L, u
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_synth: context already loaded");
   if (L == 0 || L > (uint32_t)MAX_READ_LEN || G < L) return fail(SPRING_REORDER_E_ARG, "bad synth geometry");
+  if ((err_ppm & SYN_PAIRED_FLAG) && (n & 1)) return fail(SPRING_REORDER_E_ARG, "a paired pool holds an even number of reads");
   HIPCHK(hipSetDevice(ctx->dev));
   int r = setup_geometry(ctx, n, L);
   if (r) return r;
@@ -884,13 +904,11 @@ static uint32_t auto_chains(uint32_t n) {
   return (uint32_t)k;
 }
 
-int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
-  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
-  if (ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "run_chains: build_dict first");
-  HIPCHK(hipSetDevice(ctx->dev));
+// device state of the chain phase for the chains [c0, c0 + K) of Ktot this context owns; `d_prop`: caller's
+// proposal buffer or null.  Used by run_chains (c0 = 0, K = Ktot) and mg_begin.
+static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32_t Ktot, bool fused, void *d_prop) {
   hipStream_t st = ctx->st;
   const uint32_t n = ctx->n;
-  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n);
   ctx->K = K;
   DevParams &P = ctx->P;
   fill_params(ctx, P);
@@ -898,9 +916,8 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   const size_t nn = std::max<uint32_t>(n, 1);
   DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
   DMALLOC(P.resv, nn * 4);
-  const size_t needy_bytes = (((size_t)K + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
+  const size_t needy_bytes = (((size_t)Ktot + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
   DMALLOC(P.needy, needy_bytes);
-  P.needy_cnt = nullptr;
   DMALLOC(P.glob, sizeof(Globals));
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
@@ -912,10 +929,22 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   DMALLOC(P.e_order, cap * 4); DMALLOC(P.e_rc, cap); DMALLOC(P.e_flag, cap); DMALLOC(P.e_pos, cap * 8);
   DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
   DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
-  P.K = K; P.c0 = 0; P.Ktot = K; P.prop = nullptr; P.alive_round = nullptr;
-  DMALLOC(P.dbg, 4096 * 32 * 8);
-  HIPCHK(hipMemsetAsync(P.dbg, 0, 4096 * 32 * 8, st));
-
+  P.K = K; P.c0 = c0; P.Ktot = Ktot;
+  P.fused = fused ? 1 : 0;
+  P.prop = nullptr; P.alive_round = P.alive_next = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
+  ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
+  ctx->alive_buf = nullptr;
+  if (fused) {  // the rounds whose shared state k_mg_mark keeps: proposal words + double-buffered counters
+    const size_t nblk = (size_t)Ktot / 2048 + 1;
+    if (d_prop) P.prop = (unsigned long long *)d_prop;
+    else DMALLOC(P.prop, (size_t)Ktot * 8);
+    DMALLOC(ctx->cnt_buf[0], 2 * nblk * 4);
+    ctx->cnt_buf[1] = ctx->cnt_buf[0] + nblk;
+    DMALLOC(ctx->alive_buf, 16);
+    HIPCHK(hipMemsetAsync(ctx->cnt_buf[0], 0, 2 * nblk * 4, st));
+    HIPCHK(hipMemsetAsync(ctx->alive_buf, 0, 16, st));
+    P.needy_cnt = ctx->cnt_buf[1];  // what the first round reads: nobody needs a seed yet
+  }
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   launch_init_taken(st, P.taken, nwords, n);
   launch_fill_u32(st, P.resv, n, 0xffffffffu);
@@ -925,16 +954,42 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   memset(&g, 0, sizeof(g));
   g.cursor = (long long)n - 1;
   g.e_alloc = g.s_alloc = K * CHUNK;
-  g.alive = n == 0 ? 0 : (n / K > 0 ? K : 1);  // chains that get a seed (reorder.h:405-421)
+  g.alive = n == 0 ? 0 : (n / Ktot > 0 ? K : (c0 == 0 ? 1 : 0));  // chains that get a seed (reorder.h:405-421)
   launch_fill_u32(st, P.e_chain, cap, 0xffffffffu);
   launch_fill_u32(st, P.s_chain, cap, 0xffffffffu);
   HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
   launch_init_chains(st, P);
   HIPCHK(hipGetLastError());
+  ctx->round_no = 0;
+  return 0;
+}
 
+// pointers of the double-buffered counters for round t (reorder_device.h): k_round(t) ranks seeds with what
+// k_mg_mark(t-1) counted; k_mg_mark(t) fills the other buffer and zeroes the one just read
+static void set_round_buffers(spring_reorder_ctx *ctx) {
+  DevParams &P = ctx->P;
+  const int w = (int)(ctx->round_no & 1);
+  P.needy_cnt = ctx->cnt_buf[w ^ 1];
+  P.needy_cnt_next = ctx->cnt_buf[w];
+  P.alive_round = ctx->alive_buf + w;
+  P.alive_next = ctx->alive_buf + (w ^ 1);
+}
+
+int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "run_chains: build_dict first");
+  HIPCHK(hipSetDevice(ctx->dev));
+  hipStream_t st = ctx->st;
+  const uint32_t n = ctx->n;
+  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n);
   const bool stats = ctx->o.collect_stats != 0;
   const bool timed = ctx->o.time_search != 0;
   const bool literal = ctx->o.force_literal_update != 0;
+  // one chain kernel per round (k_round + k_mg_mark) unless the literal consensus path or the two-kernel round is asked for
+  const bool fused = !literal && ctx->o.fused >= 0;
+  int r0 = setup_chains(ctx, K, 0, K, fused, nullptr);
+  if (r0) return r0;
+  DevParams &P = ctx->P;
   int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : (K >= 256 ? 16 : 256);
   std::vector<hipEvent_t> tev;
   if (timed) {
@@ -951,14 +1006,23 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   while (*h_alive) {
     for (int r = 0; r < R; r++) {
       if (timed) HIPCHK(hipEventRecord(tev[2 * r], st));
-      launch_search(st, P, stats);
-      if (timed) HIPCHK(hipEventRecord(tev[2 * r + 1], st));
-      launch_apply(st, P, literal);
+      if (fused) {
+        set_round_buffers(ctx);
+        launch_round(st, P, stats, false);
+        if (timed) HIPCHK(hipEventRecord(tev[2 * r + 1], st));
+        launch_mg_mark(st, P);
+        ctx->round_no++;
+      } else {
+        launch_search(st, P, stats);
+        if (timed) HIPCHK(hipEventRecord(tev[2 * r + 1], st));
+        launch_apply(st, P, literal);
+      }
     }
     rounds += R;
     for (int l = 0; l < 2; l++)  // shrink deep bins whose tail has been consumed (exact; see k_trim_bins)
       launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
-    HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
+    // chains still running: the two-kernel round keeps the count, the fused round recounts it every round
+    HIPCHK(hipMemcpyAsync(h_alive, fused ? P.alive_round : &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     if (timed) {
@@ -972,19 +1036,6 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   }
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   HIPCHK(hipStreamSynchronize(st));
-#ifdef SPRING_DBG_WAVETIME
-  {
-    std::vector<unsigned long long> all(4096 * 32);
-    HIPCHK(hipMemcpy(all.data(), P.dbg, all.size() * 8, hipMemcpyDeviceToHost));
-    unsigned long long d[32] = {0};
-    for (size_t i = 0; i < all.size(); i++) d[i & 31] += all[i];
-    static const char *nm[16] = {"S done", "S seed", "S stopped", "S hit batch0", "S hit batch1", "S hit tail", "S fail", "S fail (fresh seed)",
-                                 "A done", "A finishing", "A lost", "A match", "A seed", "A failpath", "A none", ""};
-    for (int i = 0; i < 15; i++)
-      if (d[2 * i]) fprintf(stderr, "[wavetime] %-20s waves %12llu  avg %8.2f us  total %10.1f wave-ms\n", nm[i], d[2 * i],
-                            d[2 * i + 1] * 0.01 / d[2 * i], d[2 * i + 1] * 1e-5);
-  }
-#endif
   (void)hipHostFree(h_alive);
   for (auto &e : tev) (void)hipEventDestroy(e);
   ctx->stats.rounds = rounds;
@@ -995,10 +1046,11 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
 }
 
 // ------------------------------------------------- single-pool multi-GPU
-// Every rank holds the full read pool and both dictionaries; rank r owns chains
-// [r*K/world, (r+1)*K/world).  One round = mg_search (own chains) -> all-gather of the
-// per-chain proposal words (done by the caller: torch.distributed over RCCL, or
-// spring_reorder_mg_exchange_virtual between contexts of one process) -> mg_apply.
+// Every rank holds the full read pool and the dictionary table; rank r owns chains
+// [r*K/world, (r+1)*K/world).  One round = mg_search (k_round over the own chains: apply of the last
+// proposals + search) -> all-gather of the per-chain proposal words (mg_run: inside the library; the
+// step-wise API: by the caller, or spring_reorder_mg_exchange_virtual between contexts of one process) ->
+// mg_apply (k_mg_resolve + k_mg_mark over all chains, on every rank identically).
 // Output is bit-identical to run_chains() with num_chains = total_chains on one GPU.
 int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains,
                             void *d_prop) {
@@ -1006,50 +1058,12 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   if (ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_begin: build_dict first");
   if (world == 0 || rank >= world || total_chains == 0 || total_chains % world)
     return fail(SPRING_REORDER_E_ARG, "mg_begin: total_chains (%u) must be a positive multiple of world (%u)", total_chains, world);
+  if (ctx->o.force_literal_update) return fail(SPRING_REORDER_E_ARG, "mg_begin: the literal consensus path only exists in the two-kernel round");
   HIPCHK(hipSetDevice(ctx->dev));
-  hipStream_t st = ctx->st;
-  const uint32_t n = ctx->n, Ktot = total_chains, K = Ktot / world;
-  ctx->K = K;
-  DevParams &P = ctx->P;
-  fill_params(ctx, P);
-  const uint64_t nwords = ((uint64_t)n + 63) / 64;
-  const size_t nn = std::max<uint32_t>(n, 1);
-  DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
-  DMALLOC(P.resv, nn * 4);
-  DMALLOC(P.needy, ((size_t)Ktot + 31) / 32 * 4);
-  DMALLOC(P.needy_cnt, ((size_t)Ktot / 2048 + 1) * 4);
-  HIPCHK(hipMemsetAsync(P.needy_cnt, 0, ((size_t)Ktot / 2048 + 1) * 4, st));
-  DMALLOC(P.glob, sizeof(Globals));
-  DMALLOC(P.alive_round, 16);
-  DMALLOC(P.chains, (size_t)K * sizeof(Chain));
-  DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
-  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t));
-  DMALLOC(P.dbg, 4096 * 32 * 8);
-  HIPCHK(hipMemsetAsync(P.dbg, 0, 4096 * 32 * 8, st));
-  if (d_prop) P.prop = (unsigned long long *)d_prop;
-  else DMALLOC(P.prop, (size_t)Ktot * 8);
-  const size_t cap = (size_t)n + (size_t)K * CHUNK;
-  if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
-  ctx->cap = cap;
-  DMALLOC(P.e_order, cap * 4); DMALLOC(P.e_rc, cap); DMALLOC(P.e_flag, cap); DMALLOC(P.e_pos, cap * 8);
-  DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
-  DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
-  P.K = K; P.c0 = rank * K; P.Ktot = Ktot;
-  HIPCHK(hipEventRecord(ctx->ev[4], st));
-  launch_init_taken(st, P.taken, nwords, n);
-  launch_fill_u32(st, P.resv, n, 0xffffffffu);
-  HIPCHK(hipMemsetAsync(P.needy, 0, ((size_t)Ktot + 31) / 32 * 4, st));
-  HIPCHK(hipMemsetAsync(P.chains, 0, (size_t)K * sizeof(Chain), st));
-  Globals g;
-  memset(&g, 0, sizeof(g));
-  g.cursor = (long long)n - 1;
-  g.e_alloc = g.s_alloc = K * CHUNK;
-  HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
-  launch_fill_u32(st, P.e_chain, cap, 0xffffffffu);
-  launch_fill_u32(st, P.s_chain, cap, 0xffffffffu);
-  launch_init_chains(st, P);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
+  const uint32_t K = total_chains / world;
+  int r = setup_chains(ctx, K, rank * K, total_chains, true, d_prop);
+  if (r) return r;
+  HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->mg = true;
   ctx->stats.rounds = 0;
   return 0;
@@ -1058,7 +1072,8 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
 int spring_reorder_mg_search(spring_reorder_ctx *ctx) {
   if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_search: mg_begin first");
   HIPCHK(hipSetDevice(ctx->dev));
-  launch_search(ctx->st, ctx->P, ctx->o.collect_stats != 0);
+  set_round_buffers(ctx);
+  launch_round(ctx->st, ctx->P, ctx->o.collect_stats != 0, true);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->st));  // the caller's exchange reads this rank's slice next
   return 0;
@@ -1078,10 +1093,10 @@ int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32
   if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_apply: mg_begin first");
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
-  launch_mg_post_exchange(st, ctx->P);
-  launch_apply(st, ctx->P, ctx->o.force_literal_update != 0);
+  launch_mg_resolve(st, ctx->P);
   launch_mg_mark(st, ctx->P);
   HIPCHK(hipGetLastError());
+  ctx->round_no++;
   ctx->stats.rounds++;
   if (ctx->stats.rounds % 16 == 0)
     for (int l = 0; l < 2; l++)
@@ -1122,7 +1137,7 @@ int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world
   return 0;
 }
 
-int spring_reorder_rccl_unique_id(void *id128) {
+int spring_mg_rccl_unique_id(void *id128) {
   if (!id128) return fail(SPRING_REORDER_E_ARG, "id buffer is NULL");
   int r = rccl_load();
   if (r) return r;
@@ -1131,66 +1146,80 @@ int spring_reorder_rccl_unique_id(void *id128) {
   return 0;
 }
 
-int spring_reorder_mg_use_rccl(spring_reorder_ctx *ctx, const void *id128, uint32_t rank, uint32_t world) {
-  if (!ctx || !id128 || !world || rank >= world) return fail(SPRING_REORDER_E_ARG, "mg_use_rccl: bad arguments");
+int spring_mg_comm_create_rccl(spring_mg_comm **out, int32_t device, const void *id128, uint32_t rank, uint32_t world) {
+  if (!out || !id128 || !world || rank >= world) return fail(SPRING_REORDER_E_ARG, "comm_create_rccl: bad arguments");
   int r = rccl_load();
   if (r) return r;
-  HIPCHK(hipSetDevice(ctx->dev));
-  rccl_release(ctx);
+  int dev = device;
+  if (dev < 0) HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipSetDevice(dev));
   RcclId128 id;
   memcpy(id.b, id128, sizeof(id.b));
-  const int e = g_rccl.CommInitRank(&ctx->rccl_comm, (int)world, id, (int)rank);
-  if (e) { ctx->rccl_comm = nullptr; return fail(SPRING_REORDER_E_HIP, "ncclCommInitRank: %s", rccl_err(e)); }
-  ctx->host_xchg = nullptr;
+  void *comm = nullptr;
+  const int e = g_rccl.CommInitRank(&comm, (int)world, id, (int)rank);
+  if (e) return fail(SPRING_REORDER_E_HIP, "ncclCommInitRank: %s", rccl_err(e));
+  spring_mg_comm *c = new spring_mg_comm();
+  c->rank = rank; c->world = world; c->dev = dev; c->rccl = comm;
+  *out = c;
   return 0;
 }
 
-int spring_reorder_mg_use_host_exchange(spring_reorder_ctx *ctx, spring_mg_allgather_fn fn, void *user) {
-  if (!ctx || !fn) return fail(SPRING_REORDER_E_ARG, "mg_use_host_exchange: bad arguments");
-  rccl_release(ctx);
-  ctx->host_xchg = fn;
-  ctx->host_xchg_user = user;
+int spring_mg_comm_create_host(spring_mg_comm **out, spring_mg_allgather_fn fn, void *user, uint32_t rank, uint32_t world) {
+  if (!out || !fn || !world || rank >= world) return fail(SPRING_REORDER_E_ARG, "comm_create_host: bad arguments");
+  spring_mg_comm *c = new spring_mg_comm();
+  c->rank = rank; c->world = world; c->dev = -1; c->host_fn = fn; c->host_user = user;
+  *out = c;
   return 0;
 }
 
-// one pool over `world` ranks with the exchange inside the library; see include/spring_reorder.h
-int spring_reorder_mg_run(spring_reorder_ctx *ctx, uint32_t rank, uint32_t world, uint32_t total_chains) {
-  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
-  if (!ctx->rccl_comm && !ctx->host_xchg && world > 1)
-    return fail(SPRING_REORDER_E_STATE, "mg_run: choose a transport first (mg_use_rccl / mg_use_host_exchange)");
-  int r = spring_reorder_mg_begin(ctx, rank, world, total_chains, nullptr);
+void spring_mg_comm_destroy(spring_mg_comm *c) {
+  if (!c) return;
+  if (c->rccl && g_rccl.CommDestroy) {
+    (void)hipSetDevice(c->dev);
+    (void)g_rccl.CommDestroy(c->rccl);
+  }
+  delete c;
+}
+
+// one pool over the communicator's ranks with the exchange inside the library; see include/spring_reorder.h
+int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_t total_chains) {
+  if (!ctx || !comm) return fail(SPRING_REORDER_E_ARG, "mg_run: NULL argument");
+  if (comm->rccl && comm->dev != ctx->dev)
+    return fail(SPRING_REORDER_E_ARG, "mg_run: the communicator lives on device %d, the context on %d", comm->dev, ctx->dev);
+  int r = spring_reorder_mg_begin(ctx, comm->rank, comm->world, total_chains, nullptr);
   if (r) return r;
   hipStream_t st = ctx->st;
   DevParams &P = ctx->P;
-  const bool stats = ctx->o.collect_stats != 0, literal = ctx->o.force_literal_update != 0;
+  const bool stats = ctx->o.collect_stats != 0;
   const int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : 8;
   const size_t slice = (size_t)P.K * 8, total = (size_t)P.Ktot * 8;
   uint32_t *h_alive = nullptr;
   void *h_stage = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
-  if (ctx->host_xchg) HIPCHK(hipHostMalloc(&h_stage, total, hipHostMallocDefault));
+  if (comm->host_fn) HIPCHK(hipHostMalloc(&h_stage, total, hipHostMallocDefault));
   int ret = 0;
   *h_alive = 1;
   while (*h_alive && !ret) {
     for (int i = 0; i < R && !ret; i++) {
-      launch_search(st, P, stats);
-      if (ctx->rccl_comm) {  // in place: this rank's words already sit at their offset of the receive buffer
-        const int e = g_rccl.AllGather(P.prop + P.c0, P.prop, P.K, RCCL_UINT64, ctx->rccl_comm, st);
+      set_round_buffers(ctx);
+      launch_round(st, P, stats, true);
+      if (comm->rccl) {  // in place: this rank's words already sit at their offset of the receive buffer
+        const int e = g_rccl.AllGather(P.prop + P.c0, P.prop, P.K, RCCL_UINT64, comm->rccl, st);
         if (e) ret = fail(SPRING_REORDER_E_HIP, "ncclAllGather: %s", rccl_err(e));
-      } else if (ctx->host_xchg) {
+      } else {
         hipError_t he = hipMemcpyAsync((char *)h_stage + (size_t)P.c0 * 8, P.prop + P.c0, slice, hipMemcpyDeviceToHost, st);
         if (he == hipSuccess) he = hipStreamSynchronize(st);
         if (he != hipSuccess) { ret = fail(SPRING_REORDER_E_HIP, "staging copy failed: %s", hipGetErrorString(he)); break; }
-        if (ctx->host_xchg(h_stage, (size_t)P.c0 * 8, slice, total, ctx->host_xchg_user)) {
+        if (comm->host_fn(h_stage, (size_t)P.c0 * 8, slice, total, comm->host_user)) {
           ret = fail(SPRING_REORDER_E_IO, "mg_run: the caller's all-gather reported an error");
           break;
         }
         he = hipMemcpyAsync(P.prop, h_stage, total, hipMemcpyHostToDevice, st);
         if (he != hipSuccess) { ret = fail(SPRING_REORDER_E_HIP, "staging copy failed: %s", hipGetErrorString(he)); break; }
       }
-      launch_mg_post_exchange(st, P);
-      launch_apply(st, P, literal);
+      launch_mg_resolve(st, P);
       launch_mg_mark(st, P);
+      ctx->round_no++;
       ctx->stats.rounds++;
       if (ctx->stats.rounds % 16 == 0)
         for (int l = 0; l < 2; l++)

@@ -122,41 +122,54 @@ def host_allgather(dist):
     return _lib.MG_ALLGATHER_FN(fn)
 
 
-class DistPool:
-    """One process per GPU, ONE read pool: the whole round loop runs inside the library (spring_reorder_mg_run).
-    transport "rccl": ncclAllGather on the library's stream; the 128-byte communicator id is made by rank 0 and
-    broadcast through `dist` (an initialised torch.distributed module).  transport "host": all-gather on a host
-    staging buffer through `dist` (gloo) -- for ranks that share a GPU."""
+class PoolComm:
+    """spring_mg_comm: the exchange transport of one rank, made once per process and reused by every run.
+    transport "rccl": ncclAllGather on the library's stream; the 128-byte id is made by rank 0 and broadcast through
+    `dist` (an initialised torch.distributed module).  transport "host": all-gather on a host staging buffer
+    through `dist` (gloo) -- for ranks that share a GPU."""
 
-    def __init__(self, dist, device, total_chains, num_thr=1, transport="rccl", **opt_kw):
+    def __init__(self, dist, device, transport="rccl"):
         import torch
-        self.torch, self.dist, self.device = torch, dist, device
+        self.dist, self.device, self.transport = dist, device, transport
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.K, self.T, self.transport = total_chains, num_thr, transport
-        self.stage = _MgStage(ReorderOpts(device=device.index if device.type == "cuda" else -1,
-                                          num_chains=total_chains, num_thr=num_thr, **opt_kw))
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
         self._cb = None
-        L_ = _lib.lib()
         if transport == "rccl":
             idbuf = np.zeros(128, np.uint8)
             if self.rank == 0:
-                _chk(L_.spring_reorder_rccl_unique_id(idbuf.ctypes.data))
-            on_gpu = dist.get_backend() == "nccl"
-            t = torch.from_numpy(idbuf).to(device) if on_gpu else torch.from_numpy(idbuf)
+                _chk(self._L.spring_mg_rccl_unique_id(idbuf.ctypes.data))
+            t = torch.from_numpy(idbuf).to(device) if dist.get_backend() == "nccl" else torch.from_numpy(idbuf)
             dist.broadcast(t, src=0)
-            idbuf = t.cpu().numpy().copy()
-            _chk(L_.spring_reorder_mg_use_rccl(self.stage._h, idbuf.ctypes.data, self.rank, self.world))
+            idbuf = np.ascontiguousarray(t.cpu().numpy())
+            _chk(self._L.spring_mg_comm_create_rccl(C.byref(self._h), device.index, idbuf.ctypes.data, self.rank,
+                                                    self.world))
         elif transport == "host":
-            self._cb = host_allgather(dist)  # keep the trampoline alive as long as the stage
-            _chk(L_.spring_reorder_mg_use_host_exchange(self.stage._h, self._cb, None))
+            self._cb = host_allgather(dist)  # the trampoline must live as long as the communicator
+            _chk(self._L.spring_mg_comm_create_host(C.byref(self._h), self._cb, None, self.rank, self.world))
         else:
             raise ValueError("transport must be 'rccl' or 'host'")
+
+    def close(self):
+        if self._h:
+            self._L.spring_mg_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class DistPool:
+    """One process per GPU, ONE read pool: the whole round loop runs inside the library (spring_reorder_mg_run)."""
+
+    def __init__(self, comm: PoolComm, total_chains, num_thr=1, **opt_kw):
+        self.comm, self.K, self.T = comm, total_chains, num_thr
+        dev = comm.device
+        self.stage = _MgStage(ReorderOpts(device=dev.index if dev.type == "cuda" else -1, num_chains=total_chains,
+                                          num_thr=num_thr, **opt_kw))
 
     def run(self, load):
         s = self.stage
         load(s)
         s.build_dict()
-        _chk(s._L.spring_reorder_mg_run(s._h, self.rank, self.world, self.K))
+        _chk(s._L.spring_reorder_mg_run(s._h, self.comm._h, self.K))
         s.finalize()
         st = s.stats()
         self.rounds = st["rounds"]

@@ -36,6 +36,7 @@ class ReorderOpts:
     search_wpb: int = 0
     dbg_search_lds: int = 0
     dbg_apply_lds: int = 0
+    fused: int = 0            # -1: the two-kernel round
 
     def to_c(self):
         o = _lib.Opts()
@@ -45,6 +46,7 @@ class ReorderOpts:
         o.force_literal_update, o.rounds_per_sync = int(self.force_literal_update), self.rounds_per_sync
         o.first_shifts, o.seed_wide, o.tab_scale = self.first_shifts, self.seed_wide, self.tab_scale
         o.search_wpb, o.dbg_search_lds, o.dbg_apply_lds = self.search_wpb, self.dbg_search_lds, self.dbg_apply_lds
+        o.fused = self.fused
         return o
 
 
@@ -209,6 +211,17 @@ def synth_dna_host(n, L, G, seed, err_ppm=10000) -> bytes:
     buf = np.zeros(max(nb, 1), np.uint8)
     _chk(L_.spring_synth_dna_host(buf.ctypes.data, n, L, G, seed, err_ppm))
     return buf[:nb].tobytes()
+
+
+SYNTH_REPEATS = 0x80000000  # OR into err_ppm (include/spring_reorder.h)
+SYNTH_PAIRED = 0x40000000
+
+
+def synth_genome_host(G, seed, flags=0) -> bytes:
+    L_ = _lib.lib()
+    buf = np.zeros(max(G, 1), np.uint8)
+    _chk(L_.spring_synth_genome_host(buf.ctypes.data, G, seed, flags))
+    return buf[:G].tobytes()
 
 
 class CompressionParams:

@@ -152,6 +152,15 @@ def unpack_dnaN(buf, count=None):
     return out
 
 
+def decode_dna_fixed(dna: bytes, n: int, L: int):
+    """fixed-length .dna record stream (u16 len + 2-bit bases, util.cpp:269-294) -> list of bytes strings."""
+    rec = 2 + (L + 3) // 4
+    a = np.frombuffer(dna, dtype=np.uint8).reshape(n, rec)[:, 2:]
+    codes = np.stack([(a >> s) & 3 for s in (0, 2, 4, 6)], axis=2).reshape(n, -1)[:, :L]
+    letters = np.frombuffer(b"AGCT", dtype=np.uint8)[codes]
+    return [letters[i].tobytes() for i in range(n)]
+
+
 def read_strings(read, ln):
     """2-bit limbs -> list of strings (bitsettostring, reorder.h:76-92)."""
     out = []

@@ -107,6 +107,11 @@ def test_fastq_frontend_errors():
     with spring_amd.ReorderStage() as s:
         with pytest.raises(spring_amd.ReorderError, match="paired files do not match"):
             s.load_fastq(_synth_fastq(6, 10, 50, 50), _synth_fastq(7, 11, 50, 50))
+    # characters outside A C G T N (lower case, IUPAC codes) are undefined in the reference's tables: an error here
+    for bad in (b"ACGTacgt", b"ACGRT", b"AC.GT"):
+        with spring_amd.ReorderStage() as s:
+            with pytest.raises(spring_amd.ReorderError, match="Invalid character"):
+                s.load_fastq(b"@a\nACGT\n+\nIIII\n@b\n" + bad + b"\n+\n" + b"I" * len(bad) + b"\n")
 
 
 # ------------------------------------------------------------------ row f4: reorder-only output

@@ -63,13 +63,15 @@ def test_dictionary_matches_constructdictionary(name):
             assert np.array_equal(gids[:len(ids)], ids)  # same ids, same in-bin order, bins in key order
 
 
+@pytest.mark.parametrize("fused", [0, -1])
 @pytest.mark.parametrize("name", SMALL_SETS)
-def test_k1_bit_exact_vs_serial_oracle(name):
-    """K = 1 must reproduce the reference's `-t 1` order byte for byte."""
+def test_k1_bit_exact_vs_serial_oracle(name, fused):
+    """K = 1 must reproduce the reference's `-t 1` order byte for byte -- with the fused round kernel (default) and
+    with the two-kernel round."""
     dna, n, L = named_set(name)
     read, ln = po.load_dna(dna, n, L)
     want = po.reorder_serial(read, ln, L)
-    got = _gpu(name, 1, collect_stats=True)
+    got = _gpu(name, 1, collect_stats=True, fused=fused)
     _same(got, want, name)
     for k in ("unmatched", "probes", "keyok", "cands", "hits", "iterations"):
         assert got["stats"][k] == want["stats"][k], (name, k, got["stats"][k], want["stats"][k])
@@ -282,3 +284,52 @@ def test_single_pool_1M_4_virtual_ranks():
         vp.close()
     for k in KEYS:
         assert np.array_equal(got[k], single[k]), k
+
+
+@pytest.mark.parametrize("kw", [dict(first_shifts=1), dict(first_shifts=4), dict(first_shifts=16), dict(seed_wide=-1),
+                                dict(tab_scale=1), dict(tab_scale=4), dict(search_wpb=2), dict(search_wpb=4),
+                                dict(dbg_search_lds=20000), dict(dbg_apply_lds=20000, fused=-1), dict(fused=-1),
+                                dict(first_shifts=3, seed_wide=-1, tab_scale=1, search_wpb=4, fused=-1)])
+@pytest.mark.parametrize("name,K,T", [("syn5k_150", 64, 3), ("var2k", 7, 2), ("heavy", 16, 1)])
+def test_tuning_opts_do_not_change_results(name, K, T, kw):
+    """Every tuning / experiment field of spring_reorder_opts at a non-default value: same streams, same per-tid
+    offsets, same reference-equivalent work counters as the rounds oracle (the fields only move work between
+    batches, table sizes and block shapes)."""
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, T)
+    got = _gpu(name, K, T, collect_stats=True, **kw)
+    _same(got, want, (name, kw))
+    assert np.array_equal(got["tid_off"], want["tid_off"])
+    for k in ("probes", "keyok", "cands", "hits", "unmatched"):
+        assert got["stats"][k] == want["stats"][k], (k, kw)
+
+
+def test_paired_pool_through_pe_encode():
+    """BASELINE config 4 at test size (tools/pe_config4.py runs it at 1 M and 50 M pairs): a paired synthetic pool
+    (file-1 reads then their mates, reorder.h:233-242) -> reorder == rounds oracle -> encoder -> pe_encode == the
+    real reference pe_encode.cpp when oracle/_ref/ref_order is present, else the oracle twin; mates end up n/2 apart."""
+    sa = _sa()
+    from spring_amd import order_ops as oo
+    from spring_amd.encoder import EncoderStage
+    npairs, L, K, T = 60_000, 150, 117, 4
+    n = 2 * npairs
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T)) as st:
+        st.load_synth(n, L, n * L // 25, 17, 10000 | sa.SYNTH_PAIRED)
+        got = st.run().streams()
+        dna = st.download_dna()
+        with EncoderStage() as enc:
+            enc.encode(st)
+            es = enc.streams()
+    assert dna == sa.synth_dna_host(n, L, n * L // 25, 17, 10000 | sa.SYNTH_PAIRED)   # device generator == host generator
+    read, ln = po.load_dna(dna, n, L)
+    _same(got, po.reorder_rounds(read, ln, L, K, T), "paired pool")
+    new, _ = oo.pe_encode(es["order"])
+    ref = po.ref_order("pe_encode", es["order"]) if po.ref_order_bin() else po.pe_encode(es["order"])
+    assert np.array_equal(new, ref)
+    order, half = es["order"], npairs
+    pos_of = np.empty(n, np.uint32)
+    pos_of[order] = np.arange(n, dtype=np.uint32)
+    f1 = order < half
+    assert np.array_equal(new[f1], np.arange(half, dtype=np.uint32))
+    assert np.array_equal(new[~f1], new[pos_of[order[~f1] - half]] + half)

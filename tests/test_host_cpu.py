@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     from spring_amd import _lib
     hdr = (open(os.path.join(ROOT, "include", "spring_reorder.h")).read()
            + open(os.path.join(ROOT, "include", "spring_encoder.h")).read())
-    declared = set(re.findall(r"\b(spring_(?:reorder|synth|order|encoder|fastq)_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(spring_(?:reorder|synth|order|encoder|fastq|mg)_\w+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     L = _lib.lib()
     for name in sorted(declared):
@@ -42,6 +42,35 @@ def test_synth_host_deterministic_and_plausible():
     assert np.all(ln == 100)
     r = po.reorder_serial(read, ln, 100)  # 25x coverage, 1 % errors: most reads must cluster
     assert len(r["order"]) > 1500
+
+
+def test_synth_paired_pool_is_mate_pairs():
+    """SPRING_SYNTH_PAIRED (BASELINE config 4): read j and read npairs + j are the two ends of one fragment of
+    ~N(400, 50) bases, on opposite strands -- checked against the generator's own genome, error-free."""
+    import spring_amd
+    from helpers import decode_dna_fixed
+    npairs, L, G, seed = 3000, 100, 60000, 9
+    dna = spring_amd.synth_dna_host(2 * npairs, L, G, seed, 0 | spring_amd.SYNTH_PAIRED)
+    genome = spring_amd.synth_genome_host(G, seed)
+    reads = decode_dna_fixed(dna, 2 * npairs, L)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    frag = []
+    for j in range(npairs):
+        a, b = reads[j], reads[npairs + j]
+        pa, pb = genome.find(a), genome.find(b.translate(comp)[::-1])
+        if pa < 0:  # the fragment lies on the reverse strand: the first read is the reverse complement of its END
+            pa, pb = genome.find(a.translate(comp)[::-1]), genome.find(b)
+            assert pa >= 0 and pb >= 0 and pb <= pa, j
+            frag.append(pa + L - pb)
+        else:
+            assert pb >= pa, j
+            frag.append(pb + L - pa)
+    frag = np.array(frag)
+    assert frag.min() >= L and 390 < frag.mean() < 410 and 40 < frag.std() < 60
+    strands = sum(genome.find(reads[j]) >= 0 for j in range(npairs))
+    assert 0.4 * npairs < strands < 0.6 * npairs
+    with pytest.raises(spring_amd.ReorderError, match="even number"):
+        spring_amd.synth_dna_host(7, L, G, seed, spring_amd.SYNTH_PAIRED)
 
 
 def test_wrong_bitset_size_raises_like_reference():

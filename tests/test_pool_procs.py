@@ -1,0 +1,123 @@
+"""The single-pool multi-GPU data path with REAL processes.
+
+* CPU (gloo, no GPU): the host all-gather callback the library calls once per round (spring_amd.pool.host_allgather)
+  fills every rank's slice of the staging buffer -- two processes, raw buffers, exactly the C callback signature.
+* GPU box (one MI355X): two processes, BOTH on device 0, run one shared read pool through
+  spring_reorder_mg_run with the host-staged exchange over gloo (RCCL cannot put two ranks on one device); the
+  merged per-rank streams must equal the single-GPU run with the same total number of chains, byte for byte,
+  and the rounds oracle.  With --gpus N the only difference is the transport (ncclAllGather on the library's
+  stream instead of the staging copies)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(script, world, extra_env=None, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=timeout)
+        assert p.returncode == 0, o
+        outs.append(o)
+    return outs
+
+
+CB_WORKER = r"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from spring_amd.pool import host_allgather
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+K = 1000                                   # words per rank
+cb = host_allgather(dist)
+ok = True
+for rnd in range(3):                        # the library calls it once per round
+    buf = np.zeros(world * K, np.uint64)
+    buf[rank * K:(rank + 1) * K] = np.arange(K, dtype=np.uint64) + (rank + 1) * 1_000_000 + rnd
+    rc = cb(buf.ctypes.data, rank * K * 8, K * 8, world * K * 8, None)
+    want = np.concatenate([np.arange(K, dtype=np.uint64) + (r + 1) * 1_000_000 + rnd for r in range(world)])
+    ok = ok and rc == 0 and np.array_equal(buf, want)
+print("RESULT " + json.dumps({"rank": rank, "ok": bool(ok)}), flush=True)
+dist.destroy_process_group()
+""" % ROOT
+
+
+def test_host_allgather_callback_two_processes(tmp_path):
+    script = tmp_path / "cb_worker.py"
+    script.write_text(CB_WORKER)
+    outs = _spawn(script, 2, timeout=180)
+    res = [json.loads([x for x in o.splitlines() if x.startswith("RESULT ")][0][7:]) for o in outs]
+    assert sorted(r["rank"] for r in res) == [0, 1] and all(r["ok"] for r in res)
+
+
+POOL_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from spring_amd.pool import DistPool, PoolComm
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, L, K, T, out = [int(os.environ[k]) for k in ("P_N", "P_L", "P_K", "P_T")] + [os.environ["P_OUT"]]
+comm = PoolComm(dist, torch.device("cuda", 0), transport="host")
+dp = DistPool(comm, K, num_thr=T, collect_stats=True)
+st = dp.run(lambda s: s.load_synth(n, L, n * L // 25, 3, 10000))
+s = dp.streams()
+np.savez(os.path.join(out, "rank%%d.npz" %% rank), **{k: s[k] for k in ("order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s")})
+print("RESULT " + json.dumps({"rank": rank, "rounds": int(st["rounds"]), "probes": int(st["probes"]), "hits": int(st["hits"])}), flush=True)
+dp.close()
+comm.close()
+dist.destroy_process_group()
+""" % ROOT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,L,K,T", [(200_000, 100, 64, 3), (300_000, 150, 500, 1)])
+def test_one_pool_two_processes_one_gpu(tmp_path, n, L, K, T):
+    import spring_amd
+    from oracle import pyoracle as po
+    from spring_amd.pool import merge_rank_streams
+    script = tmp_path / "pool_worker.py"
+    script.write_text(POOL_WORKER)
+    outs = _spawn(script, 2, extra_env=dict(P_N=str(n), P_L=str(L), P_K=str(K), P_T=str(T), P_OUT=str(tmp_path)))
+    res = sorted((json.loads([x for x in o.splitlines() if x.startswith("RESULT ")][0][7:]) for o in outs),
+                 key=lambda d: d["rank"])
+    assert res[0]["rounds"] == res[1]["rounds"] > 0
+    per_rank = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    got = merge_rank_streams(per_rank, T)
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=K, num_thr=T, collect_stats=True)) as s:
+        s.load_synth(n, L, n * L // 25, 3, 10000)
+        want = s.run().streams()
+        dna = s.download_dna()
+    for k in ("order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s"):
+        assert np.array_equal(got[k], want[k]), k
+    assert res[0]["probes"] + res[1]["probes"] == want["stats"]["probes"]
+    assert res[0]["hits"] + res[1]["hits"] == want["stats"]["hits"]
+    read, ln = po.load_dna(dna, n, L)
+    orc = po.reorder_rounds(read, ln, L, K, T)
+    for k in ("order", "rc", "flag", "pos", "rlen", "order_s"):
+        assert np.array_equal(got[k], orc[k]), ("oracle", k)

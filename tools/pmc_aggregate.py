@@ -14,7 +14,18 @@ csv.field_size_limit(1 << 30)
 
 def short(name):
     n = name.split("(")[0].replace("void ", "")
-    return n.replace("sr::k_search<false, false>", "sr::k_search<false>")
+    if n.startswith("sr::k_search<"):
+        return "sr::k_search"   # the production instantiation is the only one scale_probe launches
+    return n
+
+
+def kernels_sha():
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("reorder_kernels.hip", "reorder_device.h"):
+        h.update(open(os.path.join(root, "spring_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 kern = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -31,7 +42,7 @@ for p in ("fetch", "write", "sq", "tcc", "grbm"):
             launches[k].add(r["Dispatch_Id"])
     for r in csv.DictReader(open(os.path.join(d, "pmc_kernel_trace.csv"))):
         dur[short(r["Kernel_Name"])][p] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-res = {"reads": reads, "read_len": 150, "chains": 65536,
+res = {"reads": reads, "read_len": 150, "chains": 65536, "kernels_sha": kernels_sha(),
        "source": "tools/pmc_probe.sh (5 separate rocprofv3 --pmc passes) aggregated by tools/pmc_aggregate.py", "kernels": {}}
 for k, c in kern.items():
     if not ("k_search" in k or "k_apply" in k):

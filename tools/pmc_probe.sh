@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 run() { # name, counters...
   name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -o pmc -- \
-     python tools/scale_probe.py $n,150,65536 > $out/$name.log 2>&1
+     python tools/scale_probe.py $n,150,0 > $out/$name.log 2>&1
   ls $out/$name | head -5
 }
 mkdir -p $out
