@@ -333,3 +333,24 @@ def test_paired_pool_through_pe_encode():
     f1 = order < half
     assert np.array_equal(new[f1], np.arange(half, dtype=np.uint32))
     assert np.array_equal(new[~f1], new[pos_of[order[~f1] - half]] + half)
+
+
+@pytest.mark.slow
+def test_parity_10M_reads():
+    """10 M x 150 bp (auto chains, 8 output sets): every reorder stream, the per-tid offsets and the reference-
+    equivalent work counters against the rounds oracle.  The oracle side takes about two minutes of one CPU core;
+    tools/parity_10M.py runs the same check (plus the encoder stage) at any size -- 50 M: profiles/r02_parity_50M.txt."""
+    sa = _sa()
+    n, L, T = 10_000_000, 150, 8
+    K = max(1, min(65536, n >> 10))
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, collect_stats=True)) as st:
+        st.load_synth(n, L, n * L // 25, 3, 10000)
+        got = st.run().streams()
+        dna = st.download_dna()
+    read, ln = po.load_dna(dna, n, L)
+    del dna
+    want = po.reorder_rounds(read, ln, L, K, T)
+    _same(got, want, "10M")
+    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+    for k in ("probes", "keyok", "cands", "hits", "unmatched", "iterations", "lost"):
+        assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])

@@ -28,19 +28,31 @@ def _free_port():
 
 
 def _spawn(script, world, extra_env=None, timeout=600):
-    port = _free_port()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), **(extra_env or {}))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
-    outs = []
-    for p in procs:
-        o, _ = p.communicate(timeout=timeout)
-        assert p.returncode == 0, o
-        outs.append(o)
-    return outs
+    last = ""
+    for attempt in range(3):  # a rendezvous can fail when the probed port is grabbed in between: new port, once more
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), **(extra_env or {}))
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True))
+        outs, ok = [], True
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, _ = p.communicate()
+                ok = False
+            ok = ok and p.returncode == 0
+            outs.append(o)
+        if ok:
+            return outs
+        last = "\n".join(outs)
+        if "RESULT" in last and "AssertionError" in last:
+            break  # a real failure, not a rendezvous problem
+    raise AssertionError(last)
 
 
 CB_WORKER = r"""
