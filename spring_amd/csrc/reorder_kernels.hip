@@ -755,7 +755,6 @@ __device__ __forceinline__ bool probe_valid(const DevParams &P, int l, int rev, 
 struct BatchOut {
   uint32_t found, rid;
   int code;          // probe_code of the winner
-  uint64_t pm;       // lanes whose bucket fetch did not prove the key absent from the OTHER dictionary
   uint64_t st_p, st_k, st_c;
 };
 
@@ -764,7 +763,7 @@ struct BatchOut {
 // STATS counts what the reference would have executed: every valid probe up to and including the winner.
 template <bool STATS>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
-                                            int sh_base, int nsh, int lane, int ref_len, BatchOut &out) {
+                                            int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
@@ -783,7 +782,8 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   out.found = hm != 0;
   out.code = probe_code(sh_base + (win >> 2), (win >> 1) & 1, win & 1);
   out.rid = (uint32_t)__shfl((int)rid, win, 64);
-  out.pm = __ballot(other);
+  // what this fetch told about the OTHER dictionary's probe of the same window, for the tail (probe_tail)
+  if ((lane >> 2) < nsh && shift < 32) pres[4 * shift + (lane & 3)] = other ? 1 : 0;
   out.st_p = out.st_k = out.st_c = 0;
   if (STATS) {
     const uint64_t le = win == 63 ? ~0ull : ((1ull << (win + 1)) - 1);
@@ -798,22 +798,19 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
 // 1 at shift off - start1 = (off - start0) - wl; a reverse window of dictionary 0 at start0 - off and of
 // dictionary 1 at start1 - off.  Windows already fetched by the ordered batches (as the dict-1 probe of a
 // forward shift < t0, or the dict-0 probe of a reverse shift < t0) are skipped unless that fetch saw a slot
-// of the other dictionary (pm0 / pm1).  The needed windows are compacted into `list` (LDS) so that a
+// of the other dictionary (`pres`, one byte per ordered probe).  The needed windows are compacted into `list` (LDS) so that a
 // failing search of a 150-base consensus costs 32 + 64 + 55 fetches in three dependent steps (was 237 in
 // six).  Lanes no longer run in priority order: the winner is the hit with the lowest probe_code.
 constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
 template <bool STATS>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
-                                           uint16_t *list, uint16_t *stat, int t0, int fs, uint64_t pm0,
-                                           uint64_t pm1, int lane, int ref_len, BatchOut &out) {
+                                           uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
+                                           int ref_len, BatchOut &out) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
-  // did the ordered batches' fetch for shift sp (lane slot x: 1 = forward dict 1, 2 = reverse dict 0) leave
-  // the other dictionary's presence open?
-  auto present = [&](int sp, int x) -> bool {
-    const uint64_t m = sp < fs ? pm0 : pm1;
-    return (m >> (4 * (sp < fs ? sp : sp - fs) + x)) & 1ull;
-  };
+  // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
+  // dictionary's presence open?  (t0 <= 32: probe_batch recorded every shift below t0)
+  auto present = [&](int sp, int x) -> bool { return pres[4 * sp + x] != 0; };
   const int nF = wl + ms - t0;
   int T = 0;
   for (int base = 0; base < 2 * nF; base += 64) {
@@ -883,7 +880,6 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
   out.code = wmin;
   const uint64_t wm = __ballot(best == wmin);
   out.rid = (uint32_t)__shfl((int)brid, __ffsll((unsigned long long)wm) - 1, 64);
-  out.pm = 0;
   out.st_p = out.st_k = out.st_c = 0;
   if (STATS) {  // what the reference would have executed: every valid probe of the tail up to the winner
     int cp = 0, ck = 0, cc = 0;
@@ -919,7 +915,8 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 // `h` is the chain's header as it stands (all lanes hold the same copy); ref / revref are already in s_refs.
 template <bool STATS, bool WORD, bool DIRECT>
 __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
-                                            uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat) {
+                                            uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat,
+                                            uint8_t *s_pres /* [128] */) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
     const long long seed = find_seed(P, cid, lane, &is_last);
@@ -970,22 +967,25 @@ __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32
   }
   const uint64_t *sref = s_refs + LDS_PAD, *srev = s_refs + LDS_LIMBS + LDS_PAD;
   wave_sync();
-  // most chains match within the first few shifts: the first batch covers only fs of them (every lane past the
-  // winner is a wasted 64-byte request).  A fresh seed (nothing matched to it yet) fails about every second
-  // search: it gets a full first batch.
-  const int fs = (h.prev_unmatched && P.seed_wide) ? 16 : P.first_shifts;
+  // The ordered batches of a search, narrow first: most chains match within the first few shifts and every lane
+  // past the winner is a wasted 64-byte request; every further batch is a further dependent round trip (8 + 16 is
+  // the measured optimum).  A fresh seed (nothing matched to it yet) fails nine searches out of
+  // ten and needs every window anyway: it gets the wide plan.  P.plan[which] = batch widths in shifts (each <= 16, sum <= 32), 0-terminated.
+  const int *plan = P.plan[(h.prev_unmatched && P.seed_wide) ? 1 : 0];
   BatchOut o;
+  o.found = 0;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
-  uint64_t pm0 = 0, pm1 = 0;
+  int t0 = 0;
 #pragma nounroll
-  for (int ph = 0; ph < 2; ph++) {  // the two ordered batches: shifts [0, fs) and [fs, fs + 16)
-    probe_batch<STATS>(P, sref, srev, ph ? fs : 0, ph ? 16 : fs, lane, ref_len, o);
+  for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
+    probe_batch<STATS>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
-    if (ph) pm1 = o.pm; else pm0 = o.pm;
-    if (o.found || fs >= P.maxshift) break;
+    t0 += plan[ph];
+    if (o.found) break;
   }
-  if (!o.found && fs + 16 < P.maxshift) {
-    probe_tail<STATS>(P, sref, srev, s_list, s_stat, fs + 16, fs, pm0, pm1, lane, ref_len, o);
+  if (!o.found && t0 < P.maxshift) {
+    wave_sync();  // s_pres
+    probe_tail<STATS>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
   }
   if (lane == 0) {
@@ -1016,6 +1016,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   __shared__ uint64_t s_refs[WPB][2][LDS_LIMBS];
   __shared__ uint16_t s_list[WPB][TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
+  __shared__ uint8_t s_pres[WPB][128];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t li = blockIdx.x * WPB + wave;
   if (li >= P.K) return;
@@ -1031,7 +1032,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
   }
   if (h.done) return;
-  search_step<STATS, false, true>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0]);
+  search_step<STATS, false, true>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave]);
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1204,6 +1205,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
   __shared__ uint16_t s_list[TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? 2 * TAIL_CAP : 2];
+  __shared__ uint8_t s_pres[128];
   __shared__ WaveLds lds;
   const int lane = threadIdx.x;
   const uint32_t li = blockIdx.x;
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
-  search_step<STATS, true, !MG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat);
+  search_step<STATS, true, !MG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres);
 }
 
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange

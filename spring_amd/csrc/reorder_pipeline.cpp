@@ -884,7 +884,10 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = ctx->n;
   P.L = ctx->L; P.W = ctx->W; P.S = ctx->S; P.Lpad = ctx->Lpad;
   P.maxshift = ctx->L / 2;  // reorder.h:750
-  P.first_shifts = o.first_shifts > 0 ? std::min(16, o.first_shifts) : 8;
+  memset(P.plan, 0, sizeof(P.plan));
+  if (o.first_shifts < 0) { P.plan[0][0] = 4; P.plan[0][1] = 4; P.plan[0][2] = 8; P.plan[0][3] = 8; }  // progressive (experiment)
+  else { P.plan[0][0] = o.first_shifts > 0 ? std::min(16, o.first_shifts) : 8; P.plan[0][1] = 16; }   // one narrow batch, one wide
+  P.plan[1][0] = 16; P.plan[1][1] = 16;
   P.seed_wide = o.seed_wide < 0 ? 0 : 1;
   P.search_wpb = (o.search_wpb == 1 || o.search_wpb == 2 || o.search_wpb == 4) ? o.search_wpb : 1;  // 1: a block is a chain; its slot frees when that chain is done
   P.dbg_search_lds = std::max(0, o.dbg_search_lds);
