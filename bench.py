@@ -59,6 +59,13 @@ def algorithmic_bytes_search(st, W):
     return st["probes"] * 16 + st["keyok"] * (4 + B) + st["cands"] * (7 + B)
 
 
+def algorithmic_bytes_apply(st):
+    """SURVEY.md 8(d), the two remaining chain-phase terms: R*(8+4) [two bin removals per claimed read] +
+    E*16 [order, RC, flag, pos, len of every emitted read]."""
+    n = st["n_reads"]
+    return 2 * n * 12 + n * 16
+
+
 def kernels_sha():
     """Identity of the kernels a PMC summary belongs to (profiles/pmc_latest.json carries the same stamp)."""
     import hashlib
@@ -180,13 +187,16 @@ def main():
     }
 
     if rank == 0 and world == 1 and not a.no_roofline:
-        # two extra passes: (1) the production search kernel with a HIP-event pair around every launch
-        # (on the library's stream), (2) the counting variant for the reference-equivalent work counters
-        # (it is ~20 % slower, so it is not the one that is timed)
+        # three extra passes: (1) the production round kernel (k_round = apply of the last proposals + search, 85 % of
+        # the GPU time) with a HIP-event pair around every launch, on the library's stream; (2) the counting variant
+        # for the reference-equivalent work counters (slower, so it is not the one that is timed); (3) the two-kernel
+        # round (opts.fused = -1), where the Hamming search is a kernel of its own, for the search-only figure
         st_t = one_pass(time_search=True)
         sr = one_pass(collect_stats=True)
+        st_2k = one_pass(time_search=True, fused=-1)
         W = (2 * L - 1) // 64 + 1
-        alg = algorithmic_bytes_search(sr, W)
+        alg_search = algorithmic_bytes_search(sr, W)
+        alg = alg_search + algorithmic_bytes_apply(sr)
         ms = st_t["ms_search_kernel"]
         launches = max(st_t["search_launches"], 1)
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -199,7 +209,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             # only a summary taken from THESE kernels counts (the stamp is the hash of the kernel sources)
             if pmc.get("reads") == n and pmc.get("read_len") == L and pmc.get("kernels_sha") == kernels_sha():
-                ks = pmc["kernels"]["sr::k_search"]
+                ks = pmc["kernels"]["sr::k_round"]
                 traffic = round(ks["fetch_bytes_per_launch"] + ks["write_bytes_per_launch"], 1)
         except Exception:
             traffic = None
@@ -208,7 +218,7 @@ def main():
         # (tools/random_gather_bench.hip, profiles/r01_pmc_calibration_random_gather.csv), not 8 TB/s / 64 B
         req = None
         try:
-            fetch = pmc["kernels"]["sr::k_search"]["fetch_bytes_per_launch"] if traffic is not None else None
+            fetch = pmc["kernels"]["sr::k_round"]["fetch_bytes_per_launch"] if traffic is not None else None
             if fetch:
                 rate = fetch / 64.0 / (ms * 1e-3 / launches) / 1e9
                 req = {"achieved": round(rate, 2), "peak": RANDOM_REQ_PEAK_G, "unit": "G random 64-byte requests/s",
@@ -218,12 +228,23 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_kernels_sha": kernels_sha(),
-            "kernel": "sr::k_search", "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+            "kernel": "sr::k_round (one chain per wavefront: apply of the last proposal + Hamming search)",
+            "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
             "algorithmic_bytes_per_launch": round(alg / launches, 1),
             "algorithmic_bytes_per_read": round(alg / n, 1),
+            "algorithmic_bytes_model": "SURVEY 8(d): P*16 + Kv*(4+B) + C*(7+B) [search] + R*12 + E*16 [claims, emission]; "
+                                       "the chain state the kernel also moves (counts, consensus) is not counted",
             "work": {"probes": sr["probes"], "keyok": sr["keyok"], "cands": sr["cands"], "hits": sr["hits"]},
             "random_request_ceiling": req,
         }
+        ms2, l2 = st_2k["ms_search_kernel"], max(st_2k["search_launches"], 1)
+        if ms2 > 0:
+            a2 = alg_search / (ms2 * 1e-3) / 1e9
+            out["roofline"]["search_kernel_alone"] = {
+                "kernel": "sr::k_search (two-kernel round, opts.fused = -1: the same search as its own launch)",
+                "avg_launch_us": round(ms2 * 1e3 / l2, 2), "achieved": round(a2, 2), "frac": round(a2 / HBM_PEAK_GBS, 5),
+                "algorithmic_bytes_per_launch": round(alg_search / l2, 1),
+                "stage_ms_chains_two_kernel_round": round(st_2k["ms_chains"], 2)}
     if rank == 0 and world == 1 and not a.no_roofline:
         # row f2: the encoder stage chained on the same workload, streams never leave HBM.
         # Reported beside the headline, never part of `value`.

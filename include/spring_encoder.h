@@ -102,8 +102,9 @@ int spring_reorder_encode_run(const char *temp_dir, uint32_t max_readlen, int32_
                               uint32_t num_reads_clean_1, uint32_t num_reads_clean_2, uint32_t num_reads,
                               const spring_reorder_opts *opts, spring_encoder_info *info);
 
-/* File contract of the encoder stage alone: drop-in for spring::call_encoder(temp_dir, cp)
- * (call_template_functions.cpp:65-142).  Reads the per-tid files a reorder stage left in temp_dir (the
+/* File contract of the encoder stage alone: spring::call_encoder(temp_dir, cp) (call_template_functions.cpp:65-142)
+ * up to, not including, the BSC_compress calls of pack_compress_seq (encoder.cpp:146-150): read_seq.bin.<tid> is
+ * left as .tmp + .tail and the caller compresses it.  Reads the per-tid files a reorder stage left in temp_dir (the
  * reference's reorder_main or spring_reorder_run; gzip members are read through zlib), the singleton files,
  * input_N.dna and read_order_N.bin; writes the same outputs as spring_reorder_encode_run and removes its
  * inputs.  num_reads = cp.num_reads, num_reads_clean = cp.num_reads_clean[0] + cp.num_reads_clean[1]. */

@@ -28,7 +28,9 @@ void call_reorder(const std::string &temp_dir, const reorder_params &cp,
 // Mirror of void spring::call_encoder(const std::string &temp_dir, compression_params &cp)
 // (reference src/call_template_functions.h:11, .cpp:65-142): consumes the files call_reorder left in temp_dir;
 // num_reads = cp.num_reads (clean + N reads).  Throws std::runtime_error ("Wrong bitset size." when
-// 3 * max_readlen does not fit 1536 bits).  read_seq.bin.<tid> is left as .tmp + .tail for the caller's BSC step.
+// 3 * max_readlen does not fit 1536 bits).  NOT a complete drop-in: it stops before pack_compress_seq's BSC step
+// (encoder.cpp:146-150) -- read_seq.bin.<tid> is left as .tmp + .tail, the caller runs BSC_compress(.tmp -> .bsc)
+// and removes the .tmp (INTEGRATION.md section 4 shows the loop).
 void call_encoder(const std::string &temp_dir, const reorder_params &cp, uint32_t num_reads, int device = -1);
 
 // Both stages back to back with the intermediate streams kept in HBM (spring.cpp:150-160).

@@ -83,13 +83,12 @@ struct DevParams {
   // rounds whose shared state is kept by k_mg_mark (fused rounds, multi-GPU pools; null in the two-kernel round):
   uint32_t *needy_cnt;       // set bits per 64 words of needy (2048 chains) as k_mg_mark of the LAST round left them
   uint32_t *needy_cnt_next;  // the buffer k_mg_mark of THIS round fills (zeroed by the previous k_mg_mark)
-  uint32_t *alive_next;      // the other alive counter: zeroed by this round's k_mg_mark for the next one
   int fused;                 // 1: k_round (apply + search in one kernel)
   Globals *glob;
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;
   unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
-  uint32_t *alive_round;      // [1] chains not done, recounted from prop every round by k_mg_mark
+  uint32_t *alive_wave;       // [ceil(Ktot / 64)] chains not done per 64 chains, rewritten every round by k_mg_mark
   Chain *chains;
   int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong: wide format (some count > 255)
   uint32_t *cnt8;     // same, one byte per count: the format of almost every update (4x fewer bytes moved)

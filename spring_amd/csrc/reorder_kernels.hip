@@ -1272,11 +1272,11 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
     P.needy[w0] = (uint32_t)nb;
     if ((cid & ~63u) + 32 < ((P.Ktot + 31) & ~31u)) P.needy[w0 + 1] = (uint32_t)(nb >> 32);
     if (nb) atomicAdd(&P.needy_cnt_next[cid >> 11], (uint32_t)__popcll(nb));
-    if (na) atomicAdd(P.alive_round, na);
+    P.alive_wave[cid >> 6] = na;  // summed by the host when it checks for the end (a same-address atomic per wavefront
+                                  // was most of this kernel's time)
   }
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
-  if (cid == 0) *P.alive_next = 0;
 }
 
 // ------------------------------------------------------------ K7 finalize / emit

@@ -137,7 +137,6 @@ struct spring_reorder_ctx {
   uint64_t nrec = 0, nsing = 0, cap = 0;
   bool mg = false;
   uint32_t *cnt_buf[2] = {nullptr, nullptr};  // needy_cnt double buffer (reorder_device.h)
-  uint32_t *alive_buf = nullptr;              // [2] running-chain counters
   uint64_t round_no = 0;
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
@@ -934,18 +933,17 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
   P.K = K; P.c0 = c0; P.Ktot = Ktot;
   P.fused = fused ? 1 : 0;
-  P.prop = nullptr; P.alive_round = P.alive_next = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
+  P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
   ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
-  ctx->alive_buf = nullptr;
   if (fused) {  // the rounds whose shared state k_mg_mark keeps: proposal words + double-buffered counters
     const size_t nblk = (size_t)Ktot / 2048 + 1;
     if (d_prop) P.prop = (unsigned long long *)d_prop;
     else DMALLOC(P.prop, (size_t)Ktot * 8);
     DMALLOC(ctx->cnt_buf[0], 2 * nblk * 4);
     ctx->cnt_buf[1] = ctx->cnt_buf[0] + nblk;
-    DMALLOC(ctx->alive_buf, 16);
+    DMALLOC(P.alive_wave, ((size_t)Ktot + 63) / 64 * 4);
     HIPCHK(hipMemsetAsync(ctx->cnt_buf[0], 0, 2 * nblk * 4, st));
-    HIPCHK(hipMemsetAsync(ctx->alive_buf, 0, 16, st));
+    HIPCHK(hipMemsetAsync(P.alive_wave, 0, ((size_t)Ktot + 63) / 64 * 4, st));
     P.needy_cnt = ctx->cnt_buf[1];  // what the first round reads: nobody needs a seed yet
   }
   HIPCHK(hipEventRecord(ctx->ev[4], st));
@@ -974,8 +972,19 @@ static void set_round_buffers(spring_reorder_ctx *ctx) {
   const int w = (int)(ctx->round_no & 1);
   P.needy_cnt = ctx->cnt_buf[w ^ 1];
   P.needy_cnt_next = ctx->cnt_buf[w];
-  P.alive_round = ctx->alive_buf + w;
-  P.alive_next = ctx->alive_buf + (w ^ 1);
+
+}
+
+// chains still running after the last k_mg_mark: per-wavefront counts summed here (the stream is synchronised)
+static int running_chains(spring_reorder_ctx *ctx, std::vector<uint32_t> &buf, uint32_t *alive) {
+  const size_t nw = ((size_t)ctx->P.Ktot + 63) / 64;
+  buf.resize(nw);
+  HIPCHK(hipMemcpyAsync(buf.data(), ctx->P.alive_wave, nw * 4, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  uint64_t a = 0;
+  for (uint32_t v : buf) a += v;
+  *alive = (uint32_t)std::min<uint64_t>(a, 0xffffffffull);
+  return 0;
 }
 
 int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
@@ -1000,6 +1009,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
     for (auto &e : tev) HIPCHK(hipEventCreate(&e));
   }
   uint32_t *h_alive = nullptr;
+  std::vector<uint32_t> alive_tmp;
   HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
   uint64_t rounds = 0;
   double ms_search = 0;
@@ -1025,8 +1035,13 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
     for (int l = 0; l < 2; l++)  // shrink deep bins whose tail has been consumed (exact; see k_trim_bins)
       launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
     // chains still running: the two-kernel round keeps the count, the fused round recounts it every round
-    HIPCHK(hipMemcpyAsync(h_alive, fused ? P.alive_round : &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (fused) {
+      int ra = running_chains(ctx, alive_tmp, h_alive);
+      if (ra) return ra;
+    } else {
+      HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
     HIPCHK(hipGetLastError());
     if (timed) {
       for (int r = 0; r < R; r++) {
@@ -1106,8 +1121,9 @@ int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32
       launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, ctx->P.taken);
   if (check_alive) {
     uint32_t a = 0;
-    HIPCHK(hipMemcpyAsync(&a, ctx->P.alive_round, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> tmp;
+    int ra = running_chains(ctx, tmp, &a);
+    if (ra) return ra;
     if (alive) *alive = a;
   }
   return 0;
@@ -1197,6 +1213,7 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
   const int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : 8;
   const size_t slice = (size_t)P.K * 8, total = (size_t)P.Ktot * 8;
   uint32_t *h_alive = nullptr;
+  std::vector<uint32_t> alive_tmp;
   void *h_stage = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
   if (comm->host_fn) HIPCHK(hipHostMalloc(&h_stage, total, hipHostMallocDefault));
@@ -1230,10 +1247,11 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
     }
     if (ret) break;
     // every rank recounted the running chains from the same gathered words: the same decision everywhere
-    hipError_t he = hipMemcpyAsync(h_alive, P.alive_round, 4, hipMemcpyDeviceToHost, st);
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
-    if (he == hipSuccess) he = hipGetLastError();
-    if (he != hipSuccess) ret = fail(SPRING_REORDER_E_HIP, "mg_run: %s", hipGetErrorString(he));
+    ret = running_chains(ctx, alive_tmp, h_alive);
+    if (!ret) {
+      hipError_t he = hipGetLastError();
+      if (he != hipSuccess) ret = fail(SPRING_REORDER_E_HIP, "mg_run: %s", hipGetErrorString(he));
+    }
   }
   (void)hipHostFree(h_alive);
   if (h_stage) (void)hipHostFree(h_stage);

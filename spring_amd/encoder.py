@@ -88,8 +88,10 @@ class EncoderStage:
 
 
 def call_encoder(temp_dir: str, cp, num_reads: int, device: int = -1):
-    """spring::call_encoder(temp_dir, cp) (reference call_template_functions.cpp:65-142): consumes the files a
-    reorder stage left in temp_dir, writes encoder_main's outputs.  cp is a reorder.CompressionParams,
+    """spring::call_encoder(temp_dir, cp) (reference call_template_functions.cpp:65-142) MINUS its BSC step:
+    consumes the files a reorder stage left in temp_dir and writes encoder_main's outputs, but the packed consensus
+    stays as read_seq.bin.<tid>.tmp (+ .tail): the caller runs BSC_compress(.tmp -> .bsc) and removes the .tmp, as
+    pack_compress_seq does (encoder.cpp:146-150).  cp is a reorder.CompressionParams,
     num_reads = cp.num_reads of the reference (clean + N reads).  -> info dict."""
     bitset_size = (3 * cp.max_readlen - 1) // 64 * 64 + 64
     if cp.max_readlen <= 0 or bitset_size > 1536:

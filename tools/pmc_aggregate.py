@@ -14,8 +14,8 @@ csv.field_size_limit(1 << 30)
 
 def short(name):
     n = name.split("(")[0].replace("void ", "")
-    if n.startswith("sr::k_search<"):
-        return "sr::k_search"   # the production instantiation is the only one scale_probe launches
+    if n.startswith("sr::k_round<"):
+        return "sr::k_round"   # the production instantiation is the only one scale_probe launches
     return n
 
 
@@ -45,7 +45,7 @@ for p in ("fetch", "write", "sq", "tcc", "grbm"):
 res = {"reads": reads, "read_len": 150, "chains": 65536, "kernels_sha": kernels_sha(),
        "source": "tools/pmc_probe.sh (5 separate rocprofv3 --pmc passes) aggregated by tools/pmc_aggregate.py", "kernels": {}}
 for k, c in kern.items():
-    if not ("k_search" in k or "k_apply" in k):
+    if not ("k_round" in k or "k_mg_mark" in k or "k_search" in k or "k_apply" in k):
         continue
     n = max(len(launches[k]), 1)
     e = dict(launches=n, total_us_by_pass={p: round(v, 1) for p, v in dur[k].items()})
