@@ -48,7 +48,7 @@ typedef struct {
   int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per search block  */
   int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
   int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (k_round: apply + search) + mark  */
-  int32_t reserved2;
+  int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
 } spring_reorder_opts;
 
 typedef struct {

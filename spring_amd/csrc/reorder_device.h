@@ -66,6 +66,7 @@ struct DevParams {
   int plan[2][6];     // ordered probe batches of a search: widths in shifts (<= 16 each, sum <= 32), 0-terminated;
                       // [0] a chain in its stride, [1] a chain whose seed has no match yet; the tail covers the rest
   int seed_wide;      // 1: plan[1] is in use
+  int deep_bins;      // 1: the dictionary has deep bins -> the kernel variants that trim dead bin tails while they scan
   int search_wpb;     // chains (wavefronts) per block of k_search: 1, 2 or 4
   int dbg_search_lds, dbg_apply_lds;   // occupancy experiments: dummy dynamic LDS bytes per block
   int wl;             // length of both dictionary windows in bases (dend - dstart + 1)

@@ -681,6 +681,7 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
 // ---- one probe of search_match (reorder.h:262-316): dictionary l, direction rev, at `shift`.  The window's
 // key and hash come from the caller because one consensus window is the probe key of both dictionaries
 // (at shifts wl apart).  sx = ref (forward) or revref (reverse) in LDS.
+template <bool TRIM>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
                                            bool &keyok, uint32_t &ncand, bool &other) {
@@ -729,10 +730,11 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       start = (uint32_t)rec.y; count = (uint32_t)(rec.y >> 32);
     }
     bool verified = !single;
-    int live = 0;
+    int live = 0, top_live = -1;
     for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
       const uint32_t r = single ? pay : ids[start + j];
       if (is_taken(P.taken, r)) continue;
+      if (TRIM && top_live < 0) top_live = j;
       const int wt = within_thresh(r, single);
       if (wt < 0) break;  // fingerprint collision (single-read bin)
       verified = true;
@@ -740,6 +742,14 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       if (wt) { hit = true; rid = r; break; }
     }
     if (!verified) continue;  // taken or colliding single-read slot: the key's own bin may sit in a later slot
+    // Chains consume a bin from its tail, and a taken read stays taken: the entries above the first live one are
+    // dead for good, so the bin's count shrinks to it (exact; the reference gets the same from
+    // bbhashdict::remove, bitset_util.cpp:37-63).  Later scans of a deep bin then start at its live tail
+    // instead of walking the dead one entry by entry.  TRIM variants of the kernels only: they are launched when the
+    // dictionary has deep bins (pools of a few hundred x coverage and more: +23 % at 1600x); on shallow data the extra
+    // state in the hot loop costs 5 %.
+    if (TRIM && !single && (uint32_t)(top_live + 1) < count)
+      atomicMin(reinterpret_cast<uint32_t *>(const_cast<ulonglong2 *>(&urec[pay])) + 3, (uint32_t)(top_live + 1));
     break;
   }
 }
@@ -761,7 +771,7 @@ struct BatchOut {
 // ---- shifts [sh_base, sh_base + nsh), nsh <= 16, in lane order: lane = 4*(shift - sh_base) + 2*rev + dict,
 // so lane order == priority order and the first set bit of the hit ballot is the reference's winner.
 // STATS counts what the reference would have executed: every valid probe up to and including the winner.
-template <bool STATS>
+template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                             int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
@@ -775,7 +785,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   if (valid) {
     const int ds = P.dstart[l];
     const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
-    eval_probe(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other);
+    eval_probe<TRIM>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other);
   }
   const uint64_t hm = __ballot(hit);
   const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
@@ -802,7 +812,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
 // failing search of a 150-base consensus costs 32 + 64 + 55 fetches in three dependent steps (was 237 in
 // six).  Lanes no longer run in priority order: the winner is the hit with the lowest probe_code.
 constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
-template <bool STATS>
+template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
                                            int ref_len, BatchOut &out) {
@@ -863,7 +873,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         const int sh = l ? sh1 : sh0;
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
-        eval_probe(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other);
+        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
         if (hit) {
           const int code = probe_code(sh, rev, l);
@@ -913,7 +923,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 // WORD: publish the proposal as a word of P.prop (multi-GPU pools: resolved after the all-gather; fused rounds:
 // read by k_mg_mark).  DIRECT: reserve the read at once (atomicMin on resv[]), everything is on this GPU.
 // `h` is the chain's header as it stands (all lanes hold the same copy); ref / revref are already in s_refs.
-template <bool STATS, bool WORD, bool DIRECT>
+template <bool STATS, bool WORD, bool DIRECT, bool TRIM>
 __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
                                             uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat,
                                             uint8_t *s_pres /* [128] */) {
@@ -978,14 +988,14 @@ __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32
   int t0 = 0;
 #pragma nounroll
   for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
-    probe_batch<STATS>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, o);
+    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     t0 += plan[ph];
     if (o.found) break;
   }
   if (!o.found && t0 < P.maxshift) {
     wave_sync();  // s_pres
-    probe_tail<STATS>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, o);
+    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
   }
   if (lane == 0) {
@@ -1032,7 +1042,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
   }
   if (h.done) return;
-  search_step<STATS, false, true>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave]);
+  search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave]);
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1200,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
 // MG (one pool over several GPUs): a rank runs its own chains only and publishes one word per chain; the lowest-
 // chain-id resolution (k_mg_resolve) runs after the all-gather on every rank, then k_mg_mark.  One GPU: the
 // proposals go straight to resv[] (atomicMin) and the words are only k_mg_mark's input.
-template <int NP, bool STATS, bool MG>
+template <int NP, bool STATS, bool MG, bool TRIM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_round(DevParams P) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
   __shared__ uint16_t s_list[TAIL_CAP];
@@ -1228,7 +1238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
-  search_step<STATS, true, !MG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres);
+  search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres);
 }
 
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
@@ -1441,14 +1451,16 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   if (!P.K) return;
   const dim3 g(P.K), b(64);
   const size_t dyn = (size_t)P.dbg_search_lds;
-#define RCALL(N)                                                                          \
-  do {                                                                                    \
-    if (mg) { if (stats) hipLaunchKernelGGL((k_round<N, true, true>), g, b, dyn, st, P);  \
-              else hipLaunchKernelGGL((k_round<N, false, true>), g, b, dyn, st, P); }     \
-    else { if (stats) hipLaunchKernelGGL((k_round<N, true, false>), g, b, dyn, st, P);    \
-           else hipLaunchKernelGGL((k_round<N, false, false>), g, b, dyn, st, P); }       \
+#define RCALL2(N, T)                                                                         \
+  do {                                                                                       \
+    if (mg) { if (stats) hipLaunchKernelGGL((k_round<N, true, true, T>), g, b, dyn, st, P);  \
+              else hipLaunchKernelGGL((k_round<N, false, true, T>), g, b, dyn, st, P); }     \
+    else { if (stats) hipLaunchKernelGGL((k_round<N, true, false, T>), g, b, dyn, st, P);    \
+           else hipLaunchKernelGGL((k_round<N, false, false, T>), g, b, dyn, st, P); }       \
   } while (0)
+#define RCALL(N) do { if (P.deep_bins) RCALL2(N, true); else RCALL2(N, false); } while (0)
   if (P.Lpad <= 192) RCALL(3); else RCALL(8);
+#undef RCALL2
 #undef RCALL
 }
 void launch_mg_resolve(hipStream_t st, const DevParams &P) {

@@ -898,6 +898,10 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
     P.urec[l] = ctx->dict[l].urec; P.ids[l] = ctx->dict[l].ids;
   }
   P.fpt = ctx->fpt; P.bshift = ctx->bshift;
+  // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
+  // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
+  const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
+  P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : (nd * 10 >= nk * 13);
 }
 static uint32_t auto_chains(uint32_t n) {
   uint64_t k = n >> 10;  // ~1000 reads per chain

@@ -37,6 +37,7 @@ class ReorderOpts:
     dbg_search_lds: int = 0
     dbg_apply_lds: int = 0
     fused: int = 0            # -1: the two-kernel round
+    deep_bins: int = 0        # 1 / -1: force the bin-trimming kernel variant on / off (0 = from the dictionary)
 
     def to_c(self):
         o = _lib.Opts()
@@ -46,7 +47,7 @@ class ReorderOpts:
         o.force_literal_update, o.rounds_per_sync = int(self.force_literal_update), self.rounds_per_sync
         o.first_shifts, o.seed_wide, o.tab_scale = self.first_shifts, self.seed_wide, self.tab_scale
         o.search_wpb, o.dbg_search_lds, o.dbg_apply_lds = self.search_wpb, self.dbg_search_lds, self.dbg_apply_lds
-        o.fused = self.fused
+        o.fused, o.deep_bins = self.fused, self.deep_bins
         return o
 
 

@@ -286,7 +286,7 @@ def test_single_pool_1M_4_virtual_ranks():
         assert np.array_equal(got[k], single[k]), k
 
 
-@pytest.mark.parametrize("kw", [dict(first_shifts=1), dict(first_shifts=4), dict(first_shifts=-1), dict(first_shifts=16), dict(seed_wide=-1),
+@pytest.mark.parametrize("kw", [dict(first_shifts=1), dict(first_shifts=4), dict(first_shifts=-1), dict(deep_bins=1), dict(deep_bins=-1), dict(first_shifts=16), dict(seed_wide=-1),
                                 dict(tab_scale=1), dict(tab_scale=4), dict(search_wpb=2), dict(search_wpb=4),
                                 dict(dbg_search_lds=20000), dict(dbg_apply_lds=20000, fused=-1), dict(fused=-1),
                                 dict(first_shifts=3, seed_wide=-1, tab_scale=1, search_wpb=4, fused=-1)])
