@@ -6,10 +6,14 @@
 // consumes the GPU stage's output unchanged.  Also the C++ mirror of the
 // reference's operator interface (call_reorder.h).
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <zlib.h>
@@ -110,6 +114,22 @@ int read_file(const std::string &path, std::vector<uint8_t> &buf) {
   return 0;
 }
 
+int file_size(const std::string &path, size_t *sz) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
+  fseek(f, 0, SEEK_END);
+  *sz = (size_t)ftell(f);
+  fclose(f);
+  return 0;
+}
+int read_into(const std::string &path, uint8_t *dst, size_t sz) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
+  const bool ok = !sz || fread(dst, 1, sz, f) == sz;
+  fclose(f);
+  return ok ? 0 : fail(SPRING_REORDER_E_IO, "short read from %s", path.c_str());
+}
+
 struct CtxGuard {
   spring_reorder_ctx *c = nullptr;
   ~CtxGuard() { spring_reorder_destroy(c); }
@@ -119,6 +139,14 @@ struct CtxGuard {
 
 extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, int32_t paired_end,
                                   uint32_t n0, uint32_t n1, const spring_reorder_opts *opts) {
+  const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;  // phase timings on stderr, no effect on results
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[run] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   if (!temp_dir) return fail(SPRING_REORDER_E_ARG, "temp_dir is NULL");
   if (num_thr <= 0) return fail(SPRING_REORDER_E_ARG, "num_thr must be >= 1");
   spring_reorder_opts o;
@@ -130,19 +158,22 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
   if (ntot > 4294967290ull) return fail(SPRING_REORDER_E_ARG, "too many reads");           // params.h:24
   const uint32_t n = (uint32_t)ntot;
 
-  std::vector<uint8_t> dna;
-  int r = read_file(in1, dna);
+  // both input files into one buffer that is not zero-filled first (4 GB at 100 M reads)
+  size_t sz1 = 0, sz2 = 0;
+  int r = file_size(in1, &sz1);
   if (r) return r;
-  if (paired_end) {  // file-2 reads are appended to the same pool (reorder.h:233-242)
-    r = read_file(in2, dna);
-    if (r) return r;
-  }
+  if (paired_end && (r = file_size(in2, &sz2))) return r;
+  std::unique_ptr<uint8_t[]> dna(new uint8_t[sz1 + sz2 + 1]);
+  if ((r = read_into(in1, dna.get(), sz1))) return r;
+  if (paired_end && (r = read_into(in2, dna.get() + sz1, sz2))) return r;  // file-2 reads follow in the same pool (reorder.h:233-242)
+  lap("read input files");
   CtxGuard g;
   r = spring_reorder_create(&g.c, &o);
   if (r) return r;
-  r = spring_reorder_load_dna(g.c, dna.data(), dna.size(), n, max_readlen);
+  r = spring_reorder_load_dna(g.c, dna.get(), sz1 + sz2, n, max_readlen);
   if (r) return r;
-  std::vector<uint8_t>().swap(dna);
+  dna.reset();
+  lap("create + load (H2D)");
   remove(in1.c_str());  // the stage consumes its inputs (reorder.h:232,241)
   if (paired_end) remove(in2.c_str());
   if ((r = spring_reorder_build_dict(g.c))) return r;
@@ -150,39 +181,61 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
   if ((r = spring_reorder_finalize(g.c))) return r;
   spring_reorder_stats st;
   if ((r = spring_reorder_get_stats(g.c, &st))) return r;
+  lap("dict + chains + final");
 
   const size_t nm = st.n_matched, ns = st.n_single;
-  std::vector<uint32_t> order(nm ? nm : 1), order_s(ns ? ns : 1);
-  std::vector<char> rc(nm ? nm : 1), flag(nm ? nm : 1);
-  std::vector<int64_t> pos(nm ? nm : 1);
-  std::vector<uint16_t> rlen(nm ? nm : 1);
+  // not zero-filled: the download overwrites every byte (1.6 GB at 100 M reads)
+  std::unique_ptr<uint32_t[]> order(new uint32_t[nm + 1]), order_s(new uint32_t[ns + 1]);
+  std::unique_ptr<char[]> rc(new char[nm + 1]), flag(new char[nm + 1]);
+  std::unique_ptr<int64_t[]> pos(new int64_t[nm + 1]);
+  std::unique_ptr<uint16_t[]> rlen(new uint16_t[nm + 1]);
   std::vector<uint64_t> toff(num_thr + 1), toff_s(num_thr + 1);
-  r = spring_reorder_download(g.c, order.data(), rc.data(), flag.data(), pos.data(), rlen.data(), order_s.data(),
+  r = spring_reorder_download(g.c, order.get(), rc.get(), flag.get(), pos.get(), rlen.get(), order_s.get(),
                               toff.data(), toff_s.data());
   if (r) return r;
-  std::vector<uint8_t> stream;
-  for (int t = 0; t < num_thr; t++) {  // all six files must exist for every tid (encoder.h:147-175)
+  lap("download streams");
+  // temp.dna.<tid> / temp.dna.singleton are built on the device (reverse complement + repack), one stream after the
+  // other; the file sets are then written by one host thread per tid (CRC-32 + file system, the slow half)
+  std::vector<std::vector<uint8_t>> dna_t(num_thr + 1);
+  for (int t = 0; t <= num_thr; t++) {
+    const int32_t which = t < num_thr ? t : -1;
+    size_t nb = 0;
+    if ((r = spring_reorder_emit_dna(g.c, which, nullptr, 0, &nb))) return r;
+    dna_t[t].resize(nb ? nb : 1);
+    if ((r = spring_reorder_emit_dna(g.c, which, dna_t[t].data(), nb, &nb))) return r;
+    dna_t[t].resize(nb);
+  }
+  lap("emit temp.dna (D2H)");
+  if (!crc_ready) crc_init();
+  std::vector<int> trc(num_thr, 0);
+  std::vector<std::string> terr(num_thr);
+  auto write_tid = [&](int t) {  // all six files must exist for every tid (encoder.h:147-175)
     const std::string ts = "." + std::to_string(t);
     const size_t a = toff[t], c = toff[t + 1] - toff[t];
-    if ((r = write_raw(base + "/read_order.bin" + ts, order.data() + a, c * 4))) return r;
-    if ((r = write_gzip_stored(base + "/read_rev.txt" + ts, rc.data() + a, c))) return r;
-    if ((r = write_gzip_stored(base + "/tempflag.txt" + ts, flag.data() + a, c))) return r;
-    if ((r = write_gzip_stored(base + "/temppos.txt" + ts, pos.data() + a, c * 8))) return r;
-    if ((r = write_gzip_stored(base + "/read_lengths.bin" + ts, rlen.data() + a, c * 2))) return r;
-    size_t nb = 0;
-    if ((r = spring_reorder_emit_dna(g.c, t, nullptr, 0, &nb))) return r;
-    stream.resize(nb ? nb : 1);
-    if ((r = spring_reorder_emit_dna(g.c, t, stream.data(), nb, &nb))) return r;
-    if ((r = write_raw(base + "/temp.dna" + ts, stream.data(), nb))) return r;
+    int e;
+    if ((e = write_raw(base + "/read_order.bin" + ts, order.get() + a, c * 4)) ||
+        (e = write_gzip_stored(base + "/read_rev.txt" + ts, rc.get() + a, c)) ||
+        (e = write_gzip_stored(base + "/tempflag.txt" + ts, flag.get() + a, c)) ||
+        (e = write_gzip_stored(base + "/temppos.txt" + ts, pos.get() + a, c * 8)) ||
+        (e = write_gzip_stored(base + "/read_lengths.bin" + ts, rlen.get() + a, c * 2)) ||
+        (e = write_raw(base + "/temp.dna" + ts, dna_t[t].data(), dna_t[t].size()))) {
+      trc[t] = e;
+      terr[t] = spring_reorder_last_error();  // the message is thread-local
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < num_thr; t++) th.emplace_back(write_tid, t);
+    write_tid(0);
+    for (auto &x : th) x.join();
   }
-  size_t nb = 0;
-  if ((r = spring_reorder_emit_dna(g.c, -1, nullptr, 0, &nb))) return r;
-  stream.resize(nb ? nb : 1);
-  if ((r = spring_reorder_emit_dna(g.c, -1, stream.data(), nb, &nb))) return r;
-  if ((r = write_raw(base + "/temp.dna.singleton", stream.data(), nb))) return r;  // reorder.h:704-728
-  if ((r = write_raw(base + "/read_order.bin.singleton", order_s.data(), ns * 4))) return r;
+  for (int t = 0; t < num_thr; t++)
+    if (trc[t]) return fail(trc[t], "%s", terr[t].c_str());
+  if ((r = write_raw(base + "/temp.dna.singleton", dna_t[num_thr].data(), dna_t[num_thr].size()))) return r;  // reorder.h:704-728
+  if ((r = write_raw(base + "/read_order.bin.singleton", order_s.get(), ns * 4))) return r;
   const uint32_t numreads_s = (uint32_t)ns;
   if ((r = write_raw(base + "/temp.dna.singleton.count", &numreads_s, 4))) return r;  // reorder.h:699-701
+  lap("write files");
   printf("Reordering done, %llu were unmatched\n", (unsigned long long)st.unmatched);  // reorder.h:633-635
   return 0;
 }

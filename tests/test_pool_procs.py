@@ -133,3 +133,41 @@ def test_one_pool_two_processes_one_gpu(tmp_path, n, L, K, T):
     orc = po.reorder_rounds(read, ln, L, K, T)
     for k in ("order", "rc", "flag", "pos", "rlen", "order_s"):
         assert np.array_equal(got[k], orc[k]), ("oracle", k)
+
+
+RCCL_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+import torch.distributed as dist
+import spring_amd
+from spring_amd.pool import DistPool, PoolComm
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n, L, K, T = 300_000, 150, 777, 4
+comm = PoolComm(dist, torch.device("cuda", 0), transport="rccl")
+ok = True
+for rep in range(2):                      # the communicator is reused by several runs
+    dp = DistPool(comm, K, num_thr=T)
+    dp.run(lambda s: s.load_synth(n, L, n * L // 25, 5 + rep, 10000))
+    got = dp.streams()
+    dp.close()
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=K, num_thr=T)) as s:
+        s.load_synth(n, L, n * L // 25, 5 + rep, 10000)
+        want = s.run().streams()
+    ok = ok and all(np.array_equal(got[k], want[k]) for k in ("order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s"))
+comm.close()
+print("RESULT " + json.dumps({"ok": bool(ok)}), flush=True)
+dist.destroy_process_group()
+""" % ROOT
+
+
+@pytest.mark.gpu
+def test_in_library_rccl_exchange_one_rank(tmp_path):
+    """The production transport of the pool -- ncclAllGather issued by the library on its own stream -- with a 1-rank
+    communicator (all a single-GPU box allows): same streams as run_chains; the communicator serves two runs."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    outs = _spawn(script, 1, timeout=600)
+    res = json.loads([x for x in outs[0].splitlines() if x.startswith("RESULT ")][0][7:])
+    assert res["ok"]
