@@ -17,6 +17,15 @@
 
 namespace {
 
+// runs with cwd = dir (BooPHF drops temp files in cwd, BooPHF.h:1211) and goes back afterwards: the caller's
+// temp directory is deleted later and a process must not be left sitting in it
+struct CwdGuard {
+  char old[4096];
+  bool ok;
+  explicit CwdGuard(const char *dir) { ok = getcwd(old, sizeof(old)) != nullptr && chdir(dir) == 0; }
+  ~CwdGuard() { if (ok && chdir(old) != 0) ok = false; }
+};
+
 template <size_t BS>
 int build_dict(const uint64_t *limbs, const uint16_t *len, uint32_t n, int which_start[2],
                int which_end[2], const char *basedir, int num_thr, int which,
@@ -86,7 +95,8 @@ int ref_build_dict(const uint64_t *limbs, const uint16_t *len, uint32_t n, int W
                    const uint64_t *probe_keys, uint32_t nprobe, uint32_t *bin_size,
                    uint32_t *bin_ids, uint32_t *numkeys, uint32_t *dict_numreads) {
   int s[2] = {start0, start1}, e[2] = {end0, end1};
-  if (chdir(basedir) != 0) return -2;
+  CwdGuard cwd(basedir);
+  if (!cwd.ok) return -2;
 #define CALL(BS) build_dict<BS>(limbs, len, n, s, e, basedir, num_thr, which, probe_keys, nprobe, bin_size, bin_ids, numkeys, dict_numreads)
   DISPATCH(W, CALL)
 #undef CALL
@@ -132,7 +142,8 @@ int ref_build_dict_bpb(const uint64_t *limbs, const uint16_t *len, uint32_t n, i
                        uint32_t nprobe, uint32_t *bin_size, uint32_t *bin_ids, uint32_t *numkeys,
                        uint32_t *dict_numreads, int bpb) {
   int s[2] = {start0, start1}, e[2] = {end0, end1};
-  if (chdir(basedir) != 0) return -2;
+  CwdGuard cwd(basedir);
+  if (!cwd.ok) return -2;
 #define CALL(BS) build_dict<BS>(limbs, len, n, s, e, basedir, num_thr, which, probe_keys, nprobe, bin_size, bin_ids, numkeys, dict_numreads, bpb)
   DISPATCH(W, CALL)
 #undef CALL

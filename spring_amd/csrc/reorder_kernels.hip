@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
 // ------------------------------------------------------------ fused round: apply(t-1) + search(t) in one kernel
 // The two phases of consecutive rounds for one chain, back to back: the chain's header and consensus are loaded
 // once, the new consensus goes from the update straight into the search's LDS copy, and a round is one chain
-// kernel + k_mg_mark instead of two chain kernels.  Same schedule as the two-kernel round (same oracle): every
+// kernel + k_mg_mark instead of two chain kernels.  Same schedule as the two-kernel round (same specification): every
 // search of round t sees taken[] with all claims of round t-1, because k_mg_mark(t-1) -- which sets the winners'
 // taken bits, the cursor and the needy bitmap from the proposal words -- runs between the two launches; the
 // resv[] entries the apply halves read belong to reads that are all taken by then, so the proposals of round t

@@ -44,7 +44,7 @@ def test_two_lanes_over_gloo(tmp_path):
         env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
+                                      stderr=subprocess.STDOUT, text=True, cwd=ROOT))
     outs = []
     for p in procs:
         o, _ = p.communicate(timeout=180)

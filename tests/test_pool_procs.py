@@ -36,7 +36,7 @@ def _spawn(script, world, extra_env=None, timeout=600):
             env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), **(extra_env or {}))
             procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                          stderr=subprocess.STDOUT, text=True))
+                                          stderr=subprocess.STDOUT, text=True, cwd=ROOT))
         outs, ok = [], True
         for p in procs:
             try:
