@@ -63,16 +63,6 @@ __device__ __forceinline__ uint64_t lds_window(const uint64_t *s, int bitpos) {
   return off ? (lo >> off) | (hi << (64 - off)) : lo;
 }
 
-__device__ __forceinline__ uint64_t spread32(uint32_t x) {
-  uint64_t v = x;
-  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  v = (v | (v << 2)) & 0x3333333333333333ull;
-  v = (v | (v << 1)) & 0x5555555555555555ull;
-  return v;
-}
-
 __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uint32_t rid) {
   return (taken[rid >> 6] >> (rid & 63)) & 1ull;
 }
@@ -348,33 +338,47 @@ __device__ __forceinline__ int argmax_code(const int4 &v) {  // reorder.h:204-21
   return code_of_cidx(ind);
 }
 
-// packs LDS codes[0..R) into limbs (ballot based) and stores ref + revref; with lds_refs (the fused round kernel)
-// the limbs also go to the search's LDS copy [2][LDS_LIMBS] (zero padded either side)
+// 16 bits -> the even bit positions of 32 bits
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
+// packs LDS codes[0..R) into limbs and stores ref + revref; with lds_refs (the fused round kernel) the limbs
+// also go to the search's LDS copy [2][LDS_LIMBS] (zero padded either side).  Block k of 64 bases gives four
+// wave-uniform ballots (bit planes of ref and of revref); lane 4k+t keeps the 32-bit half it will interleave
+// (t bit 0 = high half, bit 1 = revref), so the bit interleave runs once for all 32 limbs instead of per block.
 __device__ __forceinline__ void pack_consensus(WaveLds *ws, int R, int lane, Chain *c, uint64_t *lds_refs = nullptr) {
   wave_sync();
   const int nblk = (R + 63) >> 6;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
-    if (k < nblk) {
-      const int p = k * 64 + lane;
-      int cf = 0, cr = 0;
-      if (p < R) {
-        cf = ws->code[p];
-        cr = 3 - ws->code[R - 1 - p];
-      }
-      f0 = __ballot(cf & 1); f1 = __ballot(cf & 2);
-      r0 = __ballot(cr & 1); r1 = __ballot(cr & 2);
+  const int myk = lane >> 2;
+  const bool hi = lane & 1, isrev = lane & 2;
+  uint32_t a = 0, b = 0;  // bit plane 0 / 1 of this lane's 32 bases; blocks >= nblk stay zero
+  for (int k = 0; k < nblk; k++) {
+    const int p = k * 64 + lane;
+    int cf = 0, cr = 0;
+    if (p < R) {
+      cf = ws->code[p];
+      cr = 3 - ws->code[R - 1 - p];
     }
-    // limbs 2k, 2k+1 of ref by lanes 0,1; of revref by lanes 2,3 (values are wave-uniform)
-    if (lane < 4) {
-      const bool hi = lane & 1, isrev = lane & 2;
-      const uint64_t a = isrev ? r0 : f0, b = isrev ? r1 : f1;
-      const uint64_t limb = spread32((uint32_t)(hi ? a >> 32 : a)) | (spread32((uint32_t)(hi ? b >> 32 : b)) << 1);
-      uint64_t *dst = isrev ? c->revref : c->ref;
-      dst[2 * k + (hi ? 1 : 0)] = limb;
-      if (lds_refs) lds_refs[(isrev ? LDS_LIMBS : 0) + LDS_PAD + 2 * k + (hi ? 1 : 0)] = limb;
+    const uint64_t f0 = __ballot(cf & 1), f1 = __ballot(cf & 2);
+    const uint64_t r0 = __ballot(cr & 1), r1 = __ballot(cr & 2);
+    if (myk == k) {
+      const uint64_t x = isrev ? r0 : f0, y = isrev ? r1 : f1;
+      a = (uint32_t)(hi ? x >> 32 : x);
+      b = (uint32_t)(hi ? y >> 32 : y);
     }
+  }
+  if (lane < 32) {
+    const uint32_t lo = spread16(a & 0xFFFFu) | (spread16(b & 0xFFFFu) << 1);
+    const uint32_t up = spread16(a >> 16) | (spread16(b >> 16) << 1);
+    const uint64_t limb = ((uint64_t)up << 32) | lo;
+    uint64_t *dst = isrev ? c->revref : c->ref;
+    dst[2 * myk + (hi ? 1 : 0)] = limb;
+    if (lds_refs) lds_refs[(isrev ? LDS_LIMBS : 0) + LDS_PAD + 2 * myk + (hi ? 1 : 0)] = limb;
   }
 }
 
