@@ -682,13 +682,26 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   return seed;
 }
 
+// A candidate read is compared STAGE_LIMBS limbs at a time: its dwords go from global memory straight into the
+// wavefront's LDS staging area (global_load_lds: LDS address = uniform base + 4 * lane, one 256-byte row per dword), all
+// in flight together -- one memory round trip per candidate instead of one per limb, and no registers held for the
+// data while it is in flight (the round kernel runs at 64 VGPRs; limbs preloaded into registers spill).
+constexpr int STAGE_LIMBS = 5;
+constexpr int STAGE_WORDS = 2 * STAGE_LIMBS * 64;  // uint32_t per wavefront
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+#ifndef SR_ROUND_WAVES
+#define SR_ROUND_WAVES 8  // minimum waves per SIMD the round kernel is compiled for (64 VGPRs)
+#endif
+
 // ---- one probe of search_match (reorder.h:262-316): dictionary l, direction rev, at `shift`.  The window's
 // key and hash come from the caller because one consensus window is the probe key of both dictionaries
 // (at shifts wl apart).  sx = ref (forward) or revref (reverse) in LDS.
 template <bool TRIM>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
-                                           bool &keyok, uint32_t &ncand, bool &other) {
+                                           bool &keyok, uint32_t &ncand, bool &other, uint32_t *s_best, uint32_t *stage,
+                                           int lane) {
   const int W = P.W;
   const int ds = P.dstart[l];
   const int klen2 = 2 * P.wl;
@@ -704,21 +717,49 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     const int clen = P.uniform_len ? P.L : (int)P.lens[r];
     const int m = clen < mref ? clen : mref;
     const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
-    if (check_key && read_window(rdp, P.S, ds, klen2) != key) return -1;
     const int blo = 2 * lo, bhi = 2 * m;
+    // The key re-check of a single-read bin needs no load of its own: `key` is the consensus window that the
+    // alignment puts on the read's own key window [ka, kb), so the keys are equal iff the XOR below is zero on those
+    // bits (a valid probe keeps the window inside the compared range).
+    const int ka = 2 * ds, kb = ka + klen2;
+    uint32_t kdiff = 0;
     int hd = 0;
-    for (int i = 0; i < W; i++) {
-      const int s0 = i * 64;
-      if (s0 >= bhi) break;
-      if (s0 + 64 <= blo) continue;
-      uint64_t x = lds_window(sx, s0 + bitshift) ^ rdp[i];
-      if (blo > s0) x &= ~0ull << (blo - s0);
-      if (bhi < s0 + 64) x &= (1ull << (bhi - s0)) - 1;
-      hd += __popcll(x);
+    for (int i0 = 0; i0 < W; i0 += STAGE_LIMBS) {
+      const uint32_t *g = reinterpret_cast<const uint32_t *>(rdp + i0);
+#pragma unroll
+      for (int d = 0; d < 2 * STAGE_LIMBS; d++)
+        if (2 * i0 + d < 2 * W)
+          __builtin_amdgcn_global_load_lds((glb_void_t *)(g + d), (lds_void_t *)(stage + d * 64), 4, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma nounroll  // LDS reads are cheap; unrolled, their ten result registers would all be live at once
+      for (int u = 0; u < STAGE_LIMBS; u++) {
+        const int i = i0 + u, s0 = i * 64;
+        const int a = blo - s0, b = bhi - s0;  // bits [max(a,0), min(b,64)) of this limb are compared
+        if (a < 64 && b > 0 && i < W) {
+          const uint64_t xr = (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32);
+          uint64_t y = lds_window(sx, s0 + bitshift) ^ xr;
+          if (a > 0) y &= ~0ull << a;
+          if (b < 64) y &= (1ull << b) - 1;
+          hd += __popcll(y);
+          const int c = ka - s0, d = kb - s0;
+          if (check_key && c < 64 && d > 0) {
+            if (c > 0) y &= ~0ull << c;
+            if (d < 64) y &= (1ull << d) - 1;
+            kdiff |= (uint32_t)y | (uint32_t)(y >> 32);
+          }
+        }
+      }
     }
+    if (kdiff) return -1;
     return hd <= THRESH;
   };
+  // *s_best (LDS) = lowest priority code that has hit so far in this batch of probes: the lanes run in lock step, so
+  // a lane still walking a bin after another lane with a lower code has hit can never be the winner and leaves
+  // (the wavefront waits for its slowest lane; each further candidate is three dependent memory round trips)
+  const uint32_t mycode = (uint32_t)((shift << 2) | (rev << 1) | l);
+  auto beaten = [&]() -> bool { return *(volatile uint32_t *)s_best < mycode; };
   for (int skip = 0;; skip++) {
+    if (skip && beaten()) break;
     uint32_t pay;
     const int kind = tab_find(P.fpt, P.bshift, hsh, l, skip, pay, other);
     if (kind == 0) break;  // key absent
@@ -733,9 +774,10 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       if (rec.x != key) continue;  // fingerprint collision
       start = (uint32_t)rec.y; count = (uint32_t)(rec.y >> 32);
     }
-    bool verified = !single;
+    bool verified = !single, gave_up = false;
     int live = 0, top_live = -1;
     for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
+      if (j != (int)count - 1 && beaten()) { gave_up = true; break; }
       const uint32_t r = single ? pay : ids[start + j];
       if (is_taken(P.taken, r)) continue;
       if (TRIM && top_live < 0) top_live = j;
@@ -743,8 +785,9 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       if (wt < 0) break;  // fingerprint collision (single-read bin)
       verified = true;
       live++; keyok = true; ncand++;
-      if (wt) { hit = true; rid = r; break; }
+      if (wt) { hit = true; rid = r; atomicMin(s_best, mycode); break; }
     }
+    if (gave_up) break;  // (no trim below: the scan did not reach the bin's live tail)
     if (!verified) continue;  // taken or colliding single-read slot: the key's own bin may sit in a later slot
     // Chains consume a bin from its tail, and a taken read stays taken: the entries above the first live one are
     // dead for good, so the bin's count shrinks to it (exact; the reference gets the same from
@@ -777,7 +820,8 @@ struct BatchOut {
 // STATS counts what the reference would have executed: every valid probe up to and including the winner.
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
-                                            int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, BatchOut &out) {
+                                            int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, uint32_t *s_best,
+                                            uint32_t *stage, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
@@ -786,10 +830,12 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   const bool valid = (lane >> 2) < nsh && probe_valid(P, l, rev, shift, ref_len);
   bool hit = false, keyok = false, other = false;
   uint32_t rid = 0, ncand = 0;
+  if (lane == 0) *s_best = 0x7fffffffu;
+  wave_sync();
   if (valid) {
     const int ds = P.dstart[l];
     const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
-    eval_probe<TRIM>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other);
+    eval_probe<TRIM>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, s_best, stage, lane);
   }
   const uint64_t hm = __ballot(hit);
   const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
@@ -819,7 +865,7 @@ constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
-                                           int ref_len, BatchOut &out) {
+                                           int ref_len, uint32_t *s_best, uint32_t *stage, BatchOut &out) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
@@ -855,6 +901,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
     }
     T += __popcll(m);
   }
+  if (lane == 0) *s_best = 0x7fffffffu;
   wave_sync();
   int best = 0x7fffffff;
   uint32_t brid = 0;
@@ -877,7 +924,8 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         const int sh = l ? sh1 : sh0;
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
-        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other);
+        if ((base || k) && *(volatile uint32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
+        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
         if (hit) {
           const int code = probe_code(sh, rev, l);
@@ -928,9 +976,9 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 // read by k_mg_mark).  DIRECT: reserve the read at once (atomicMin on resv[]), everything is on this GPU.
 // `h` is the chain's header as it stands (all lanes hold the same copy); ref / revref are already in s_refs.
 template <bool STATS, bool WORD, bool DIRECT, bool TRIM>
-__device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
+__device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
                                             uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat,
-                                            uint8_t *s_pres /* [128] */) {
+                                            uint8_t *s_pres /* [128] */, uint32_t *s_best, uint32_t *s_stage /* [STAGE_WORDS] */) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
     const long long seed = find_seed(P, cid, lane, &is_last);
@@ -949,7 +997,7 @@ __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32
       }
       store_hot(c, h);
     }
-    return;
+    return -2;
   }
 
   // ---- search mode
@@ -968,7 +1016,7 @@ __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32
       if (WORD) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
       if (STATS && new_iter) c->st_iter++;
     }
-    return;
+    return -3;
   }
 
   // the bookkeeping fields changed above go back now; the 64-byte header is not kept in registers across
@@ -992,14 +1040,14 @@ __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32
   int t0 = 0;
 #pragma nounroll
   for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
-    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, o);
+    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     t0 += plan[ph];
     if (o.found) break;
   }
   if (!o.found && t0 < P.maxshift) {
     wave_sync();  // s_pres
-    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, o);
+    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, o);
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
   }
   if (lane == 0) {
@@ -1021,6 +1069,7 @@ __device__ __forceinline__ void search_step(const DevParams &P, Chain *c, uint32
       if (new_iter) c->st_iter++;
     }
   }
+  return o.found ? o.code : -1;  // debug builds time the search by outcome; unused otherwise
 }
 
 // ------------------------------------------------------------ K4 search (phase A of the two-kernel round)
@@ -1031,6 +1080,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   __shared__ uint16_t s_list[WPB][TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
   __shared__ uint8_t s_pres[WPB][128];
+  __shared__ uint32_t s_best[WPB];
+  __shared__ uint32_t s_stage[WPB][STAGE_WORDS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t li = blockIdx.x * WPB + wave;
   if (li >= P.K) return;
@@ -1046,7 +1097,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
   }
   if (h.done) return;
-  search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave]);
+  search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave],
+                                          &s_best[wave], s_stage[wave]);
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1220,29 +1272,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   __shared__ uint16_t s_list[TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? 2 * TAIL_CAP : 2];
   __shared__ uint8_t s_pres[128];
-  __shared__ WaveLds lds;
+  __shared__ uint32_t s_best;
+  // the search's staging area; the apply half's scratch (WaveLds) is dead by then and shares the space
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];
+  static_assert(sizeof(WaveLds) <= sizeof(uint32_t) * STAGE_WORDS, "WaveLds overlays s_stage");
+  WaveLds &lds = *reinterpret_cast<WaveLds *>(s_stage);
   const int lane = threadIdx.x;
   const uint32_t li = blockIdx.x;
   const uint32_t cid = P.c0 + li;
   Chain *c = &P.chains[li];
-  ChainHot h;
-  load_hot(c, h);
+#ifdef SR_PHASE_TIMING
+  const long long T0 = clock64();
+#endif
+  // the header lives in LDS, not in registers: its 16 dwords are wave-uniform, and held in every lane's VGPRs
+  // across the update and the search they are what pushes the kernel past 64 VGPRs into scratch
+  __shared__ ChainHot s_h;
+  if (lane < 4) reinterpret_cast<uint4 *>(&s_h)[lane] = reinterpret_cast<const uint4 *>(&c->h)[lane];
+  ChainHot &h = s_h;
   if (lane < LDS_LIMBS) {
     const int i = lane - LDS_PAD;
     const bool in = i >= 0 && i < P.W;
     s_refs[0][lane] = in ? c->ref[i] : 0ull;
     s_refs[1][lane] = in ? c->revref[i] : 0ull;
   }
+  wave_sync();  // s_h; the update below rewrites s_refs
   if (h.done) {
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
-  wave_sync();  // the update below rewrites s_refs
+#ifdef SR_PHASE_TIMING
+  const long long T1 = clock64();
+#endif
   if (!apply_step<NP, false, true>(P, c, cid, li, h, lane, &lds, nullptr, &s_refs[0][0])) {
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
-  search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres);
+#ifdef SR_PHASE_TIMING
+  const long long T2 = clock64();
+#endif
+  const int outcome = search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, &s_best, s_stage);
+#ifdef SR_PHASE_TIMING
+  if (lane == 0 && outcome >= -1) {  // search time by outcome (debug builds only): first batch, second batch, tail, failed
+    const uint64_t dt = (uint64_t)(clock64() - T2);
+    (void)T0; (void)T1;
+    const int sh = outcome >> 2;
+    if (outcome < 0) c->st_iter += dt;
+    else if (sh < P.plan[0][0]) { c->st_probes += dt; c->st_hits += 1; }
+    else if (sh < P.plan[0][0] + P.plan[0][1]) { c->st_keyok += dt; c->st_lost += 1ull << 32; }
+    else c->st_cands += dt;
+  }
+#endif
 }
 
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
