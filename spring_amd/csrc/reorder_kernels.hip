@@ -653,31 +653,44 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   *is_last = rank + 1 == nneedy;
   uint32_t need = rank + 1;
   long long seed = -1;
+  // 64 lanes x 4 bitmap words = 16 384 reads per step, highest first (late in a run few reads are left and the
+  // wanted one is many words below the cursor: every step is a dependent round trip)
   while (top >= 0) {
-    const long long wtop = top >> 6, w = wtop - lane;
-    uint64_t u = 0;
-    if (w >= 0) {
-      u = ~P.taken[w];
-      if (w == wtop) {
-        int bits = (int)(top & 63) + 1;
-        if (bits < 64) u &= (1ull << bits) - 1;
-      }
+    const long long wtop = top >> 6, wl0 = wtop - 4 * lane;
+    uint64_t u[4];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const long long w = wl0 - k;
+      u[k] = w >= 0 ? ~P.taken[w] : 0ull;
     }
-    int cnt = __popcll(u);
-    int incl = wave_incl_scan_i(cnt, lane);
-    uint32_t total = (uint32_t)__shfl(incl, 63, 64);
+    if (lane == 0) {
+      const int bits = (int)(top & 63) + 1;
+      if (bits < 64) u[0] &= (1ull << bits) - 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cnt += __popcll(u[k]);
+    const int incl = wave_incl_scan_i(cnt, lane);
+    const uint32_t total = (uint32_t)__shfl(incl, 63, 64);
     if (total >= need) {
-      uint64_t m = __ballot((uint32_t)incl >= need);
-      int wl = __ffsll((unsigned long long)m) - 1;
-      int before = __shfl(incl - cnt, wl, 64);
-      uint64_t uu = shfl_u64(u, wl);
-      int kth = (int)need - before;  // kth highest set bit of uu
-      for (int t = 1; t < kth; t++) uu &= ~(1ull << (63 - __clzll(uu)));
-      seed = (wtop - wl) * 64 + (63 - __clzll(uu));
+      const uint64_t m = __ballot((uint32_t)incl >= need);
+      const int wl = __ffsll((unsigned long long)m) - 1;
+      int kth = (int)need - __shfl(incl - cnt, wl, 64);  // kth highest untaken read of lane wl's four words
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint64_t uu = shfl_u64(u[k], wl);
+        const int c = __popcll(uu);
+        if (seed < 0) {
+          if (kth <= c) {
+            for (int t = 1; t < kth; t++) uu &= ~(1ull << (63 - __clzll(uu)));
+            seed = (wtop - 4 * wl - k) * 64 + (63 - __clzll(uu));
+          } else kth -= c;
+        }
+      }
       break;
     }
     need -= total;
-    top = (wtop - 64) * 64 + 63;
+    top = (wtop - 256) * 64 + 63;
   }
   return seed;
 }
@@ -1183,7 +1196,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     if (h.mode == MODE_SEARCH) h.retrying = 1;
     if (lane == 0) {
       store_hot(c, h);
-      c->st_lost++;
+      atomicAdd((unsigned long long *)&c->st_lost, 1ull);  // no returned value: nothing to wait for
     }
     return true;
   }
@@ -1222,7 +1235,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
         atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
       }
       if (h.prev_unmatched) emit_single(P, h, li, h.prev);
-      c->n_unmatched++;
+      atomicAdd((unsigned long long *)&c->n_unmatched, 1ull);
     }
     h.prev_unmatched = 1; h.first_rid = rid; h.prev = rid;
     h.ref_pos = 0; h.mode = MODE_SEARCH;
