@@ -94,7 +94,26 @@ def pool_main(a, lanes, torch, spring_amd, L_):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
-    comm = PoolComm(dist, torch.device("cuda", dev), transport="rccl")
+    # the exchange: ncclAllGather issued by the library on its own stream.  Should the RCCL communicator not come
+    # up on some rank, every rank falls back to the host-staged all-gather over a gloo group (slower per round,
+    # same result) and the line says so in config.exchange.
+    comm, ok = None, 1
+    try:
+        comm = PoolComm(dist, torch.device("cuda", dev), transport="rccl")
+    except Exception as e:  # noqa: BLE001
+        ok = 0
+        print("# rank %d: RCCL communicator failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+    flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    exchange = "rccl"
+    if int(flag.item()) == 0:
+        from spring_amd.pool import GroupView
+        if comm is not None:
+            comm.close()
+        gl = dist.new_group(backend="gloo")
+        comm = PoolComm(GroupView(dist, gl, "gloo"), torch.device("cuda", dev), transport="host")
+        exchange = "host-staged all-gather over gloo (RCCL communicator unavailable)"
 
     def one_pass():
         dp = DistPool(comm, Ktot, num_thr=a.num_thr)
@@ -116,7 +135,7 @@ def pool_main(a, lanes, torch, spring_amd, L_):
                         "records; %d chains sharded over %d GPUs, one RCCL all-gather of %d proposal bytes per round "
                         "issued by the library on its stream"
                         % (n, L, a.pool_reads_per_gpu, G, a.coverage, a.err_ppm / 1e4, Ktot, world, Ktot * 8),
-            "pool_reads": n, "reads_per_gpu": a.pool_reads_per_gpu, "read_len": L, "chains": Ktot, "num_thr": a.num_thr,
+            "exchange": exchange, "pool_reads": n, "reads_per_gpu": a.pool_reads_per_gpu, "read_len": L, "chains": Ktot, "num_thr": a.num_thr,
             "parallelism": "1 process per GPU, single shared pool: reads + dictionaries replicated, chains sharded, "
                            "all-gather per round (DESIGN.md section 7)",
             "stage_ms_rank0": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},

@@ -122,6 +122,29 @@ def host_allgather(dist):
     return _lib.MG_ALLGATHER_FN(fn)
 
 
+class GroupView:
+    """The slice of the torch.distributed module PoolComm / host_allgather use, bound to one process group (e.g. a
+    gloo group next to a default nccl group: the host transport moves HOST buffers)."""
+
+    def __init__(self, dist, group, backend):
+        self._d, self._g, self._b = dist, group, backend
+
+    def get_world_size(self):
+        return self._d.get_world_size(self._g)
+
+    def get_rank(self):
+        return self._d.get_rank(self._g)
+
+    def get_backend(self):
+        return self._b
+
+    def broadcast(self, t, src=0):
+        return self._d.broadcast(t, src=src, group=self._g)
+
+    def all_gather(self, out, t):
+        return self._d.all_gather(out, t, group=self._g)
+
+
 class PoolComm:
     """spring_mg_comm: the exchange transport of one rank, made once per process and reused by every run.
     transport "rccl": ncclAllGather on the library's stream; the 128-byte id is made by rank 0 and broadcast through

@@ -60,13 +60,15 @@ import ctypes as C, json, os, sys
 sys.path.insert(0, %r)
 import numpy as np
 import torch.distributed as dist
-from spring_amd.pool import host_allgather
+from spring_amd.pool import GroupView, host_allgather
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 K = 1000                                   # words per rank
-cb = host_allgather(dist)
-ok = True
-for rnd in range(3):                        # the library calls it once per round
+# the default group, then a second group behind GroupView (bench.py's fallback next to an nccl default group)
+view = GroupView(dist, dist.new_group(backend="gloo"), "gloo")
+ok = view.get_world_size() == world and view.get_rank() == rank and view.get_backend() == "gloo"
+for rnd in range(6):                        # the library calls it once per round
+    cb = host_allgather(dist if rnd < 3 else view)
     buf = np.zeros(world * K, np.uint64)
     buf[rank * K:(rank + 1) * K] = np.arange(K, dtype=np.uint64) + (rank + 1) * 1_000_000 + rnd
     rc = cb(buf.ctypes.data, rank * K * 8, K * 8, world * K * 8, None)
