@@ -29,6 +29,17 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// a wave-uniform value pinned to scalar registers (the compiler otherwise turns `lane_bit ? P.x[1] : P.x[0]` back
+// into a per-lane vector load from the kernel-argument buffer: a memory round trip in front of every probe)
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *p) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -702,6 +713,7 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
 constexpr int STAGE_LIMBS = 5;
 constexpr int STAGE_WORDS = 2 * STAGE_LIMBS * 64;  // uint32_t per wavefront
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // the staging rows are addressed as LDS (no generic-pointer checks)
 typedef const __attribute__((address_space(1))) void glb_void_t;
 #ifndef SR_ROUND_WAVES
 #define SR_ROUND_WAVES 8  // minimum waves per SIMD the round kernel is compiled for (64 VGPRs)
@@ -713,13 +725,14 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 template <bool TRIM>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
-                                           bool &keyok, uint32_t &ncand, bool &other, uint32_t *s_best, uint32_t *stage,
+                                           bool &keyok, uint32_t &ncand, bool &other, uint32_t *s_best, lds_u32_t *stage,
                                            int lane) {
   const int W = P.W;
-  const int ds = P.dstart[l];
+  // (l differs between lanes: P.x[l] would be a vector load from the kernel-argument buffer -- select instead)
+  const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   const int klen2 = 2 * P.wl;
-  const ulonglong2 *__restrict__ urec = P.urec[l];
-  const uint32_t *__restrict__ ids = P.ids[l];
+  const ulonglong2 *__restrict__ urec = l ? uni_ptr(P.urec[1]) : uni_ptr(P.urec[0]);
+  const uint32_t *__restrict__ ids = l ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]);
   const int bitshift = rev ? -2 * shift : 2 * shift;
   const int lo = rev ? shift : 0;
   const int mref = rev ? ref_len + shift : ref_len - shift;
@@ -737,29 +750,39 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     const int ka = 2 * ds, kb = ka + klen2;
     uint32_t kdiff = 0;
     int hd = 0;
+    // only the first and the last limb of the compared range [blo, bhi) are partial; the limbs between need no mask
+    const int first = blo >> 6, last = (bhi - 1) >> 6;
     for (int i0 = 0; i0 < W; i0 += STAGE_LIMBS) {
       const uint32_t *g = reinterpret_cast<const uint32_t *>(rdp + i0);
-#pragma unroll
-      for (int d = 0; d < 2 * STAGE_LIMBS; d++)
-        if (2 * i0 + d < 2 * W)
-          __builtin_amdgcn_global_load_lds((glb_void_t *)(g + d), (lds_void_t *)(stage + d * 64), 4, 0, 0);
+      // dword d of the chunk -> staging row d: the instruction offset moves the global address by 4 d bytes and the
+      // LDS address with it, so row d's base is given 252 d bytes further (one address register for all ten loads)
+#define STAGE_ROW(D) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (D) * 63), 4, (D) * 4, 0)
+      static_assert(STAGE_LIMBS == 5, "ten rows below");
+      if (W - i0 >= STAGE_LIMBS) {
+        STAGE_ROW(0); STAGE_ROW(1); STAGE_ROW(2); STAGE_ROW(3); STAGE_ROW(4);
+        STAGE_ROW(5); STAGE_ROW(6); STAGE_ROW(7); STAGE_ROW(8); STAGE_ROW(9);
+      } else {
+        const int nd = 2 * (W - i0);
+        STAGE_ROW(0); STAGE_ROW(1);
+        if (nd > 2) { STAGE_ROW(2); STAGE_ROW(3); }
+        if (nd > 4) { STAGE_ROW(4); STAGE_ROW(5); }
+        if (nd > 6) { STAGE_ROW(6); STAGE_ROW(7); }
+      }
+#undef STAGE_ROW
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ihi = min(i0 + STAGE_LIMBS - 1, last);
 #pragma nounroll  // LDS reads are cheap; unrolled, their ten result registers would all be live at once
-      for (int u = 0; u < STAGE_LIMBS; u++) {
-        const int i = i0 + u, s0 = i * 64;
-        const int a = blo - s0, b = bhi - s0;  // bits [max(a,0), min(b,64)) of this limb are compared
-        if (a < 64 && b > 0 && i < W) {
-          const uint64_t xr = (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32);
-          uint64_t y = lds_window(sx, s0 + bitshift) ^ xr;
-          if (a > 0) y &= ~0ull << a;
-          if (b < 64) y &= (1ull << b) - 1;
-          hd += __popcll(y);
-          const int c = ka - s0, d = kb - s0;
-          if (check_key && c < 64 && d > 0) {
-            if (c > 0) y &= ~0ull << c;
-            if (d < 64) y &= (1ull << d) - 1;
-            kdiff |= (uint32_t)y | (uint32_t)(y >> 32);
-          }
+      for (int i = max(i0, first); i <= ihi; i++) {
+        const int u = i - i0;
+        const uint64_t xr = (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32);
+        uint64_t y = lds_window(sx, i * 64 + bitshift) ^ xr;
+        if (i == first) y &= ~0ull << (blo & 63);
+        if (i == last) y &= ~0ull >> (63 - ((bhi - 1) & 63));
+        hd += __popcll(y);
+        if (check_key && i >= (ka >> 6) && i <= ((kb - 1) >> 6)) {
+          if (i == (ka >> 6)) y &= ~0ull << (ka & 63);
+          if (i == ((kb - 1) >> 6)) y &= ~0ull >> (63 - ((kb - 1) & 63));
+          kdiff |= (uint32_t)y | (uint32_t)(y >> 32);
         }
       }
     }
@@ -819,7 +842,8 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
 __device__ __forceinline__ int probe_code(int shift, int rev, int l) { return (shift << 2) | (rev << 1) | l; }
 __device__ __forceinline__ bool probe_valid(const DevParams &P, int l, int rev, int shift, int ref_len) {
   if (shift >= P.maxshift) return false;
-  return rev ? (P.dend[l] < ref_len + shift && P.dstart[l] > shift) : (P.dend[l] + shift < ref_len);
+  const int de = l ? uni_i32(P.dend[1]) : uni_i32(P.dend[0]), ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+  return rev ? (de < ref_len + shift && ds > shift) : (de + shift < ref_len);
 }
 
 struct BatchOut {
@@ -834,7 +858,7 @@ struct BatchOut {
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                             int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, uint32_t *s_best,
-                                            uint32_t *stage, BatchOut &out) {
+                                            lds_u32_t *stage, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
@@ -846,7 +870,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   if (lane == 0) *s_best = 0x7fffffffu;
   wave_sync();
   if (valid) {
-    const int ds = P.dstart[l];
+    const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
     const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
     eval_probe<TRIM>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, s_best, stage, lane);
   }
@@ -878,7 +902,7 @@ constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
-                                           int ref_len, uint32_t *s_best, uint32_t *stage, BatchOut &out) {
+                                           int ref_len, uint32_t *s_best, lds_u32_t *stage, BatchOut &out) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
@@ -991,7 +1015,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 template <bool STATS, bool WORD, bool DIRECT, bool TRIM>
 __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
                                             uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat,
-                                            uint8_t *s_pres /* [128] */, uint32_t *s_best, uint32_t *s_stage /* [STAGE_WORDS] */) {
+                                            uint8_t *s_pres /* [128] */, uint32_t *s_best, lds_u32_t *s_stage /* [STAGE_WORDS] */) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
     const long long seed = find_seed(P, cid, lane, &is_last);
@@ -1034,8 +1058,9 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
 
   // the bookkeeping fields changed above go back now; the 64-byte header is not kept in registers across
   // the probe loop (the kernel is latency-bound at 8 waves/SIMD, i.e. 64 VGPRs, so every register counts)
-  const int ref_len = h.ref_len;
-  const bool left_search = h.left_search;
+  // (wave-uniform values read from the header -- in LDS for the fused kernel -- are pinned to scalar registers)
+  const int ref_len = __builtin_amdgcn_readfirstlane(h.ref_len);
+  const bool left_search = __builtin_amdgcn_readfirstlane((int)h.left_search) != 0;
   if (lane == 0 && new_iter) {
     c->h.num_reads_thr = h.num_reads_thr;
     c->h.num_unmatched_past = h.num_unmatched_past;
@@ -1046,7 +1071,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   // past the winner is a wasted 64-byte request; every further batch is a further dependent round trip (8 + 16 is
   // the measured optimum).  A fresh seed (nothing matched to it yet) fails nine searches out of
   // ten and needs every window anyway: it gets the wide plan.  P.plan[which] = batch widths in shifts (each <= 16, sum <= 32), 0-terminated.
-  const int *plan = P.plan[(h.prev_unmatched && P.seed_wide) ? 1 : 0];
+  const int *plan = P.plan[(__builtin_amdgcn_readfirstlane((int)h.prev_unmatched) && P.seed_wide) ? 1 : 0];
   BatchOut o;
   o.found = 0;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
@@ -1111,7 +1136,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
   if (h.done) return;
   search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave],
-                                          &s_best[wave], s_stage[wave]);
+                                          &s_best[wave], (lds_u32_t *)s_stage[wave]);
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1323,7 +1348,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #ifdef SR_PHASE_TIMING
   const long long T2 = clock64();
 #endif
-  const int outcome = search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, &s_best, s_stage);
+  const int outcome = search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, &s_best, (lds_u32_t *)s_stage);
 #ifdef SR_PHASE_TIMING
   if (lane == 0 && outcome >= -1) {  // search time by outcome (debug builds only): first batch, second batch, tail, failed
     const uint64_t dt = (uint64_t)(clock64() - T2);
