@@ -725,14 +725,17 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 template <bool TRIM>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
-                                           bool &keyok, uint32_t &ncand, bool &other, uint32_t *s_best, lds_u32_t *stage,
+                                           bool &keyok, uint32_t &ncand, bool &other, lds_u32_t *s_best, lds_u32_t *stage,
                                            int lane) {
   const int W = P.W;
   // (l differs between lanes: P.x[l] would be a vector load from the kernel-argument buffer -- select instead)
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   const int klen2 = 2 * P.wl;
-  const ulonglong2 *__restrict__ urec = l ? uni_ptr(P.urec[1]) : uni_ptr(P.urec[0]);
-  const uint32_t *__restrict__ ids = l ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]);
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) u64x2_t g_urec_t;  // (an integer-made pointer is generic: say "global")
+  typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+  g_urec_t *urec = (g_urec_t *)(l ? uni_ptr(P.urec[1]) : uni_ptr(P.urec[0]));
+  g_u32_t *ids = (g_u32_t *)(l ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
   const int bitshift = rev ? -2 * shift : 2 * shift;
   const int lo = rev ? shift : 0;
   const int mref = rev ? ref_len + shift : ref_len - shift;
@@ -793,7 +796,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
   // a lane still walking a bin after another lane with a lower code has hit can never be the winner and leaves
   // (the wavefront waits for its slowest lane; each further candidate is three dependent memory round trips)
   const uint32_t mycode = (uint32_t)((shift << 2) | (rev << 1) | l);
-  auto beaten = [&]() -> bool { return *(volatile uint32_t *)s_best < mycode; };
+  auto beaten = [&]() -> bool { return *(volatile lds_u32_t *)s_best < mycode; };
   for (int skip = 0;; skip++) {
     if (skip && beaten()) break;
     uint32_t pay;
@@ -806,7 +809,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     const bool single = kind == 2;
     uint32_t start = 0, count = 1;
     if (!single) {
-      const ulonglong2 rec = urec[pay];
+      const u64x2_t rec = urec[pay];
       if (rec.x != key) continue;  // fingerprint collision
       start = (uint32_t)rec.y; count = (uint32_t)(rec.y >> 32);
     }
@@ -821,7 +824,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       if (wt < 0) break;  // fingerprint collision (single-read bin)
       verified = true;
       live++; keyok = true; ncand++;
-      if (wt) { hit = true; rid = r; atomicMin(s_best, mycode); break; }
+      if (wt) { hit = true; rid = r; __hip_atomic_fetch_min(s_best, mycode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); break; }
     }
     if (gave_up) break;  // (no trim below: the scan did not reach the bin's live tail)
     if (!verified) continue;  // taken or colliding single-read slot: the key's own bin may sit in a later slot
@@ -832,7 +835,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     // dictionary has deep bins (pools of a few hundred x coverage and more: +23 % at 1600x); on shallow data the extra
     // state in the hot loop costs 5 %.
     if (TRIM && !single && (uint32_t)(top_live + 1) < count)
-      atomicMin(reinterpret_cast<uint32_t *>(const_cast<ulonglong2 *>(&urec[pay])) + 3, (uint32_t)(top_live + 1));
+      atomicMin((uint32_t *)(uint64_t)(&urec[pay]) + 3, (uint32_t)(top_live + 1));
     break;
   }
 }
@@ -857,7 +860,7 @@ struct BatchOut {
 // STATS counts what the reference would have executed: every valid probe up to and including the winner.
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
-                                            int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, uint32_t *s_best,
+                                            int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, lds_u32_t *s_best,
                                             lds_u32_t *stage, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
@@ -902,7 +905,7 @@ constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
-                                           int ref_len, uint32_t *s_best, lds_u32_t *stage, BatchOut &out) {
+                                           int ref_len, lds_u32_t *s_best, lds_u32_t *stage, BatchOut &out) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
@@ -961,7 +964,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         const int sh = l ? sh1 : sh0;
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
-        if ((base || k) && *(volatile uint32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
+        if ((base || k) && *(volatile lds_u32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
         eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
         if (hit) {
@@ -1015,7 +1018,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 template <bool STATS, bool WORD, bool DIRECT, bool TRIM>
 __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
                                             uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat,
-                                            uint8_t *s_pres /* [128] */, uint32_t *s_best, lds_u32_t *s_stage /* [STAGE_WORDS] */) {
+                                            uint8_t *s_pres /* [128] */, lds_u32_t *s_best, lds_u32_t *s_stage /* [STAGE_WORDS] */) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
     const long long seed = find_seed(P, cid, lane, &is_last);
@@ -1136,7 +1139,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
   if (h.done) return;
   search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave],
-                                          &s_best[wave], (lds_u32_t *)s_stage[wave]);
+                                          (lds_u32_t *)&s_best[wave], (lds_u32_t *)s_stage[wave]);
 }
 
 // ------------------------------------------------------------- K5/K6 apply (phase B)
@@ -1348,7 +1351,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #ifdef SR_PHASE_TIMING
   const long long T2 = clock64();
 #endif
-  const int outcome = search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, &s_best, (lds_u32_t *)s_stage);
+  const int outcome = search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
 #ifdef SR_PHASE_TIMING
   if (lane == 0 && outcome >= -1) {  // search time by outcome (debug builds only): first batch, second batch, tail, failed
     const uint64_t dt = (uint64_t)(clock64() - T2);
