@@ -121,14 +121,20 @@ __device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshif
     // gather and the line is often evicted again before it is read (tools/wave_hop_bench.hip)
     const uint4 t = fpt[b * 2];
     other = other || (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || t.w != 0;
-#define SLOT(T, I)                                              \
-    if ((T) == 0) return 0;                                     \
-    if (((T) & ~1u) == mine && skip-- == 0) {                   \
-      pay = reinterpret_cast<const uint32_t *>(fpt)[b * 8 + 4 + (I)]; \
-      return 1 + (int)((T) & 1u);                               \
+    // slots fill in order and never empty again, so the matches of `mine` all lie before the first free slot and a
+    // free last slot ends the key's run; one bit per matching slot instead of a branch per slot
+    uint32_t m = (uint32_t)((t.x & ~1u) == mine) | ((uint32_t)((t.y & ~1u) == mine) << 1) |
+                 ((uint32_t)((t.z & ~1u) == mine) << 2) | ((uint32_t)((t.w & ~1u) == mine) << 3);
+    const int c = __popc(m);
+    if (c > skip) {
+      for (; skip > 0; skip--) m &= m - 1;
+      const int I = __ffs((int)m) - 1;
+      const uint32_t T = I == 0 ? t.x : I == 1 ? t.y : I == 2 ? t.z : t.w;
+      pay = reinterpret_cast<const uint32_t *>(fpt)[b * 8 + 4 + I];
+      return 1 + (int)(T & 1u);
     }
-    SLOT(t.x, 0) SLOT(t.y, 1) SLOT(t.z, 2) SLOT(t.w, 3)
-#undef SLOT
+    if (t.w == 0) return 0;
+    skip -= c;
     b = (b + 1) & bmask;
   }
 }
