@@ -1129,13 +1129,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   __shared__ uint8_t s_pres[WPB][128];
   __shared__ uint32_t s_best[WPB];
   __shared__ uint32_t s_stage[WPB][STAGE_WORDS];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uni_i32((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: the chain pointer stays in SGPRs)
   const uint32_t li = blockIdx.x * WPB + wave;
   if (li >= P.K) return;
   const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
   Chain *c = &P.chains[li];
-  ChainHot h;
-  load_hot(c, h);
+  __shared__ ChainHot s_h[WPB];  // header in LDS (wave-uniform values do not belong in 16 VGPRs of every lane)
+  if (lane < 4) reinterpret_cast<uint4 *>(&s_h[wave])[lane] = reinterpret_cast<const uint4 *>(&c->h)[lane];
+  ChainHot &h = s_h[wave];
   // stage ref / revref in LDS right away (same dependency level as the header load)
   if (lane < LDS_LIMBS) {
     const int i = lane - LDS_PAD;
@@ -1143,6 +1144,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
     s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
   }
+  wave_sync();
   if (h.done) return;
   search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave],
                                           (lds_u32_t *)&s_best[wave], (lds_u32_t *)s_stage[wave]);
