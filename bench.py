@@ -77,6 +77,22 @@ def kernels_sha():
 
 def pool_main(a, lanes, torch, spring_amd, L_):
     """N>1: one shared read pool, chains sharded over the GPUs, the exchange inside the library (RCCL)."""
+    # RCCL prints a version banner with printf when its first communicator comes up, and stdout must carry exactly
+    # one line: fd 1 points at stderr until the JSON line is due (the C stdio buffer is flushed before it comes back)
+    sys.stdout.flush()
+    saved_fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out, rank = _pool_run(a, lanes, torch, spring_amd, L_)
+    finally:
+        C.CDLL(None).fflush(None)
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def _pool_run(a, lanes, torch, spring_amd, L_):
     from spring_amd.pool import DistPool, PoolComm
     world, rank = lanes.world, lanes.rank
     dev = torch.cuda.current_device()
@@ -146,11 +162,11 @@ def pool_main(a, lanes, torch, spring_amd, L_):
     }
     if rank == 0:
         assert int(tot_matched + tot_single) == n, "the ranks' streams do not add up to the pool"
-        print(json.dumps(out), flush=True)
     comm.close()
     if lanes.dist is None:
         dist.destroy_process_group()
     lanes.close()
+    return out, rank
 
 
 def main():
