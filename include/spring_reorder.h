@@ -119,7 +119,8 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx);
 
 /* ---- FASTQ front end.  The sequence side of preprocess() (src/preprocess.cpp:186-214,:293-304;
  * read_fastq_block src/util.cpp:31-54; write_dna_in_bits / write_dnaN_in_bits src/util.cpp:269-294,:322-348) on
- * the GPU: uncompressed 4-line FASTQ text in host memory -> reads without N packed 2 bits/base straight into the
+ * the GPU: 4-line FASTQ in host memory -- text, or a gzip file image (magic 1f 8b, any number of members:
+ * preprocess.cpp:154-183 reads .gz input too), which is inflated on the host first -> reads without N packed 2 bits/base straight into the
  * record stream the reorder stage consumes (what the reference writes to input_clean_{1,2}.dna; file-2 reads
  * follow file-1 reads), reads with N packed 4 bits/base (input_N.dna[.2]) with their position in their file
  * (read_order_N.bin[.2]).  Errors mirror the reference's exceptions ("Invalid FASTQ(A) file. Number of lines not

@@ -20,6 +20,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <zlib.h>
 
 #include "reorder_device.h"
 #include "reorder_internal.h"
@@ -496,11 +497,59 @@ static int fq_scan_file(spring_reorder_ctx *ctx, const uint8_t *txt, size_t nbyt
   return 0;
 }
 
+// A gzip'ed FASTQ buffer (magic 1f 8b; preprocess.cpp:154-183 reads .gz input through
+// boost::iostreams::gzip_decompressor) is inflated on the host, every member of a multi-member file (bgzip,
+// concatenated .gz) in turn; anything else is taken as text.
+static int gunzip_if_needed(const uint8_t *&p, size_t &n, std::vector<uint8_t> &buf) {
+  if (n < 2 || p[0] != 0x1f || p[1] != 0x8b) return 0;
+  z_stream z;
+  memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, 15 + 16) != Z_OK) return fail(SPRING_REORDER_E_IO, "zlib: inflateInit2 failed");
+  buf.clear();
+  buf.reserve(n * 4);
+  size_t in_pos = 0;
+  std::vector<uint8_t> tmp(1 << 22);
+  int zr = Z_OK;
+  for (;;) {
+    if (z.avail_in == 0 && in_pos < n) {
+      const size_t take = std::min<size_t>(n - in_pos, 1u << 30);
+      z.next_in = const_cast<uint8_t *>(p + in_pos);
+      z.avail_in = (uInt)take;
+      in_pos += take;
+    }
+    z.next_out = tmp.data();
+    z.avail_out = (uInt)tmp.size();
+    zr = inflate(&z, Z_NO_FLUSH);
+    if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) {
+      inflateEnd(&z);
+      return fail(SPRING_REORDER_E_IO, "gzip error in the FASTQ input (zlib %d)", zr);
+    }
+    buf.insert(buf.end(), tmp.data(), tmp.data() + (tmp.size() - z.avail_out));
+    if (zr == Z_STREAM_END) {
+      if (z.avail_in == 0 && in_pos >= n) break;  // last member
+      if (inflateReset(&z) != Z_OK) { inflateEnd(&z); return fail(SPRING_REORDER_E_IO, "zlib: inflateReset failed"); }
+    } else if (zr == Z_BUF_ERROR && z.avail_in == 0 && in_pos >= n) {
+      inflateEnd(&z);
+      return fail(SPRING_REORDER_E_IO, "gzip error in the FASTQ input (truncated member)");
+    }
+  }
+  inflateEnd(&z);
+  p = buf.data();
+  n = buf.size();
+  return 0;
+}
+
 int spring_reorder_load_fastq(spring_reorder_ctx *ctx, const uint8_t *fastq_1, size_t nbytes_1, const uint8_t *fastq_2,
                               size_t nbytes_2, spring_fastq_info *info) {
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_fastq: context already loaded");
   if ((nbytes_1 && !fastq_1) || (nbytes_2 && !fastq_2)) return fail(SPRING_REORDER_E_ARG, "NULL FASTQ buffer");
+  std::vector<uint8_t> unz[2];
+  {
+    int gr = gunzip_if_needed(fastq_1, nbytes_1, unz[0]);
+    if (!gr && fastq_2) gr = gunzip_if_needed(fastq_2, nbytes_2, unz[1]);
+    if (gr) return gr;
+  }
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
   const bool paired = fastq_2 != nullptr;

@@ -96,6 +96,39 @@ def test_fastq_frontend_bit_exact(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("members", [1, 3])
+def test_fastq_frontend_gzip_input(members):
+    """.gz input (preprocess.cpp:154-183): a gzip image -- one member, or several concatenated members cut in the
+    middle of a record -- gives exactly what its text gives; paired input with one file compressed and one not."""
+    import gzip
+    import spring_amd
+    f1, f2 = _synth_fastq(11, 5000, 30, 150, 0.1), _synth_fastq(12, 5000, 30, 150, 0.1)
+
+    def gz(t):
+        cuts = [len(t) * i // members for i in range(members + 1)]  # arbitrary byte positions
+        return b"".join(gzip.compress(t[a:b], 6) for a, b in zip(cuts[:-1], cuts[1:]))
+
+    with spring_amd.ReorderStage() as s:
+        want = s.load_fastq(f1, f2)
+        want_dna, want_n = s.download_dna(), [s.fastq_N(0), s.fastq_N(1)]
+    with spring_amd.ReorderStage() as s:
+        got = s.load_fastq(gz(f1), f2)
+        for k in ("num_reads", "num_reads_clean", "num_reads_N", "max_readlen"):
+            assert got[k] == want[k], k
+        assert s.download_dna() == want_dna
+        for j in range(2):
+            nd, on = s.fastq_N(j)
+            assert nd == want_n[j][0] and np.array_equal(on, want_n[j][1])
+    with spring_amd.ReorderStage() as s:
+        with pytest.raises(spring_amd.ReorderError, match="gzip error"):
+            s.load_fastq(gz(f1)[:-20])  # truncated
+    with spring_amd.ReorderStage() as s:
+        bad = bytearray(gz(f1)); bad[len(bad) // 2] ^= 0xFF
+        with pytest.raises(spring_amd.ReorderError, match="gzip error|multiple of 4|Invalid character|Too long"):
+            s.load_fastq(bytes(bad))
+
+
+@pytest.mark.gpu
 def test_fastq_frontend_errors():
     import spring_amd
     with spring_amd.ReorderStage() as s:
