@@ -36,7 +36,7 @@ struct __attribute__((aligned(16))) ChainHot {
   uint32_t num_reads_thr, num_unmatched_past;   // early-stop window (reorder.h:380-381)
   uint32_t n_emit, n_single, s_slot;     // s_slot: next free slot in the singleton chunk
   uint8_t done, prev_unmatched, left_search, stop_searching;
-  uint8_t mode, retrying, prop_kind, prop_rev;
+  uint8_t mode, retrying, prop_kind, prop_rev;   // prop_rev: bit 0 reverse match, bit 1 dictionary of the winning probe, bit 2 "a repeated search may resume at this probe"
   uint8_t cnt_buf, finishing, cursor_writer, cnt_wide;   // cnt_wide: the committed count buffer is in cnt (else cnt8)
 };
 static_assert(sizeof(ChainHot) == 64, "ChainHot must be one 64-byte line");

@@ -856,6 +856,7 @@ __device__ __forceinline__ bool probe_valid(const DevParams &P, int l, int rev, 
 }
 
 struct BatchOut {
+  bool capped;       // a probe ahead of the winner (any probe, when nothing hit) stopped at MAX_SEARCH live candidates
   uint32_t found, rid;
   int code;          // probe_code of the winner
   uint64_t st_p, st_k, st_c;
@@ -867,14 +868,19 @@ struct BatchOut {
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                             int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, lds_u32_t *s_best,
-                                            lds_u32_t *stage, BatchOut &out) {
+                                            lds_u32_t *stage, int min_code, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   const uint64_t *sx = rev ? srev : sref;
   const int shift = sh_base + (lane >> 2);
-  const bool valid = (lane >> 2) < nsh && probe_valid(P, l, rev, shift, ref_len);
-  bool hit = false, keyok = false, other = false;
+  // min_code (a chain that lost its last proposal searches again on an unchanged consensus): every probe ahead of
+  // the last winner failed then and fails now -- taken reads stay taken -- so the search resumes at the winner's
+  // code; a skipped probe leaves "the other dictionary may hold this window" behind for the tail
+  const bool valid0 = (lane >> 2) < nsh && probe_valid(P, l, rev, shift, ref_len);
+  const bool skipped = TRIM && valid0 && probe_code(shift, rev, l) < min_code;  // (TRIM: see search_step)
+  const bool valid = valid0 && !skipped;
+  bool hit = false, keyok = false, other = skipped;
   uint32_t rid = 0, ncand = 0;
   if (lane == 0) *s_best = 0x7fffffffu;
   wave_sync();
@@ -888,6 +894,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   out.found = hm != 0;
   out.code = probe_code(sh_base + (win >> 2), (win >> 1) & 1, win & 1);
   out.rid = (uint32_t)__shfl((int)rid, win, 64);
+  out.capped = TRIM && __any(valid && (hm == 0 || lane < win) && !hit && ncand >= (uint32_t)MAX_SEARCH);
   // what this fetch told about the OTHER dictionary's probe of the same window, for the tail (probe_tail)
   if ((lane >> 2) < nsh && shift < 32) pres[4 * shift + (lane & 3)] = other ? 1 : 0;
   out.st_p = out.st_k = out.st_c = 0;
@@ -911,7 +918,7 @@ constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
-                                           int ref_len, lds_u32_t *s_best, lds_u32_t *stage, BatchOut &out) {
+                                           int ref_len, lds_u32_t *s_best, lds_u32_t *stage, int min_code, BatchOut &out) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
@@ -937,6 +944,12 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         v0 = sh0 >= t0 && probe_valid(P, 0, 1, sh0, ref_len);
         if (v1 && sh0 >= 0 && sh0 < t0) v1 = present(sh0, 2);
       }
+      // (resumed search: nothing ahead of the last winner)
+      const int sh0c = rev ? t0 + i - wl : t0 + i, sh1c = rev ? t0 + i : t0 + i - wl;
+      if (TRIM) {
+        v0 = v0 && probe_code(sh0c, rev, 0) >= min_code;
+        v1 = v1 && probe_code(sh1c, rev, 1) >= min_code;
+      }
     }
     const bool need = v0 || v1;
     const uint64_t m = __ballot(need);
@@ -949,7 +962,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
   }
   if (lane == 0) *s_best = 0x7fffffffu;
   wave_sync();
-  int best = 0x7fffffff;
+  int best = 0x7fffffff, capmin = 0x7fffffff;  // capmin: lowest code of this lane's probes that stopped at MAX_SEARCH
   uint32_t brid = 0;
   for (int base = 0; base < T; base += 64) {
     const int j = base + lane;
@@ -973,6 +986,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         if ((base || k) && *(volatile lds_u32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
         eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
+        if (TRIM && !hit && ncand >= (uint32_t)MAX_SEARCH) capmin = min(capmin, probe_code(sh, rev, l));
         if (hit) {
           const int code = probe_code(sh, rev, l);
           if (code < best) { best = code; brid = rid; }
@@ -986,6 +1000,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
   for (int o = 32; o > 0; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o, 64));
   out.found = wmin != 0x7fffffff;
   out.code = wmin;
+  out.capped = TRIM && __any(capmin < wmin);
   const uint64_t wm = __ballot(best == wmin);
   out.rid = (uint32_t)__shfl((int)brid, __ffsll((unsigned long long)wm) - 1, 64);
   out.st_p = out.st_k = out.st_c = 0;
@@ -1081,27 +1096,40 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   // the measured optimum).  A fresh seed (nothing matched to it yet) fails nine searches out of
   // ten and needs every window anyway: it gets the wide plan.  P.plan[which] = batch widths in shifts (each <= 16, sum <= 32), 0-terminated.
   const int *plan = P.plan[(__builtin_amdgcn_readfirstlane((int)h.prev_unmatched) && P.seed_wide) ? 1 : 0];
+  // a search repeated after a lost proposal resumes at the last winner's code (see probe_batch) -- unless some probe
+  // ahead of that winner had stopped at MAX_SEARCH live candidates (then a deeper candidate may have come into its
+  // reach: bit 2 of prop_rev says it had not), or the reference-equivalent work is being counted.  Only in the
+  // kernel variant for dictionaries with deep bins (TRIM): that is where proposals are lost in numbers (a third of
+  // them at 1 600x coverage, 0.3 % at 25x, where the bookkeeping costs more than it saves)
+  int min_code = 0;
+  if (TRIM && !STATS && !new_iter) {
+    const int pr = uni_i32((int)h.prop_rev);
+    if (pr & 4) min_code = (uni_i32(h.prop_shift) << 2) | ((pr & 1) << 1) | ((pr >> 1) & 1);
+  }
+  bool capped = false;
   BatchOut o;
   o.found = 0;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
   int t0 = 0;
 #pragma nounroll
   for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
-    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, o);
+    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, min_code, o);
+    capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     t0 += plan[ph];
     if (o.found) break;
   }
   if (!o.found && t0 < P.maxshift) {
     wave_sync();  // s_pres
-    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, o);
+    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, min_code, o);
+    capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
   }
   if (lane == 0) {
     if (o.found) {
       c->h.prop_rid = o.rid;
       c->h.prop_shift = o.code >> 2;
-      c->h.prop_rev = (uint8_t)((o.code >> 1) & 1);
+      c->h.prop_rev = (uint8_t)(((o.code >> 1) & 1) | ((o.code & 1) << 1) | ((TRIM && !capped) ? 4 : 0));  // rev | dict << 1 | resumable << 2
       c->h.prop_kind = PROP_MATCH;
       if (WORD) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;
       if (DIRECT) atomicMin(&P.resv[o.rid], cid);
@@ -1207,7 +1235,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
   bool do_upd = false, ureset = false, urev = false;
   uint32_t urid = 0;
   int ushift = 0;
-  if (kind == PROP_MATCH) { do_upd = true; urid = h.prop_rid; urev = h.prop_rev; ushift = h.prop_shift; }
+  if (kind == PROP_MATCH) { do_upd = true; urid = h.prop_rid; urev = h.prop_rev & 1; ushift = h.prop_shift; }
   else if (kind == PROP_SEED) { do_upd = true; urid = h.prop_rid; ureset = true; }
   else if (fail_path && !h.left_search) { do_upd = true; urid = h.first_rid; ureset = true; urev = true; }  // reorder.h:567
   int n = P.L, R_new = h.ref_len;

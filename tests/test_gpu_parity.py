@@ -305,6 +305,38 @@ def test_tuning_opts_do_not_change_results(name, K, T, kw):
         assert got["stats"][k] == want["stats"][k], (k, kw)
 
 
+@pytest.mark.parametrize("n,L,G,K", [(60_000, 100, 300, 256), (40_000, 150, 2_000, 500), (30_000, 150, 400, 37)])
+def test_resumed_search_after_lost_proposals(n, L, G, K):
+    """Contended pools (hundreds of chains on a genome of a few hundred bases: most proposals are lost, bins of
+    hundreds to thousands of reads, some beyond MAX_SEARCH) through the trimming kernel variant WITHOUT work counting:
+    that is the build in which a chain that lost its proposal resumes its search at the last winner's probe
+    (search_step).  Streams must equal the rounds oracle, which always searches from the first probe; the counting
+    run of the same pool must agree with both."""
+    sa = _sa()
+    outs = []
+    for stats in (False, True):
+        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, deep_bins=1, collect_stats=stats)) as st:
+            st.load_synth(n, L, G, 23, 10000)
+            outs.append(st.run().streams())
+            dna = st.download_dna()
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, 2)
+    _same(outs[0], want, "resumed search")
+    _same(outs[1], want, "counting run")
+    assert outs[0]["stats"]["lost"] > n // 10  # the regime the test is about
+
+
+@pytest.mark.parametrize("K", [16, 64, 300])
+def test_resumed_search_with_bins_beyond_max_search(K):
+    """Same build, on the set whose bins hold more than MAX_SEARCH_REORDER reads.  A probe that stopped at the cap may
+    succeed later (deeper candidates come into reach), so a search after a lost proposal does not resume past such a
+    probe (prop_rev bit 2); this set walks those bins, but does not by itself produce that sequence of events -- it
+    guards the path, the rule is argued in search_step."""
+    dna, n, L = named_set("heavy")
+    read, ln = po.load_dna(dna, n, L)
+    _same(_gpu("heavy", K, 1, deep_bins=1), po.reorder_rounds(read, ln, L, K, 1), ("heavy", K))
+
+
 def test_paired_pool_through_pe_encode():
     """BASELINE config 4 at test size (tools/pe_config4.py runs it at 1 M and 50 M pairs): a paired synthetic pool
     (file-1 reads then their mates, reorder.h:233-242) -> reorder == rounds oracle -> encoder -> pe_encode == the
