@@ -245,23 +245,32 @@ __global__ void k_iota_tag(uint64_t *v, uint64_t n, uint64_t tag) {
   if (i < n) v[i] = i | tag;
 }
 
-// Dead-tail trim of deep bins.  Chains consume a bin from its tail (highest read ids first), so on very
-// deep bins (PhiX-like coverage) every probe would re-skip an ever growing run of taken reads.  Entries above
-// the first live one are taken for good, so shrinking the bin's count never changes a result; the reference
-// gets the same effect from bbhashdict::remove (bitset_util.cpp:37-63).  Runs between rounds, over the list
-// of deep bins only (collected by k_tab_insert), so the hot search kernel carries no extra state.
-__global__ void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *__restrict__ ndeep,
-                            ulonglong2 *__restrict__ urec, const uint32_t *__restrict__ ids,
-                            const uint64_t *__restrict__ taken) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// Compaction of deep bins.  A taken read stays taken, so dropping it from its bin never changes a result: the
+// reference does exactly that (bbhashdict::remove, bitset_util.cpp:37-63), and without it every probe of a deep bin
+// (PhiX-like coverage: ~900 reads per bin, nine in ten taken late in a run) walks the taken entries again, two dependent
+// loads each.  Runs between rounds, over the list of deep bins only (collected by k_tab_insert): one wavefront per
+// bin keeps the untaken entries, in order, at the front of the bin and shrinks its count.  (The in-scan trim of the
+// TRIM kernel variants only cuts the dead tail.)
+__global__ __launch_bounds__(256) void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *__restrict__ ndeep,
+                                                   ulonglong2 *__restrict__ urec, uint32_t *__restrict__ ids,
+                                                   const uint64_t *__restrict__ taken) {
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= *ndeep) return;
   const uint32_t u = deep[i];
   const ulonglong2 rec = urec[u];
-  const uint32_t start = (uint32_t)rec.y;
-  int j = (int)(uint32_t)(rec.y >> 32) - 1;
-  const int j0 = j;
-  while (j >= 0 && is_taken(taken, ids[start + j])) j--;
-  if (j != j0) urec[u].y = (uint64_t)start | ((uint64_t)(uint32_t)(j + 1) << 32);
+  const uint32_t start = (uint32_t)rec.y, count = (uint32_t)(rec.y >> 32);
+  uint32_t w = 0;  // entries kept so far (wave-uniform); always <= the position being read
+  for (uint32_t base = 0; base < count; base += 64) {
+    const uint32_t j = base + lane;
+    const uint32_t r = j < count ? ids[start + j] : 0u;
+    const bool live = j < count && !is_taken(taken, r);
+    const uint64_t m = __ballot(live);
+    const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    if (live && pos != j) ids[start + pos] = r;  // (every lane has read its entry before any lane writes)
+    w += (uint32_t)__popcll(m);
+  }
+  if (lane == 0 && w != count) urec[u].y = (uint64_t)start | ((uint64_t)w << 32);
 }
 
 // test hook: start/count of the bin of each key; single-read bins report count = 1 | 0x80000000
@@ -725,15 +734,73 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 #define SR_ROUND_WAVES 8  // minimum waves per SIMD the round kernel is compiled for (64 VGPRs)
 #endif
 
+// Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
+// (mask[0][..] / mask[shift][..] of reorder.h:291-301); with check_key also the reference's key re-check of
+// a single-read bin (reorder.h:282-285): -1 = the read's window is not `key` (fingerprint collision), else 0 / 1.
+__device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t *sx, int bitshift, int lo, int mref, int ds,
+                                           int klen2, uint32_t r, bool check_key, lds_u32_t *stage, int lane) {
+  const int W = P.W;
+  const int clen = P.uniform_len ? P.L : (int)P.lens[r];
+  const int m = clen < mref ? clen : mref;
+  const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
+  const int blo = 2 * lo, bhi = 2 * m;
+  // The key re-check of a single-read bin needs no load of its own: `key` is the consensus window that the
+  // alignment puts on the read's own key window [ka, kb), so the keys are equal iff the XOR below is zero on those
+  // bits (a valid probe keeps the window inside the compared range).
+  const int ka = 2 * ds, kb = ka + klen2;
+  uint32_t kdiff = 0;
+  int hd = 0;
+  // only the first and the last limb of the compared range [blo, bhi) are partial; the limbs between need no mask
+  const int first = blo >> 6, last = (bhi - 1) >> 6;
+  for (int i0 = 0; i0 < W; i0 += STAGE_LIMBS) {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(rdp + i0);
+    // dword d of the chunk -> staging row d: the instruction offset moves the global address by 4 d bytes and the
+    // LDS address with it, so row d's base is given 252 d bytes further (one address register for all ten loads)
+#define STAGE_ROW(D) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (D) * 63), 4, (D) * 4, 0)
+    static_assert(STAGE_LIMBS == 5, "ten rows below");
+    if (W - i0 >= STAGE_LIMBS) {
+      STAGE_ROW(0); STAGE_ROW(1); STAGE_ROW(2); STAGE_ROW(3); STAGE_ROW(4);
+      STAGE_ROW(5); STAGE_ROW(6); STAGE_ROW(7); STAGE_ROW(8); STAGE_ROW(9);
+    } else {
+      const int nd = 2 * (W - i0);
+      STAGE_ROW(0); STAGE_ROW(1);
+      if (nd > 2) { STAGE_ROW(2); STAGE_ROW(3); }
+      if (nd > 4) { STAGE_ROW(4); STAGE_ROW(5); }
+      if (nd > 6) { STAGE_ROW(6); STAGE_ROW(7); }
+    }
+#undef STAGE_ROW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ihi = min(i0 + STAGE_LIMBS - 1, last);
+#pragma nounroll  // LDS reads are cheap; unrolled, their ten result registers would all be live at once
+    for (int i = max(i0, first); i <= ihi; i++) {
+      const int u = i - i0;
+      const uint64_t xr = (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32);
+      uint64_t y = lds_window(sx, i * 64 + bitshift) ^ xr;
+      if (i == first) y &= ~0ull << (blo & 63);
+      if (i == last) y &= ~0ull >> (63 - ((bhi - 1) & 63));
+      hd += __popcll(y);
+      if (check_key && i >= (ka >> 6) && i <= ((kb - 1) >> 6)) {
+        if (i == (ka >> 6)) y &= ~0ull << (ka & 63);
+        if (i == ((kb - 1) >> 6)) y &= ~0ull >> (63 - ((kb - 1) & 63));
+        kdiff |= (uint32_t)y | (uint32_t)(y >> 32);
+      }
+    }
+  }
+  if (kdiff) return -1;
+  return hd <= THRESH;
+}
+
 // ---- one probe of search_match (reorder.h:262-316): dictionary l, direction rev, at `shift`.  The window's
 // key and hash come from the caller because one consensus window is the probe key of both dictionaries
 // (at shifts wl apart).  sx = ref (forward) or revref (reverse) in LDS.
-template <bool TRIM>
+// DEFER (probe_batch's balanced scan): a multi-read bin whose key is verified is not walked here -- its extent comes back
+// in `pend` (start, count, record index) and the caller deals its entries out over the lanes.
+struct PendBin { bool on; uint32_t start, count, pay; };
+template <bool TRIM, bool DEFER = false>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
                                            bool &keyok, uint32_t &ncand, bool &other, lds_u32_t *s_best, lds_u32_t *stage,
-                                           int lane) {
-  const int W = P.W;
+                                           int lane, PendBin *pend = nullptr) {
   // (l differs between lanes: P.x[l] would be a vector load from the kernel-argument buffer -- select instead)
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   const int klen2 = 2 * P.wl;
@@ -745,58 +812,8 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
   const int bitshift = rev ? -2 * shift : 2 * shift;
   const int lo = rev ? shift : 0;
   const int mref = rev ? ref_len + shift : ref_len - shift;
-  // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
-  // (mask[0][..] / mask[shift][..] of reorder.h:291-301); with check_key also the reference's key re-check of
-  // a single-read bin (reorder.h:282-285): -1 = the read's window is not `key` (fingerprint collision), else 0 / 1.
   auto within_thresh = [&](uint32_t r, bool check_key) -> int {
-    const int clen = P.uniform_len ? P.L : (int)P.lens[r];
-    const int m = clen < mref ? clen : mref;
-    const uint64_t *__restrict__ rdp = P.reads + (uint64_t)r * P.S;
-    const int blo = 2 * lo, bhi = 2 * m;
-    // The key re-check of a single-read bin needs no load of its own: `key` is the consensus window that the
-    // alignment puts on the read's own key window [ka, kb), so the keys are equal iff the XOR below is zero on those
-    // bits (a valid probe keeps the window inside the compared range).
-    const int ka = 2 * ds, kb = ka + klen2;
-    uint32_t kdiff = 0;
-    int hd = 0;
-    // only the first and the last limb of the compared range [blo, bhi) are partial; the limbs between need no mask
-    const int first = blo >> 6, last = (bhi - 1) >> 6;
-    for (int i0 = 0; i0 < W; i0 += STAGE_LIMBS) {
-      const uint32_t *g = reinterpret_cast<const uint32_t *>(rdp + i0);
-      // dword d of the chunk -> staging row d: the instruction offset moves the global address by 4 d bytes and the
-      // LDS address with it, so row d's base is given 252 d bytes further (one address register for all ten loads)
-#define STAGE_ROW(D) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (D) * 63), 4, (D) * 4, 0)
-      static_assert(STAGE_LIMBS == 5, "ten rows below");
-      if (W - i0 >= STAGE_LIMBS) {
-        STAGE_ROW(0); STAGE_ROW(1); STAGE_ROW(2); STAGE_ROW(3); STAGE_ROW(4);
-        STAGE_ROW(5); STAGE_ROW(6); STAGE_ROW(7); STAGE_ROW(8); STAGE_ROW(9);
-      } else {
-        const int nd = 2 * (W - i0);
-        STAGE_ROW(0); STAGE_ROW(1);
-        if (nd > 2) { STAGE_ROW(2); STAGE_ROW(3); }
-        if (nd > 4) { STAGE_ROW(4); STAGE_ROW(5); }
-        if (nd > 6) { STAGE_ROW(6); STAGE_ROW(7); }
-      }
-#undef STAGE_ROW
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ihi = min(i0 + STAGE_LIMBS - 1, last);
-#pragma nounroll  // LDS reads are cheap; unrolled, their ten result registers would all be live at once
-      for (int i = max(i0, first); i <= ihi; i++) {
-        const int u = i - i0;
-        const uint64_t xr = (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32);
-        uint64_t y = lds_window(sx, i * 64 + bitshift) ^ xr;
-        if (i == first) y &= ~0ull << (blo & 63);
-        if (i == last) y &= ~0ull >> (63 - ((bhi - 1) & 63));
-        hd += __popcll(y);
-        if (check_key && i >= (ka >> 6) && i <= ((kb - 1) >> 6)) {
-          if (i == (ka >> 6)) y &= ~0ull << (ka & 63);
-          if (i == ((kb - 1) >> 6)) y &= ~0ull >> (63 - ((kb - 1) & 63));
-          kdiff |= (uint32_t)y | (uint32_t)(y >> 32);
-        }
-      }
-    }
-    if (kdiff) return -1;
-    return hd <= THRESH;
+    return cmp_candidate(P, sx, bitshift, lo, mref, ds, klen2, r, check_key, stage, lane);
   };
   // *s_best (LDS) = lowest priority code that has hit so far in this batch of probes: the lanes run in lock step, so
   // a lane still walking a bin after another lane with a lower code has hit can never be the winner and leaves
@@ -818,6 +835,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       const u64x2_t rec = urec[pay];
       if (rec.x != key) continue;  // fingerprint collision
       start = (uint32_t)rec.y; count = (uint32_t)(rec.y >> 32);
+      if (DEFER) { pend->on = true; pend->start = start; pend->count = count; pend->pay = pay; break; }
     }
     bool verified = !single, gave_up = false;
     int live = 0, top_live = -1;
@@ -868,7 +886,7 @@ struct BatchOut {
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                             int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, lds_u32_t *s_best,
-                                            lds_u32_t *stage, int min_code, BatchOut &out) {
+                                            lds_u32_t *stage, int min_code, uint8_t *owner_of /* [64], LDS */, BatchOut &out) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
@@ -882,19 +900,104 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   const bool valid = valid0 && !skipped;
   bool hit = false, keyok = false, other = skipped;
   uint32_t rid = 0, ncand = 0;
+  constexpr bool BAL = TRIM && !STATS;  // the balanced scan: deep-bin pools, production build
+  PendBin pend;
+  pend.on = false; pend.start = pend.count = pend.pay = 0;
   if (lane == 0) *s_best = 0x7fffffffu;
   wave_sync();
   if (valid) {
     const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
     const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
-    eval_probe<TRIM>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, s_best, stage, lane);
+    eval_probe<TRIM, BAL>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, s_best, stage, lane, &pend);
+  }
+  bool bal_capped = false;
+  if (BAL) {
+    // ---- balanced scan of the verified multi-read bins (deep-bin pools: every bin keeps reads that can never pass
+    // the Hamming test, and a lane walking them one after the other -- three dependent memory steps each -- is what a
+    // round waits for).  The bins' entries are dealt out in the reference's order -- probes by priority (= lane
+    // order), entries from the bin's tail -- 64 at a time, one per lane; the first passing entry in that order whose
+    // probe has not used up its MAX_SEARCH live comparisons is the winner among these bins.
+    const uint64_t hs = __ballot(hit);  // single-read bins that hit: only bins ahead of the first of them matter
+    const int wins = hs ? __ffsll((unsigned long long)hs) - 1 : 64;
+    uint64_t pm = __ballot(pend.on && lane < wins);
+    int jn = (int)pend.count - 1, livec = 0, top_live = -2;  // owner state: next entry, live so far, first live entry (-2: unknown)
+    const int klen2 = 2 * P.wl;
+    typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+    while (pm) {
+      const bool own = (pm >> lane) & 1ull;
+      const int rem = own ? jn + 1 : 0;
+      const int incl = wave_incl_scan_i(rem > 64 ? 64 : rem, lane);  // (64 is all a chunk can take from one bin)
+      const int off = incl - (rem > 64 ? 64 : rem);
+      const int take = own && off < 64 ? min(rem, 64 - off) : 0;
+      const int total = min(__shfl(incl, 63, 64), 64);
+      // owner of item t: the owning lane whose run [off, off + take) covers t
+      owner_of[lane] = 0xff;
+      wave_sync();
+      if (take > 0) owner_of[off] = (uint8_t)lane;
+      wave_sync();
+      int ow = owner_of[lane] == 0xff ? -1 : (int)owner_of[lane];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(ow, o, 64); if (lane >= o) ow = max(ow, t); }
+      wave_sync();
+      bool lv = false, ps = false;
+      uint32_t r = 0;
+      // (every lane takes part in the shuffles: a lane outside a branch supplies nothing)
+      const int src = ow >= 0 ? ow : 0;
+      const int pj = __shfl(jn, src, 64), poff = __shfl(off, src, 64);
+      const uint32_t pst = (uint32_t)__shfl((int)pend.start, src, 64);
+      if (lane < total && ow >= 0) {
+        const int j = pj - (lane - poff);
+        const int pl = ow & 1, prev = (ow >> 1) & 1, psh = sh_base + (ow >> 2);
+        g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
+        r = pids[pst + (uint32_t)j];
+        if (!is_taken(P.taken, r)) {
+          lv = true;
+          const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+          ps = cmp_candidate(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                             prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
+        }
+      }
+      const uint64_t Lm = __ballot(lv), Pm = __ballot(ps);
+      bool myhit = false, fin = own && rem == 0;  // (a bin already trimmed to nothing)
+      int hit_t = 0;
+      if (take > 0) {
+        const uint64_t mine = (take >= 64 ? ~0ull : ((1ull << take) - 1)) << off;
+        const uint64_t ml = Lm & mine, mp = Pm & mine;
+        if (top_live == -2 && ml) top_live = jn - (__ffsll((unsigned long long)ml) - 1 - off);
+        if (mp) {
+          hit_t = __ffsll((unsigned long long)mp) - 1;
+          const int before = livec + __popcll(ml & ((1ull << hit_t) - 1));
+          if (before < MAX_SEARCH) myhit = true; else { bal_capped = true; fin = true; }
+        }
+        livec += __popcll(ml);
+        jn -= take;
+        if (!myhit) {
+          if (livec >= MAX_SEARCH) { bal_capped = true; fin = true; }
+          if (jn < 0) { fin = true; if (top_live == -2) top_live = -1; }
+        }
+      }
+      const uint64_t hb = __ballot(myhit);
+      if (hb) {  // the lowest owner that hit wins (only the last owner of a chunk can be unfinished)
+        const int wl_ = __ffsll((unsigned long long)hb) - 1;
+        const int ht = __shfl(hit_t, wl_, 64);
+        const uint32_t wr = (uint32_t)__shfl((int)r, ht, 64);
+        if (lane == wl_) { hit = true; rid = wr; }
+        break;
+      }
+      pm &= ~__ballot(fin);
+    }
+    // dead tail of the bins this scan reached the live part of (same rule as the serial walk)
+    if (pend.on && top_live >= -1 && (uint32_t)(top_live + 1) < pend.count) {
+      const uint64_t ur = reinterpret_cast<uint64_t>(l ? P.urec[1] : P.urec[0]);
+      atomicMin(reinterpret_cast<uint32_t *>(ur + (uint64_t)pend.pay * 16) + 3, (uint32_t)(top_live + 1));
+    }
   }
   const uint64_t hm = __ballot(hit);
   const int win = hm ? __ffsll((unsigned long long)hm) - 1 : 63;
   out.found = hm != 0;
   out.code = probe_code(sh_base + (win >> 2), (win >> 1) & 1, win & 1);
   out.rid = (uint32_t)__shfl((int)rid, win, 64);
-  out.capped = TRIM && __any(valid && (hm == 0 || lane < win) && !hit && ncand >= (uint32_t)MAX_SEARCH);
+  out.capped = TRIM && (__any(valid && (hm == 0 || lane < win) && !hit && ncand >= (uint32_t)MAX_SEARCH) || __any(bal_capped));
   // what this fetch told about the OTHER dictionary's probe of the same window, for the tail (probe_tail)
   if ((lane >> 2) < nsh && shift < 32) pres[4 * shift + (lane & 3)] = other ? 1 : 0;
   out.st_p = out.st_k = out.st_c = 0;
@@ -1113,7 +1216,8 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   int t0 = 0;
 #pragma nounroll
   for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
-    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, min_code, o);
+    probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, min_code,
+                             reinterpret_cast<uint8_t *>(s_list), o);
     capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     t0 += plan[ph];
@@ -1554,7 +1658,7 @@ void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag) {
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
                       ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken) {
   if (!ndeep_host) return;
-  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 256), dim3(256), 0, st, deep, ndeep, urec, ids, taken);
+  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 4), dim3(256), 0, st, deep, ndeep, urec, const_cast<uint32_t *>(ids), taken);
 }
 void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
