@@ -5,6 +5,9 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2_sweeps; mkdir -p $O
 python tools/scale_probe.py 20000000,150,0,10000,0,25 20000000,150,0,10000,0,400 20000000,150,0,10000,0,1600 20000000,150,0,10000,0,6400 20000000,150,0,10000,0,25600 > $O/coverage_sweep.txt 2>&1
+python tools/scale_probe.py 20000000,150,65536,10000,0,1600 20000000,150,65536,10000,0,400 >> $O/coverage_sweep.txt 2>&1
+timeout 300 python tools/deep_bins_probe.py 10000000,150,5400,0 10000000,150,5400,65536 > $O/phix_like.txt 2>&1
+timeout 1500 python tools/parity_deep.py 1000000,150,5400,4096 10000000,150,5400,0 10000000,150,5400,65536 20000000,150,1875000,0 > $O/parity_deep.txt 2>&1
 python tools/scale_probe.py 100000000,150,65536 100000000,150,49152 100000000,150,32768 100000000,150,131072 > $O/chain_sweep.txt 2>&1
 bash tools/pmc_insts.sh $O/insts 100000000 > $O/insts.log 2>&1
 # phase clocks: the round kernel compiled with -DSR_PHASE_TIMING (search time by outcome)
