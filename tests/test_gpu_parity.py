@@ -269,6 +269,29 @@ def test_single_pool_is_independent_of_gpu_count(name, K, G):
     assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
 
 
+@pytest.mark.parametrize("G", [2, 4])
+def test_single_pool_on_a_contended_deep_pool(G):
+    """The multi-GPU instantiation of the trimming kernel variant (balanced bin scan, resumed searches) plus bin
+    compaction on every rank's replica: G virtual ranks over one contended pool == one GPU == rounds oracle."""
+    from spring_amd.pool import VirtualPool
+    sa = _sa()
+    n, L, Gn, K, T = 60_000, 150, 600, 256, 2
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, deep_bins=1)) as s:
+        s.load_synth(n, L, Gn, 29, 10000)
+        single = s.run().streams()
+        dna = s.download_dna()
+    vp = VirtualPool(G, K, T, deep_bins=1)
+    try:
+        got = vp.run(lambda s: s.load_synth(n, L, Gn, 29, 10000))
+    finally:
+        vp.close()
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, T)
+    for k in KEYS:
+        assert np.array_equal(got[k], single[k]), (G, k)
+        assert np.array_equal(got[k], want[k]), (G, k)
+
+
 def test_single_pool_1M_4_virtual_ranks():
     from spring_amd.pool import VirtualPool
     sa = _sa()
