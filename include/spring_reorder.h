@@ -31,7 +31,8 @@ typedef struct spring_reorder_ctx spring_reorder_ctx;
 typedef struct {
   int32_t device;       /* HIP device ordinal; -1 = current device                                */
   uint32_t num_chains;  /* K concurrent greedy chains (= reference threads, reorder.h:351);
-                           1 reproduces `-t 1` byte for byte; 0 = auto (from N)                    */
+                           1 reproduces `-t 1` byte for byte; 0 = auto: N/1024, or N/128 when the
+                           dictionary averages >= 1.3 reads per key (deep coverage), at most 65536 */
   int32_t num_thr;      /* number of per-tid output sets to emit (cp.num_thr, reorder.h:748)      */
   int32_t collect_stats;/* 1: count reference-equivalent probes / key hits / Hamming evaluations  */
   int32_t time_search;  /* 1: bracket every search-kernel launch with HIP events (bench roofline) */

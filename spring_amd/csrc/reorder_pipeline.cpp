@@ -927,6 +927,11 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
 // ------------------------------------------------------------------ chains
 // fields of DevParams shared by run_chains and mg_begin; the tuning values come from spring_reorder_opts (results
 // do not depend on them) -- DESIGN.md section 6
+// the dictionary averages >= 1.3 reads per key: deep-coverage pool (a few hundred x and up)
+static bool dict_is_deep(const spring_reorder_ctx *ctx) {
+  const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
+  return nd * 10 >= nk * 13;
+}
 static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   const spring_reorder_opts &o = ctx->o;
   P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = ctx->n;
@@ -949,11 +954,16 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.fpt = ctx->fpt; P.bshift = ctx->bshift;
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
-  const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
-  P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : (nd * 10 >= nk * 13);
+  P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_is_deep(ctx);
 }
-static uint32_t auto_chains(uint32_t n) {
-  uint64_t k = n >> 10;  // ~1000 reads per chain
+// Default chain count.  ~1000 reads per chain: the compressed size grows with the chain count on ordinary coverage
+// (+7 % from n/1024 to 65 536 chains at 16 M reads).  On deep-coverage pools (the dictionary
+// averages >= 1.3 reads per key: a few hundred x and up) it is the other way round -- 65 536 chains instead of
+// n/1024 give 1.3 % / 2.0 % / 1.2 % SMALLER streams at 400x / 1 600x / 6 400x (real BSC, 20 M reads; flat on a
+// PhiX-like pool; n/128 and n/256 within 0.4 % of each other at 4 M reads) and run 13 % / 9 % faster, 2.6x on the
+// PhiX-like pool -- so those get ~128 reads per chain.
+static uint32_t auto_chains(uint32_t n, bool deep) {
+  uint64_t k = deep ? n >> 7 : n >> 10;
   if (k < 1) k = 1;
   if (k > 65536) k = 65536;
   return (uint32_t)k;
@@ -1046,7 +1056,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
   const uint32_t n = ctx->n;
-  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n);
+  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n, dict_is_deep(ctx));
   const bool stats = ctx->o.collect_stats != 0;
   const bool timed = ctx->o.time_search != 0;
   const bool literal = ctx->o.force_literal_update != 0;
