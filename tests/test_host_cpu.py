@@ -78,3 +78,26 @@ def test_wrong_bitset_size_raises_like_reference():
     from spring_amd.reorder import CompressionParams
     with pytest.raises(spring_amd.ReorderError, match="Wrong bitset size"):
         spring_amd.call_reorder("/tmp", CompressionParams(600, [0, 0]))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed under profiles/ (what `python bench.py` printed on the MI355X box) carries every field
+    of the bench contract, and its derived figures are consistent with each other."""
+    import json
+    b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_100Mx150.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["higher_is_better"] is True and b["vs_baseline"] is None and "workload" in b["config"]
+    n = b["config"]["reads"] if "reads" in b["config"] else 100_000_000
+    assert abs(b["value"] - n / (b["ms_per_step"] / 1e3) / 1e6) / b["value"] < 0.01
+    r = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 0.01
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"]
+    c = b["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
