@@ -13,6 +13,7 @@ constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
 constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
 constexpr uint32_t DEEP_BIN = 16;   // bins with at least this many reads are tail-trimmed between rounds
 constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
+constexpr int UBLK_SHIFT = 14;      // DevParams::ublk counts untaken reads per 2^14 reads (256 bitmap words)
 constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in LDS
 constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
 
@@ -46,8 +47,13 @@ struct __attribute__((aligned(64))) Chain {
   uint64_t ref[16];      // consensus, 2 bits/base (reorder.h:371)
   uint64_t revref[16];   // its reverse complement
   uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost, st_hits, n_unmatched, st_pad;
+#ifdef SR_PHASE_TIMING  // experiment builds (tools/xbuild.sh): shader clocks per phase of k_round, [32 + k] = visits
+  uint64_t pt[64];
+#endif
 };
+#ifndef SR_PHASE_TIMING
 static_assert(sizeof(Chain) == 384, "Chain layout");
+#endif
 
 struct Globals {
   long long cursor;   // every read above it is taken (== min over threads of remainingpos, reorder.h:402)
@@ -79,6 +85,7 @@ struct DevParams {
   const uint32_t *ids[2];
   // shared mutable state
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
+  uint32_t *ublk;     // untaken reads per block of 2^UBLK_SHIFT reads, exact between rounds (seed selection, find_seed)
   uint32_t *resv;     // lowest chain id that proposed read r this round (0xffffffff = none)
   uint32_t *needy;    // bitmap over chains waiting for a seed (padded with zero words to a multiple of 256 words)
   // rounds whose shared state is kept by k_mg_mark (fused rounds, multi-GPU pools; null in the two-kernel round):
@@ -93,9 +100,11 @@ struct DevParams {
   Chain *chains;
   int4 *cnt;          // [K][2][Lpad] per-position counts (A,C,T,G), ping-pong: wide format (some count > 255)
   uint32_t *cnt8;     // same, one byte per count: the format of almost every update (4x fewer bytes moved)
-  // append-order emission buffers (+ chain, seq for the final scatter)
-  uint32_t *e_order; char *e_rc; char *e_flag; long long *e_pos; uint16_t *e_len; uint32_t *e_chain; uint32_t *e_seq;
-  uint32_t *s_order; uint32_t *s_chain; uint32_t *s_seq;
+  // append-order emission buffers.  A chain fills private CHUNK-slot chunks; a matched record is ONE 16-byte store
+  // {read id, rc | flag << 8, pos}; e_chunk[c] = {owning chain (local index), sequence number of the chunk's first
+  // record} is written once per chunk, so the final scatter needs no per-record tags.  Singletons: the read id.
+  uint4 *e_rec; uint2 *e_chunk;
+  uint32_t *s_rec; uint2 *s_chunk;
   // final streams (tid-major, chain ascending inside a tid)
   uint32_t *f_order; char *f_rc; char *f_flag; long long *f_pos; uint16_t *f_len; uint32_t *f_order_s;
 };
@@ -123,7 +132,7 @@ void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count);
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
-void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n);
+void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n, uint32_t *ublk);
 void launch_init_chains(hipStream_t st, const DevParams &P);
 // two-kernel round (one GPU): search -> apply
 void launch_search(hipStream_t st, const DevParams &P, bool stats);

@@ -147,6 +147,30 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ r, 
   return v;
 }
 
+// Phase clocks of the round kernel (experiment builds only, -DSR_PHASE_TIMING): PT(k) adds the shader clocks since
+// the last mark to bucket k of the wavefront's LDS table; k_round adds the table to Chain::pt when it ends.
+#ifdef SR_PHASE_TIMING
+__shared__ uint32_t g_pt_lds[66];  // k_round: one wavefront per block.  [k] clocks, [32 + k] visits, [64] last mark
+#define PT(k)                                                                                         \
+  do {                                                                                                \
+    const uint32_t t_ = (uint32_t)clock64();                                                          \
+    const unsigned long long ex_ = __ballot(1);                                                       \
+    if ((int)(threadIdx.x & 63) == __ffsll(ex_) - 1) {                                                \
+      g_pt_lds[(k)] += t_ - g_pt_lds[64]; g_pt_lds[32 + (k)] += 1u; g_pt_lds[64] = t_;                 \
+    }                                                                                                 \
+  } while (0)
+#define PTW(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PT(k); } while (0)
+#define PT_FLUSH(c)                                                              \
+  do {                                                                           \
+    wave_sync();                                                                 \
+    (c)->pt[threadIdx.x & 63] += g_pt_lds[threadIdx.x & 63];                     \
+  } while (0)
+#else
+#define PT(k) do {} while (0)
+#define PTW(k) do {} while (0)
+#define PT_FLUSH(c) do {} while (0)
+#endif
+
 // ------------------------------------------------------- K1 unpack (readDnaFile)
 // reorder.h:222-244: u16 len + ceil(len/4) raw bytes -> zero padded limbs.
 __global__ void k_unpack(const uint8_t *__restrict__ dna, const uint64_t *__restrict__ off, uint32_t n,
@@ -308,9 +332,13 @@ __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
   if (i < n) p[i] = v;
 }
 
-__global__ void k_init_taken(uint64_t *taken, uint64_t nwords, uint32_t n) {
+__global__ void k_init_taken(uint64_t *taken, uint64_t nwords, uint32_t n, uint32_t *ublk) {
   uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= nwords) return;
+  if ((w & ((1u << (UBLK_SHIFT - 6)) - 1)) == 0) {  // untaken reads of the block this word starts (find_seed)
+    const uint64_t first = w << 6;
+    ublk[w >> (UBLK_SHIFT - 6)] = first >= n ? 0u : (uint32_t)(n - first < (1ull << UBLK_SHIFT) ? n - first : (1ull << UBLK_SHIFT));
+  }
   uint64_t v = 0;
   if ((w + 1) * 64 > n) {  // bits >= n never become seeds
     int valid = (int)((int64_t)n - (int64_t)w * 64);
@@ -522,6 +550,7 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
   }
   if (lane < 16) ws->rd[lane] = myl;
   wave_sync();
+  PTW(1);
 
   if (LITERAL) {
     for (int p = lane; p < M; p += 64) {
@@ -569,6 +598,7 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
     }
   }
   overflow = __any(mx > 255);
+  PT(2);
   return Rn;
 #undef LOAD_CNT
 }
@@ -600,6 +630,10 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   const bool start = P.n > 0 && (cid == 0 || step > 0);
   ChainHot h;
   memset(&h, 0, sizeof(h));
+  if (lane == 0) {  // the chain's first chunk of either append buffer is pre-assigned
+    P.e_chunk[li] = make_uint2(li, 0u);
+    P.s_chunk[li] = make_uint2(li, 0u);
+  }
   if (!start) {
     h.done = 1;
     if (lane == 0) {
@@ -630,6 +664,7 @@ __global__ void k_init_seeds(DevParams P) {
   if (!(P.n > 0 && (cid == 0 || step > 0))) return;
   const uint32_t seed = cid * step;
   atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
+  atomicSub(&P.ublk[seed >> UBLK_SHIFT], 1u);
 }
 
 // (rank+1)-th highest untaken read at or below the cursor, rank = number of seed-needing chains
@@ -678,47 +713,66 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   const uint32_t rank = (uint32_t)wave_sum_i(r), nneedy = (uint32_t)wave_sum_i(tot);
   *is_last = rank + 1 == nneedy;
   uint32_t need = rank + 1;
-  long long seed = -1;
-  // 64 lanes x 4 bitmap words = 16 384 reads per step, highest first (late in a run few reads are left and the
-  // wanted one is many words below the cursor: every step is a dependent round trip)
-  while (top >= 0) {
-    const long long wtop = top >> 6, wl0 = wtop - 4 * lane;
-    uint64_t u[4];
+  // At most two dependent steps per 1 M reads, whatever the rank and however few reads are left.  P.ublk[b] = reads of
+  // block b (reads [b << UBLK_SHIFT, (b + 1) << UBLK_SHIFT)) not yet claimed by a MATCH (kept by whoever sets such a
+  // taken bit).  Seeds are always taken from the top and every read above the cursor is taken, so below the cursor's
+  // block ublk[] is the exact number of untaken reads; the cursor's own block is counted from its 256 bitmap words
+  // (four per lane, highest first), which are fetched together with the counts of the 63 blocks below it.
+  if (top < 0) return -1;
+  const long long bt = top >> UBLK_SHIFT;
+  constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // bitmap words per block
+  auto pick_in_block = [&](long long blk, const uint64_t *uu, int cnt, uint32_t want) -> long long {
+    const long long wtop = blk * WPB_ + (WPB_ - 1);
+    const int inc2 = wave_incl_scan_i(cnt, lane);
+    const uint64_t m = __ballot((uint32_t)inc2 >= want);
+    const int wl = __ffsll((unsigned long long)m) - 1;
+    int kth = (int)want - __shfl(inc2 - cnt, wl, 64);  // kth highest untaken read of lane wl's four words
+    long long seed = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint64_t v = shfl_u64(uu[k], wl);
+      const int c = __popcll(v);
+      if (seed < 0) {
+        if (kth <= c) {
+          for (int t = 1; t < kth; t++) v &= ~(1ull << (63 - __clzll(v)));
+          seed = (wtop - 4 * wl - k) * 64 + (63 - __clzll(v));
+        } else kth -= c;
+      }
+    }
+    return seed;
+  };
+  auto load_block = [&](long long blk, uint64_t *uu) -> int {
+    const long long wl0 = blk * WPB_ + (WPB_ - 1) - 4 * lane;
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const long long w = wl0 - k;
-      u[k] = w >= 0 ? ~P.taken[w] : 0ull;
+      uu[k] = ~P.taken[wl0 - k];  // (the bitmap is padded to whole blocks; bits >= n are set)
+      cnt += __popcll(uu[k]);
     }
-    if (lane == 0) {
-      const int bits = (int)(top & 63) + 1;
-      if (bits < 64) u[0] &= (1ull << bits) - 1;
+    return cnt;
+  };
+  static_assert(WPB_ == 256, "four bitmap words per lane");
+  uint64_t uu[4];
+  {
+    const long long b = bt - 1 - lane;
+    int u = b >= 0 ? (int)P.ublk[b] : 0;  // (in flight together with the cursor block's words)
+    const int cnt = load_block(bt, uu);
+    const uint32_t tot0 = (uint32_t)wave_sum_i(cnt);
+    if (tot0 >= need) return pick_in_block(bt, uu, cnt, need);
+    need -= tot0;
+    for (long long b0 = bt - 1; b0 >= 0; b0 -= 64) {
+      if (b0 != bt - 1) { const long long bb = b0 - lane; u = bb >= 0 ? (int)P.ublk[bb] : 0; }
+      const int incl = wave_incl_scan_i(u, lane);
+      const uint32_t total = (uint32_t)__shfl(incl, 63, 64);
+      if (total < need) { need -= total; continue; }
+      const uint64_t mb = __ballot((uint32_t)incl >= need);
+      const int wb = __ffsll((unsigned long long)mb) - 1;
+      need -= (uint32_t)__shfl(incl - u, wb, 64);  // the need-th highest untaken read of block b0 - wb
+      const int c2 = load_block(b0 - wb, uu);
+      return pick_in_block(b0 - wb, uu, c2, need);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) cnt += __popcll(u[k]);
-    const int incl = wave_incl_scan_i(cnt, lane);
-    const uint32_t total = (uint32_t)__shfl(incl, 63, 64);
-    if (total >= need) {
-      const uint64_t m = __ballot((uint32_t)incl >= need);
-      const int wl = __ffsll((unsigned long long)m) - 1;
-      int kth = (int)need - __shfl(incl - cnt, wl, 64);  // kth highest untaken read of lane wl's four words
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint64_t uu = shfl_u64(u[k], wl);
-        const int c = __popcll(uu);
-        if (seed < 0) {
-          if (kth <= c) {
-            for (int t = 1; t < kth; t++) uu &= ~(1ull << (63 - __clzll(uu)));
-            seed = (wtop - 4 * wl - k) * 64 + (63 - __clzll(uu));
-          } else kth -= c;
-        }
-      }
-      break;
-    }
-    need -= total;
-    top = (wtop - 256) * 64 + 63;
   }
-  return seed;
+  return -1;
 }
 
 // A candidate read is compared STAGE_LIMBS limbs at a time: its dwords go from global memory straight into the
@@ -770,6 +824,7 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
     }
 #undef STAGE_ROW
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PT(13);
     const int ihi = min(i0 + STAGE_LIMBS - 1, last);
 #pragma nounroll  // LDS reads are cheap; unrolled, their ten result registers would all be live at once
     for (int i = max(i0, first); i <= ihi; i++) {
@@ -824,6 +879,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     if (skip && beaten()) break;
     uint32_t pay;
     const int kind = tab_find(P.fpt, P.bshift, hsh, l, skip, pay, other);
+    if (skip == 0) PTW(12);
     if (kind == 0) break;  // key absent
     // a single-read bin (kind 2: pay is the read id) runs through the same scan as a bin of one entry; its key is
     // verified on the read itself, and only once the read is known to be untaken: a taken read contributes
@@ -1161,6 +1217,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
       }
       store_hot(c, h);
     }
+    PTW(11);
     return -2;
   }
 
@@ -1214,6 +1271,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   o.found = 0;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
   int t0 = 0;
+  PT(6);
 #pragma nounroll
   for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
     probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, min_code,
@@ -1221,6 +1279,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
     capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     t0 += plan[ph];
+    if (ph == 0) PT(7); else PT(8);
     if (o.found) break;
   }
   if (!o.found && t0 < P.maxshift) {
@@ -1228,6 +1287,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
     probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, min_code, o);
     capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
+    PT(9);
   }
   if (lane == 0) {
     if (o.found) {
@@ -1248,6 +1308,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
       if (new_iter) c->st_iter++;
     }
   }
+  PT(10);
   return o.found ? o.code : -1;  // debug builds time the search by outcome; unused otherwise
 }
 
@@ -1292,23 +1353,28 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
 // Emission slots: each chain fills private CHUNK-slot chunks of the append buffers and only
 // touches the global allocator once per CHUNK records (a same-address atomic per record from
 // every chain serialises at ~11 ns each and dominated this kernel).
-__device__ __forceinline__ uint32_t take_slot(uint32_t &slot, uint32_t *alloc) {
+__device__ __forceinline__ uint32_t take_slot(uint32_t &slot, uint32_t *alloc, uint2 *chunk, uint32_t li, uint32_t next_seq) {
   const uint32_t s0 = slot;
   uint32_t nx = s0 + 1;
-  if ((nx & (CHUNK - 1)) == 0) nx = atomicAdd(alloc, CHUNK);
+  if ((nx & (CHUNK - 1)) == 0) {
+    nx = atomicAdd(alloc, CHUNK);
+    chunk[nx / CHUNK] = make_uint2(li, next_seq);  // the chunk's owner and the sequence number of its first record
+  }
   slot = nx;
   return s0;
 }
-__device__ __forceinline__ void emit_rec(const DevParams &P, ChainHot &h, uint32_t cid, uint32_t rid, char rc,
+// one 16-byte store per matched record (length: looked up by the final scatter)
+__device__ __forceinline__ void emit_rec(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid, char rc,
                                          char flag, long long pos) {
-  const uint32_t idx = take_slot(h.e_slot, &P.glob->e_alloc);
-  P.e_order[idx] = rid; P.e_rc[idx] = rc; P.e_flag[idx] = flag; P.e_pos[idx] = pos;
-  P.e_len[idx] = P.uniform_len ? (uint16_t)P.L : P.lens[rid];
-  P.e_chain[idx] = cid; P.e_seq[idx] = h.n_emit++;
+  const uint32_t seq = h.n_emit++;
+  const uint32_t idx = take_slot(h.e_slot, &P.glob->e_alloc, P.e_chunk, li, seq + 1);
+  P.e_rec[idx] = make_uint4(rid, (uint32_t)(uint8_t)rc | ((uint32_t)(uint8_t)flag << 8), (uint32_t)pos,
+                            (uint32_t)((unsigned long long)pos >> 32));
 }
-__device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uint32_t cid, uint32_t rid) {
-  const uint32_t idx = take_slot(h.s_slot, &P.glob->s_alloc);
-  P.s_order[idx] = rid; P.s_chain[idx] = cid; P.s_seq[idx] = h.n_single++;
+__device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid) {
+  const uint32_t seq = h.n_single++;
+  const uint32_t idx = take_slot(h.s_slot, &P.glob->s_alloc, P.s_chunk, li, seq + 1);
+  P.s_rec[idx] = rid;
 }
 
 // One chain's phase B.  Resolves the proposal the chain made in the last search (lowest chain id holds resv[rid])
@@ -1368,16 +1434,21 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     }
     return true;
   }
+  PT(3);
   if (do_upd) {
     pack_consensus(ws, R_new, lane, c, lds_refs);
     h.ref_len = R_new;
     h.cnt_buf ^= 1;
     h.cnt_wide = nw;
   }
+  PT(4);
   if (kind == PROP_MATCH) {
     const uint32_t rid = h.prop_rid;
     const int shift = ushift;
-    if (!DEFER && lane == 0) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+    if (!DEFER && lane == 0) {
+      atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+      atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+    }
     const bool left = h.left_search;
     long long ref_pos = h.ref_pos, cur_pos;
     char rcch;
@@ -1417,6 +1488,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     }
   }
   if (lane == 0) store_hot(c, h);
+  PT(5);
   return true;
 }
 
@@ -1463,7 +1535,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const uint32_t cid = P.c0 + li;
   Chain *c = &P.chains[li];
 #ifdef SR_PHASE_TIMING
-  const long long T0 = clock64();
+  for (int i = lane; i < 66; i += 64) g_pt_lds[i] = 0;
+  wave_sync();
+  if (lane == 0) g_pt_lds[64] = (uint32_t)clock64();
 #endif
   // the header lives in LDS, not in registers: its 16 dwords are wave-uniform, and held in every lane's VGPRs
   // across the update and the search they are what pushes the kernel past 64 VGPRs into scratch
@@ -1481,28 +1555,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
-#ifdef SR_PHASE_TIMING
-  const long long T1 = clock64();
-#endif
+  PTW(0);
   if (!apply_step<NP, false, true>(P, c, cid, li, h, lane, &lds, nullptr, &s_refs[0][0])) {
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+    PT_FLUSH(c);
     return;
   }
-#ifdef SR_PHASE_TIMING
-  const long long T2 = clock64();
-#endif
-  const int outcome = search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
-#ifdef SR_PHASE_TIMING
-  if (lane == 0 && outcome >= -1) {  // search time by outcome (debug builds only): first batch, second batch, tail, failed
-    const uint64_t dt = (uint64_t)(clock64() - T2);
-    (void)T0; (void)T1;
-    const int sh = outcome >> 2;
-    if (outcome < 0) c->st_iter += dt;
-    else if (sh < P.plan[0][0]) { c->st_probes += dt; c->st_hits += 1; }
-    else if (sh < P.plan[0][0] + P.plan[0][1]) { c->st_keyok += dt; c->st_lost += 1ull << 32; }
-    else c->st_cands += dt;
-  }
-#endif
+  (void)search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
+  PT_FLUSH(c);
 }
 
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
@@ -1532,7 +1592,12 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
     if (pk == PK_MATCH || pk == PK_SEED) {
       const uint32_t rid = (uint32_t)pv;
       const bool won = P.resv[rid] == cid;
-      if (won) atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+      if (won) {
+        atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+        // (matches only: seeds all come from the top of the pool -- thousands of same-address atomics per round --
+        // and find_seed counts the cursor's block from the bitmap)
+        if (pk == PK_MATCH) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+      }
       if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)rid - 1;  // every seed proposed this round ends up taken
       needy = pk == PK_SEED && !won;
     } else if (pk == PK_NONE) {
@@ -1554,21 +1619,28 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
 }
 
 // ------------------------------------------------------------ K7 finalize / emit
+// slot i of the append buffers belongs to chunk i / CHUNK; its record is number first_seq + i % CHUNK of the owning chain
 __global__ void k_scatter_matched(DevParams P, uint64_t cap, const uint64_t *__restrict__ off_m) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
-  const uint32_t ch = P.e_chain[i];
-  if (ch == 0xffffffffu) return;  // unused slot of a chunk
-  uint64_t d = off_m[ch] + P.e_seq[i];
-  P.f_order[d] = P.e_order[i]; P.f_rc[d] = P.e_rc[i]; P.f_flag[d] = P.e_flag[i];
-  P.f_pos[d] = P.e_pos[i]; P.f_len[d] = P.e_len[i];
+  const uint2 ci = P.e_chunk[i / CHUNK];
+  if (ci.x == 0xffffffffu) return;  // chunk never handed out
+  const uint32_t seq = ci.y + (uint32_t)(i % CHUNK);
+  if (seq >= P.chains[ci.x].h.n_emit) return;  // unused slot of the chain's last chunk
+  const uint4 r = P.e_rec[i];
+  const uint64_t d = off_m[ci.x] + seq;
+  P.f_order[d] = r.x; P.f_rc[d] = (char)(r.y & 0xffu); P.f_flag[d] = (char)((r.y >> 8) & 0xffu);
+  P.f_pos[d] = (long long)((unsigned long long)r.z | ((unsigned long long)r.w << 32));
+  P.f_len[d] = P.uniform_len ? (uint16_t)P.L : P.lens[r.x];
 }
 __global__ void k_scatter_single(DevParams P, uint64_t cap, const uint64_t *__restrict__ off_s) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cap) return;
-  const uint32_t ch = P.s_chain[i];
-  if (ch == 0xffffffffu) return;
-  P.f_order_s[off_s[ch] + P.s_seq[i]] = P.s_order[i];
+  const uint2 ci = P.s_chunk[i / CHUNK];
+  if (ci.x == 0xffffffffu) return;
+  const uint32_t seq = ci.y + (uint32_t)(i % CHUNK);
+  if (seq >= P.chains[ci.x].h.n_single) return;
+  P.f_order_s[off_s[ci.x] + seq] = P.s_rec[i];
 }
 
 // record sizes of a temp.dna stream (writetofile, reorder.h:667-687)
@@ -1671,9 +1743,9 @@ void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
   if (!n) return;
   hipLaunchKernelGGL(k_fill_u32, GRID1(n, 256), dim3(256), 0, st, p, n, v);
 }
-void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n) {
+void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n, uint32_t *ublk) {
   if (!nwords) return;
-  hipLaunchKernelGGL(k_init_taken, GRID1(nwords, 256), dim3(256), 0, st, taken, nwords, n);
+  hipLaunchKernelGGL(k_init_taken, GRID1(nwords, 256), dim3(256), 0, st, taken, nwords, n, ublk);
 }
 #define NP_DISPATCH(CALL)                                  \
   do {                                                     \
@@ -1698,23 +1770,35 @@ static void launch_search_wpb(hipStream_t st, const DevParams &P, bool stats) {
 }
 void launch_search(hipStream_t st, const DevParams &P, bool stats) {
   if (!P.K) return;
+#ifdef SR_DEV_PROD_ONLY  // tools/xbuild.sh: experiment builds hold the production k_round only
+  (void)st; (void)stats; abort();
+#else
   if (P.search_wpb == 1) launch_search_wpb<1>(st, P, stats);
   else if (P.search_wpb == 2) launch_search_wpb<2>(st, P, stats);
   else launch_search_wpb<4>(st, P, stats);
+#endif
 }
 void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
   if (!P.K) return;
+#ifdef SR_DEV_PROD_ONLY
+  (void)st; (void)literal; abort();
+#else
   const dim3 g((P.K + 3) / 4), b(256);
   if (literal) { hipLaunchKernelGGL((k_apply<8, true>), g, b, 0, st, P); return; }
 #define CALL(N) hipLaunchKernelGGL((k_apply<N, false>), g, b, (size_t)P.dbg_apply_lds, st, P)  // dbg: occupancy experiment
   NP_DISPATCH(CALL);
 #undef CALL
+#endif
 }
 // fused round: one wavefront (= one block) per chain; NP = 3 covers reads up to 192 bases, 8 the rest
 void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   if (!P.K) return;
   const dim3 g(P.K), b(64);
   const size_t dyn = (size_t)P.dbg_search_lds;
+#ifdef SR_DEV_PROD_ONLY
+  if (stats || mg || P.deep_bins || P.Lpad > 192) abort();
+  hipLaunchKernelGGL((k_round<3, false, false, false>), g, b, dyn, st, P);
+#else
 #define RCALL2(N, T)                                                                         \
   do {                                                                                       \
     if (mg) { if (stats) hipLaunchKernelGGL((k_round<N, true, true, T>), g, b, dyn, st, P);  \
@@ -1726,6 +1810,7 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL
+#endif
 }
 void launch_mg_resolve(hipStream_t st, const DevParams &P) {
   hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);

@@ -977,9 +977,12 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   ctx->K = K;
   DevParams &P = ctx->P;
   fill_params(ctx, P);
-  const uint64_t nwords = ((uint64_t)n + 63) / 64;
+  // the bitmap is padded to whole blocks of 2^UBLK_SHIFT reads (find_seed reads a block's 256 words; bits >= n are set)
+  const uint64_t nublk = std::max<uint64_t>(((uint64_t)n + (1u << UBLK_SHIFT) - 1) >> UBLK_SHIFT, 1);
+  const uint64_t nwords = nublk << (UBLK_SHIFT - 6);
   const size_t nn = std::max<uint32_t>(n, 1);
-  DMALLOC(P.taken, std::max<uint64_t>(nwords, 1) * 8);
+  DMALLOC(P.taken, nwords * 8);
+  DMALLOC(P.ublk, nublk * 4);
   DMALLOC(P.resv, nn * 4);
   const size_t needy_bytes = (((size_t)Ktot + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
   DMALLOC(P.needy, needy_bytes);
@@ -991,9 +994,9 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   const size_t cap = (size_t)n + (size_t)K * CHUNK;
   if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
   ctx->cap = cap;
-  DMALLOC(P.e_order, cap * 4); DMALLOC(P.e_rc, cap); DMALLOC(P.e_flag, cap); DMALLOC(P.e_pos, cap * 8);
-  DMALLOC(P.e_len, cap * 2); DMALLOC(P.e_chain, cap * 4); DMALLOC(P.e_seq, cap * 4);
-  DMALLOC(P.s_order, cap * 4); DMALLOC(P.s_chain, cap * 4); DMALLOC(P.s_seq, cap * 4);
+  const size_t nchunk = cap / CHUNK + 2;
+  DMALLOC(P.e_rec, cap * sizeof(uint4)); DMALLOC(P.e_chunk, nchunk * sizeof(uint2));
+  DMALLOC(P.s_rec, cap * 4); DMALLOC(P.s_chunk, nchunk * sizeof(uint2));
   P.K = K; P.c0 = c0; P.Ktot = Ktot;
   P.fused = fused ? 1 : 0;
   P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
@@ -1010,7 +1013,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     P.needy_cnt = ctx->cnt_buf[1];  // what the first round reads: nobody needs a seed yet
   }
   HIPCHK(hipEventRecord(ctx->ev[4], st));
-  launch_init_taken(st, P.taken, nwords, n);
+  launch_init_taken(st, P.taken, nwords, n, P.ublk);
   launch_fill_u32(st, P.resv, n, 0xffffffffu);
   HIPCHK(hipMemsetAsync(P.needy, 0, needy_bytes, st));
   HIPCHK(hipMemsetAsync(P.chains, 0, (size_t)K * sizeof(Chain), st));
@@ -1019,8 +1022,8 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   g.cursor = (long long)n - 1;
   g.e_alloc = g.s_alloc = K * CHUNK;
   g.alive = n == 0 ? 0 : (n / Ktot > 0 ? K : (c0 == 0 ? 1 : 0));  // chains that get a seed (reorder.h:405-421)
-  launch_fill_u32(st, P.e_chain, cap, 0xffffffffu);
-  launch_fill_u32(st, P.s_chain, cap, 0xffffffffu);
+  HIPCHK(hipMemsetAsync(P.e_chunk, 0xff, nchunk * sizeof(uint2), st));  // owner 0xffffffff: chunk never handed out
+  HIPCHK(hipMemsetAsync(P.s_chunk, 0xff, nchunk * sizeof(uint2), st));
   HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
   launch_init_chains(st, P);
   HIPCHK(hipGetLastError());
@@ -1359,6 +1362,20 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
     s.unmatched += hc[i].n_unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
     s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost; s.hits += hc[i].st_hits;
   }
+#ifdef SR_PHASE_TIMING  // experiment builds: per-phase shader clocks of k_round (tools/xbuild.sh, XPIPE=1)
+  {
+    unsigned long long pt[64] = {0};
+    for (uint32_t i = 0; i < K; i++)
+      for (int k = 0; k < 64; k++) pt[k] += hc[i].pt[k];
+    unsigned long long tot = 0;
+    for (int k = 0; k < 12; k++) tot += pt[k];
+    fprintf(stderr, "[phase] bucket: total clocks (share of buckets 0-11), visits, clocks per visit\n");
+    for (int k = 0; k < 32; k++)
+      if (pt[32 + k])
+        fprintf(stderr, "[phase] %2d: %16llu (%5.1f %%) %12llu %9.0f\n", k, pt[k], 100.0 * (double)pt[k] / (double)std::max(tot, 1ull),
+                pt[32 + k], (double)pt[k] / (double)pt[32 + k]);
+  }
+#endif
   // a rank of a multi-GPU pool only holds the records of the chains it owns
   if ((!ctx->mg && am + as != ctx->n) || am + as > ctx->n || g.e_alloc > ctx->cap + CHUNK || g.s_alloc > ctx->cap + CHUNK)
     return fail(SPRING_REORDER_E_STATE, "internal: emission counts do not add up (%llu+%llu vs n=%u, alloc %u/%u cap %llu)",
@@ -1381,9 +1398,8 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(st));
   ctx->dfree(d_off_m); ctx->dfree(d_off_s);
   // the append-order buffers are no longer needed
-  ctx->dfree(P.e_order); ctx->dfree(P.e_rc); ctx->dfree(P.e_flag); ctx->dfree(P.e_pos); ctx->dfree(P.e_len);
-  ctx->dfree(P.e_chain); ctx->dfree(P.e_seq); ctx->dfree(P.s_order); ctx->dfree(P.s_chain); ctx->dfree(P.s_seq);
-  P.e_order = nullptr;
+  ctx->dfree(P.e_rec); ctx->dfree(P.e_chunk); ctx->dfree(P.s_rec); ctx->dfree(P.s_chunk);
+  P.e_rec = nullptr;
   ctx->stage = ST_FINAL;
   return 0;
 }
