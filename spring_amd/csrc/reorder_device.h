@@ -26,19 +26,31 @@ constexpr unsigned long long PK_CURSOR_BIT = 1ull << 40;
 constexpr unsigned long long PK_WILLNEED_BIT = 1ull << 41;  // PK_NONE after a failed left search: the chain needs a seed next
 
 // Per-chain state (one greedy chain == one reference OpenMP thread, reorder.h:351-431).
-// The 64-byte header is one cache line: a wave loads it once (4 x 16 B, broadcast)
-// and lane 0 stores it back once per kernel.
+// The 64-byte header is wave-uniform: the chain kernels fetch it with ONE scalar load into 16 SGPRs (no VGPRs, no
+// LDS round trip per field), update it with scalar ALU and write it back as 16-byte quarters (lane q stores quarter
+// q).  The search half only changes the last two quarters (dwords 8..15).
 struct __attribute__((aligned(16))) ChainHot {
   long long ref_pos;     // reorder.h:397
   int32_t ref_len;
-  uint32_t e_slot, prev, first_rid;   // e_slot: next free slot in this chain's matched-record chunk
-  uint32_t prop_rid;
-  int32_t prop_shift;
+  uint32_t e_slot;       // next free slot in this chain's matched-record chunk
+  uint32_t prev, first_rid;
+  uint32_t n_emit, n_single;
+  uint32_t s_slot;       // next free slot in the singleton chunk
   uint32_t num_reads_thr, num_unmatched_past;   // early-stop window (reorder.h:380-381)
-  uint32_t n_emit, n_single, s_slot;     // s_slot: next free slot in the singleton chunk
-  uint8_t done, prev_unmatched, left_search, stop_searching;
-  uint8_t mode, retrying, prop_kind, prop_rev;   // prop_rev: bit 0 reverse match, bit 1 dictionary of the winning probe, bit 2 "a repeated search may resume at this probe"
-  uint8_t cnt_buf, finishing, cursor_writer, cnt_wide;   // cnt_wide: the committed count buffer is in cnt (else cnt8)
+  uint32_t prop_rid;
+  union {  // dword 12
+    struct {
+      uint32_t done : 1, prev_unmatched : 1, left_search : 1, stop_searching : 1;
+      uint32_t mode : 1, retrying : 1, finishing : 1, cursor_writer : 1;
+      uint32_t cnt_buf : 1;
+      uint32_t cnt_wide : 1;   // the committed count buffer is in cnt (else cnt8)
+      uint32_t prop_kind : 2;
+      uint32_t prop_rev : 3;   // bit 0 reverse match, bit 1 dictionary of the winning probe, bit 2 "a repeated search may resume at this probe"
+      uint32_t prop_shift : 9;
+    };
+    uint32_t flags;
+  };
+  uint32_t pad[3];
 };
 static_assert(sizeof(ChainHot) == 64, "ChainHot must be one 64-byte line");
 

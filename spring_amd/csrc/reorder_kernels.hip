@@ -119,7 +119,18 @@ __device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshif
     // tags only (16 of the bucket's 32 bytes): 98 % of the probes end here.  The payload word is fetched on a
     // fingerprint match alone -- a second 16-byte load of every bucket doubles the L1 traffic of a 64-lane
     // gather and the line is often evicted again before it is read (tools/wave_hop_bench.hip)
+#if defined(SR_TAGS_NT)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t tv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(&fpt[b * 2]));
+    const uint4 t = make_uint4(tv.x, tv.y, tv.z, tv.w);
+#elif defined(SR_TAGS_SC)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t tv;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(tv) : "v"(&fpt[b * 2]) : "memory");
+    const uint4 t = make_uint4(tv.x, tv.y, tv.z, tv.w);
+#else
     const uint4 t = fpt[b * 2];
+#endif
     other = other || (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || t.w != 0;
     // slots fill in order and never empty again, so the matches of `mine` all lie before the first free slot and a
     // free last slot ends the key's run; one bit per matching slot instead of a branch per slot
@@ -603,16 +614,35 @@ __device__ __forceinline__ int wave_update_compute(const DevParams &P, uint32_t 
 #undef LOAD_CNT
 }
 
+// The chain header is wave-uniform.  load_hot: ONE scalar load puts its 16 dwords into SGPRs (the chain pointer is
+// wave-uniform; the scalar cache is invalidated at every kernel start and a kernel never re-reads a header it has
+// written); every update is scalar ALU on those registers.  store_hot: lane q writes quarter q (one store
+// instruction); [q_lo, q_hi) = the quarters that changed.
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void load_hot(const Chain *c, ChainHot &h) {
-  const uint4 *s = reinterpret_cast<const uint4 *>(&c->h);
-  uint4 *d = reinterpret_cast<uint4 *>(&h);
-  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+  u32x16_t v;
+  const Chain *cu = uni_ptr(c);  // (a chain belongs to one wavefront: the pointer is wave-uniform, say so)
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(cu) : "memory");
+  // (field by field: the header must fall apart into independent scalars, not travel as one 512-bit value)
+  h.ref_pos = (long long)(((unsigned long long)v[1] << 32) | v[0]);
+  h.ref_len = (int32_t)v[2]; h.e_slot = v[3];
+  h.prev = v[4]; h.first_rid = v[5]; h.n_emit = v[6]; h.n_single = v[7];
+  h.s_slot = v[8]; h.num_reads_thr = v[9]; h.num_unmatched_past = v[10]; h.prop_rid = v[11];
+  h.flags = v[12];
+  h.pad[0] = h.pad[1] = h.pad[2] = 0;
 }
-__device__ __forceinline__ void store_hot(Chain *c, const ChainHot &h) {
-  uint4 *d = reinterpret_cast<uint4 *>(&c->h);
-  const uint4 *s = reinterpret_cast<const uint4 *>(&h);
-  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+__device__ __forceinline__ void store_hot(Chain *c, const ChainHot &h, int lane, int q_lo = 0, int q_hi = 4) {
+  if (lane >= q_lo && lane < q_hi) {
+    const uint32_t plo = (uint32_t)(unsigned long long)h.ref_pos, phi = (uint32_t)((unsigned long long)h.ref_pos >> 32);
+    uint4 q;
+    q.x = lane == 0 ? plo : lane == 1 ? h.prev : lane == 2 ? h.s_slot : h.flags;
+    q.y = lane == 0 ? phi : lane == 1 ? h.first_rid : lane == 2 ? h.num_reads_thr : 0u;
+    q.z = lane == 0 ? (uint32_t)h.ref_len : lane == 1 ? h.n_emit : lane == 2 ? h.num_unmatched_past : 0u;
+    q.w = lane == 0 ? h.e_slot : lane == 1 ? h.n_single : lane == 2 ? h.prop_rid : 0u;
+    reinterpret_cast<uint4 *>(&c->h)[lane] = q;
+  }
 }
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ----------------------------------------------------------- chain start-up
 // reorder.h:405-431 with the critical section entered in chain-id order.
@@ -636,22 +666,20 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   }
   if (!start) {
     h.done = 1;
-    if (lane == 0) {
-      store_hot(c, h);
-      if (P.prop) P.prop[cid] = (unsigned long long)PK_DONE << 32;
-    }
+    store_hot(c, h, lane);
+    if (lane == 0 && P.prop) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
   const int n = P.uniform_len ? P.L : (int)P.lens[seed];
   bool ovf0;  // a fresh seed's counts are 0 / 1: bytes
   const int Rn = wave_update_compute<NP, false>(P, li, ws, nullptr, seed, n, true, false, 0, 0, 0, false, false, ovf0, lane);
   pack_consensus(ws, Rn, lane, c);
+  h.prev = seed; h.first_rid = seed; h.prev_unmatched = 1;
+  h.e_slot = li * CHUNK; h.s_slot = li * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
+  h.ref_len = Rn; h.cnt_buf = 1; h.cnt_wide = 0;
+  if (P.fused) h.prop_kind = PROP_FRESH;
+  store_hot(c, h, lane);
   if (lane == 0) {
-    h.prev = seed; h.first_rid = seed; h.prev_unmatched = 1;
-    h.e_slot = li * CHUNK; h.s_slot = li * CHUNK;  // first chunk is pre-assigned; Globals.*_alloc start at K*CHUNK
-    h.ref_len = Rn; h.cnt_buf = 1; h.cnt_wide = 0;
-    if (P.fused) h.prop_kind = PROP_FRESH;
-    store_hot(c, h);
     c->n_unmatched = 1;
     if (P.prop) P.prop[cid] = (unsigned long long)PK_NONE << 32;
   }
@@ -1201,22 +1229,25 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
                                             uint8_t *s_pres /* [128] */, lds_u32_t *s_best, lds_u32_t *s_stage /* [STAGE_WORDS] */) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
-    const long long seed = find_seed(P, cid, lane, &is_last);
-    if (lane == 0) {
-      if (seed >= 0) {
-        h.prop_kind = PROP_SEED;
-        h.prop_rid = (uint32_t)seed;
-        // the last-ranked needy chain proposes the lowest seed of the round: it alone moves the cursor
-        h.cursor_writer = is_last;
-        if (WORD) P.prop[cid] = ((unsigned long long)PK_SEED << 32) | (uint32_t)seed | (is_last ? PK_CURSOR_BIT : 0ull);
+    const long long seed_v = find_seed(P, cid, lane, &is_last);
+    const bool have = __builtin_amdgcn_readfirstlane((int)(seed_v >= 0)) != 0;
+    const uint32_t seed = uni_u32((uint32_t)seed_v);
+    const bool last = __builtin_amdgcn_readfirstlane((int)is_last) != 0;
+    if (have) {
+      h.prop_kind = PROP_SEED;
+      h.prop_rid = seed;
+      // the last-ranked needy chain proposes the lowest seed of the round: it alone moves the cursor
+      h.cursor_writer = last;
+      if (lane == 0) {
+        if (WORD) P.prop[cid] = ((unsigned long long)PK_SEED << 32) | seed | (last ? PK_CURSOR_BIT : 0ull);
         if (DIRECT) atomicMin(&P.resv[seed], cid);
-      } else {
-        h.prop_kind = PROP_NONE;
-        h.finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
-        if (WORD) P.prop[cid] = (unsigned long long)PK_NOSEED << 32;
       }
-      store_hot(c, h);
+    } else {
+      h.prop_kind = PROP_NONE;
+      h.finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
+      if (WORD && lane == 0) P.prop[cid] = (unsigned long long)PK_NOSEED << 32;
     }
+    store_hot(c, h, lane, 2, 4);
     PTW(11);
     return -2;
   }
@@ -1231,31 +1262,25 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   }
   const bool new_iter = !h.retrying;
   if (h.stop_searching) {
+    h.prop_kind = PROP_NONE;
+    store_hot(c, h, lane, 2, 4);
     if (lane == 0) {
-      h.prop_kind = PROP_NONE;
-      store_hot(c, h);
       if (WORD) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
       if (STATS && new_iter) c->st_iter++;
     }
     return -3;
   }
 
-  // the bookkeeping fields changed above go back now; the 64-byte header is not kept in registers across
-  // the probe loop (the kernel is latency-bound at 8 waves/SIMD, i.e. 64 VGPRs, so every register counts)
-  // (wave-uniform values read from the header -- in LDS for the fused kernel -- are pinned to scalar registers)
-  const int ref_len = __builtin_amdgcn_readfirstlane(h.ref_len);
-  const bool left_search = __builtin_amdgcn_readfirstlane((int)h.left_search) != 0;
-  if (lane == 0 && new_iter) {
-    c->h.num_reads_thr = h.num_reads_thr;
-    c->h.num_unmatched_past = h.num_unmatched_past;
-  }
+  // (the header lives in scalar registers; its last two quarters go back once, at the end of the search)
+  const int ref_len = h.ref_len;
+  const bool left_search = h.left_search;
   const uint64_t *sref = s_refs + LDS_PAD, *srev = s_refs + LDS_LIMBS + LDS_PAD;
   wave_sync();
   // The ordered batches of a search, narrow first: most chains match within the first few shifts and every lane
   // past the winner is a wasted 64-byte request; every further batch is a further dependent round trip (8 + 16 is
   // the measured optimum).  A fresh seed (nothing matched to it yet) fails nine searches out of
   // ten and needs every window anyway: it gets the wide plan.  P.plan[which] = batch widths in shifts (each <= 16, sum <= 32), 0-terminated.
-  const int *plan = P.plan[(__builtin_amdgcn_readfirstlane((int)h.prev_unmatched) && P.seed_wide) ? 1 : 0];
+  const int *plan = P.plan[(h.prev_unmatched && P.seed_wide) ? 1 : 0];
   // a search repeated after a lost proposal resumes at the last winner's code (see probe_batch) -- unless some probe
   // ahead of that winner had stopped at MAX_SEARCH live candidates (then a deeper candidate may have come into its
   // reach: bit 2 of prop_rev says it had not), or the reference-equivalent work is being counted.  Only in the
@@ -1263,8 +1288,8 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   // them at 1 600x coverage, 0.3 % at 25x, where the bookkeeping costs more than it saves)
   int min_code = 0;
   if (TRIM && !STATS && !new_iter) {
-    const int pr = uni_i32((int)h.prop_rev);
-    if (pr & 4) min_code = (uni_i32(h.prop_shift) << 2) | ((pr & 1) << 1) | ((pr >> 1) & 1);
+    const int pr = (int)h.prop_rev;
+    if (pr & 4) min_code = ((int)h.prop_shift << 2) | ((pr & 1) << 1) | ((pr >> 1) & 1);
   }
   bool capped = false;
   BatchOut o;
@@ -1289,16 +1314,26 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     PT(9);
   }
+  {
+    const bool found = __builtin_amdgcn_readfirstlane((int)o.found) != 0;
+    const uint32_t wrid = uni_u32(o.rid);
+    const int wcode = uni_i32(o.code);
+    const bool cap_u = __builtin_amdgcn_readfirstlane((int)capped) != 0;
+    if (found) {
+      h.prop_rid = wrid;
+      h.prop_shift = (uint32_t)(wcode >> 2);
+      h.prop_rev = (uint32_t)(((wcode >> 1) & 1) | ((wcode & 1) << 1) | ((TRIM && !cap_u) ? 4 : 0));  // rev | dict << 1 | resumable << 2
+      h.prop_kind = PROP_MATCH;
+    } else {
+      h.prop_kind = PROP_NONE;
+    }
+    store_hot(c, h, lane, 2, 4);
+  }
   if (lane == 0) {
     if (o.found) {
-      c->h.prop_rid = o.rid;
-      c->h.prop_shift = o.code >> 2;
-      c->h.prop_rev = (uint8_t)(((o.code >> 1) & 1) | ((o.code & 1) << 1) | ((TRIM && !capped) ? 4 : 0));  // rev | dict << 1 | resumable << 2
-      c->h.prop_kind = PROP_MATCH;
       if (WORD) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;
       if (DIRECT) atomicMin(&P.resv[o.rid], cid);
     } else {
-      c->h.prop_kind = PROP_NONE;
       // a failed left search sends the chain for a new seed (apply step): k_mg_mark puts it on the needy bitmap
       if (WORD) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (left_search ? PK_WILLNEED_BIT : 0ull);
     }
@@ -1327,18 +1362,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   if (li >= P.K) return;
   const uint32_t cid = P.c0 + li;  // global chain id (conflict priority, seed rank)
   Chain *c = &P.chains[li];
-  __shared__ ChainHot s_h[WPB];  // header in LDS (wave-uniform values do not belong in 16 VGPRs of every lane)
-  if (lane < 4) reinterpret_cast<uint4 *>(&s_h[wave])[lane] = reinterpret_cast<const uint4 *>(&c->h)[lane];
-  ChainHot &h = s_h[wave];
-  // stage ref / revref in LDS right away (same dependency level as the header load)
-  if (lane < LDS_LIMBS) {
+  // ref / revref go to LDS; their loads are in flight while the header's scalar load is waited for
+  uint64_t r0 = 0, r1 = 0;
+  {
     const int i = lane - LDS_PAD;
-    const bool in = i >= 0 && i < P.W;
-    s_refs[wave][0][lane] = in ? c->ref[i] : 0ull;
-    s_refs[wave][1][lane] = in ? c->revref[i] : 0ull;
+    if (lane < LDS_LIMBS && i >= 0 && i < P.W) { r0 = c->ref[i]; r1 = c->revref[i]; }
   }
-  wave_sync();
+  ChainHot h;
+  load_hot(c, h);
   if (h.done) return;
+  if (lane < LDS_LIMBS) { s_refs[wave][0][lane] = r0; s_refs[wave][1][lane] = r1; }
+  wave_sync();
   search_step<STATS, false, true, false>(P, c, cid, h, lane, &s_refs[wave][0][0], s_list[wave], s_stat[STATS ? wave : 0], s_pres[wave],
                                           (lds_u32_t *)&s_best[wave], (lds_u32_t *)s_stage[wave]);
 }
@@ -1353,28 +1387,38 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
 // Emission slots: each chain fills private CHUNK-slot chunks of the append buffers and only
 // touches the global allocator once per CHUNK records (a same-address atomic per record from
 // every chain serialises at ~11 ns each and dominated this kernel).
-__device__ __forceinline__ uint32_t take_slot(uint32_t &slot, uint32_t *alloc, uint2 *chunk, uint32_t li, uint32_t next_seq) {
+// (called by the whole wavefront: the slot bookkeeping stays wave-uniform, lane 0 does the memory operations)
+__device__ __forceinline__ uint32_t take_slot(uint32_t &slot, uint32_t *alloc, uint2 *chunk, uint32_t li, uint32_t next_seq, int lane) {
   const uint32_t s0 = slot;
   uint32_t nx = s0 + 1;
   if ((nx & (CHUNK - 1)) == 0) {
-    nx = atomicAdd(alloc, CHUNK);
-    chunk[nx / CHUNK] = make_uint2(li, next_seq);  // the chunk's owner and the sequence number of its first record
+    uint32_t got = 0;
+    if (lane == 0) got = atomicAdd(alloc, CHUNK);
+    nx = uni_u32(got);
+    if (lane == 0) chunk[nx / CHUNK] = make_uint2(li, next_seq);  // the chunk's owner and the sequence number of its first record
   }
   slot = nx;
   return s0;
 }
 // one 16-byte store per matched record (length: looked up by the final scatter)
 __device__ __forceinline__ void emit_rec(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid, char rc,
-                                         char flag, long long pos) {
-  const uint32_t seq = h.n_emit++;
-  const uint32_t idx = take_slot(h.e_slot, &P.glob->e_alloc, P.e_chunk, li, seq + 1);
-  P.e_rec[idx] = make_uint4(rid, (uint32_t)(uint8_t)rc | ((uint32_t)(uint8_t)flag << 8), (uint32_t)pos,
-                            (uint32_t)((unsigned long long)pos >> 32));
+                                         char flag, long long pos, int lane) {
+  const uint32_t seq = h.n_emit;
+  h.n_emit = seq + 1;
+  uint32_t slot = h.e_slot;
+  const uint32_t idx = take_slot(slot, &P.glob->e_alloc, P.e_chunk, li, seq + 1, lane);
+  h.e_slot = slot;
+  if (lane == 0)
+    P.e_rec[idx] = make_uint4(rid, (uint32_t)(uint8_t)rc | ((uint32_t)(uint8_t)flag << 8), (uint32_t)pos,
+                              (uint32_t)((unsigned long long)pos >> 32));
 }
-__device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid) {
-  const uint32_t seq = h.n_single++;
-  const uint32_t idx = take_slot(h.s_slot, &P.glob->s_alloc, P.s_chunk, li, seq + 1);
-  P.s_rec[idx] = rid;
+__device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid, int lane) {
+  const uint32_t seq = h.n_single;
+  h.n_single = seq + 1;
+  uint32_t slot = h.s_slot;
+  const uint32_t idx = take_slot(slot, &P.glob->s_alloc, P.s_chunk, li, seq + 1, lane);
+  h.s_slot = slot;
+  if (lane == 0) P.s_rec[idx] = rid;
 }
 
 // One chain's phase B.  Resolves the proposal the chain made in the last search (lowest chain id holds resv[rid])
@@ -1388,19 +1432,17 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
   const int kind = h.prop_kind;
   if (kind == PROP_FRESH) return true;  // first fused round: nothing proposed yet
   if (h.finishing) {  // seed-needing chain found the pool empty
-    if (lane == 0) {
-      if (h.prev_unmatched) emit_single(P, h, li, h.prev);
-      h.done = 1; h.finishing = 0;
-      if (!DEFER) {  // DEFER: every rank reads PK_NOSEED in the gathered words (k_mg_mark); the chain says PK_DONE from now on
-        atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
-        atomicSub(&P.glob->alive, 1u);
-      }
-      store_hot(c, h);
+    if (h.prev_unmatched) emit_single(P, h, li, h.prev, lane);
+    h.done = 1; h.finishing = 0;
+    if (!DEFER && lane == 0) {  // DEFER: every rank reads PK_NOSEED in the gathered words (k_mg_mark); the chain says PK_DONE from now on
+      atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
+      atomicSub(&P.glob->alive, 1u);
     }
+    store_hot(c, h, lane);
     return false;
   }
   // who holds the read we proposed (load in flight while the update is computed)
-  const uint32_t owner = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;
+  const uint32_t owner_v = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;
   const bool fail_path = kind == PROP_NONE && h.mode == MODE_SEARCH;
   bool do_upd = false, ureset = false, urev = false;
   uint32_t urid = 0;
@@ -1412,7 +1454,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
   const int R_old = h.ref_len;
   bool nw = false;
   if (do_upd) {
-    if (!P.uniform_len) n = (int)P.lens[urid];
+    if (!P.uniform_len) n = uni_i32((int)P.lens[urid]);
     // bytes first; the rare update that would push a count past 255 is redone in the wide format
     R_new = wave_update_compute<NP, LITERAL>(P, li, ws, wl, urid, n, ureset, urev, ushift, R_old, h.cnt_buf,
                                              h.cnt_wide != 0, false, nw, lane);
@@ -1426,12 +1468,13 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     if (lane == 0) P.glob->cursor = (long long)h.prop_rid - 1;
     h.cursor_writer = 0;
   }
+  R_new = uni_i32(R_new);
+  nw = __builtin_amdgcn_readfirstlane((int)nw) != 0;
+  const uint32_t owner = uni_u32(owner_v);
   if (owner != cid) {  // lost the read: retry, nothing committed
     if (h.mode == MODE_SEARCH) h.retrying = 1;
-    if (lane == 0) {
-      store_hot(c, h);
-      atomicAdd((unsigned long long *)&c->st_lost, 1ull);  // no returned value: nothing to wait for
-    }
+    store_hot(c, h, lane);
+    if (lane == 0) atomicAdd((unsigned long long *)&c->st_lost, 1ull);  // no returned value: nothing to wait for
     return true;
   }
   PT(3);
@@ -1461,10 +1504,8 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
       else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
       rcch = left ? 'd' : 'r';
     }
-    if (lane == 0) {
-      if (h.prev_unmatched) emit_rec(P, h, li, h.prev, 'd', '0', 0);
-      emit_rec(P, h, li, rid, rcch, '1', cur_pos);
-    }
+    if (h.prev_unmatched) emit_rec(P, h, li, h.prev, 'd', '0', 0, lane);
+    emit_rec(P, h, li, rid, rcch, '1', cur_pos, lane);
     h.prev_unmatched = 0; h.ref_pos = ref_pos; h.retrying = 0;
   } else if (kind == PROP_SEED) {  // reorder.h:580-587, :600-613
     const uint32_t rid = h.prop_rid;
@@ -1473,9 +1514,9 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
         atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
         atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
       }
-      if (h.prev_unmatched) emit_single(P, h, li, h.prev);
       atomicAdd((unsigned long long *)&c->n_unmatched, 1ull);
     }
+    if (h.prev_unmatched) emit_single(P, h, li, h.prev, lane);
     h.prev_unmatched = 1; h.first_rid = rid; h.prev = rid;
     h.ref_pos = 0; h.mode = MODE_SEARCH;
   } else if (fail_path) {  // search failed (reorder.h:559-575)
@@ -1487,7 +1528,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
       if (!DEFER && lane == 0) atomicOr(&P.needy[cid >> 5], 1u << (cid & 31));  // DEFER: k_mg_mark, from the PK_WILLNEED word
     }
   }
-  if (lane == 0) store_hot(c, h);
+  store_hot(c, h, lane);
   PT(5);
   return true;
 }
@@ -1539,18 +1580,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   wave_sync();
   if (lane == 0) g_pt_lds[64] = (uint32_t)clock64();
 #endif
-  // the header lives in LDS, not in registers: its 16 dwords are wave-uniform, and held in every lane's VGPRs
-  // across the update and the search they are what pushes the kernel past 64 VGPRs into scratch
-  __shared__ ChainHot s_h;
-  if (lane < 4) reinterpret_cast<uint4 *>(&s_h)[lane] = reinterpret_cast<const uint4 *>(&c->h)[lane];
-  ChainHot &h = s_h;
-  if (lane < LDS_LIMBS) {
+  // ref / revref go to LDS; their loads are in flight while the header's scalar load is waited for
+  uint64_t r0 = 0, r1 = 0;
+  {
     const int i = lane - LDS_PAD;
-    const bool in = i >= 0 && i < P.W;
-    s_refs[0][lane] = in ? c->ref[i] : 0ull;
-    s_refs[1][lane] = in ? c->revref[i] : 0ull;
+    if (lane < LDS_LIMBS && i >= 0 && i < P.W) { r0 = c->ref[i]; r1 = c->revref[i]; }
   }
-  wave_sync();  // s_h; the update below rewrites s_refs
+  ChainHot h;
+  load_hot(c, h);
+  if (lane < LDS_LIMBS) { s_refs[0][lane] = r0; s_refs[1][lane] = r1; }
+  wave_sync();  // the update below rewrites s_refs
   if (h.done) {
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
