@@ -104,6 +104,13 @@ struct DevParams {
   uint32_t *needy_cnt;       // set bits per 64 words of needy (2048 chains) as k_mg_mark of the LAST round left them
   uint32_t *needy_cnt_next;  // the buffer k_mg_mark of THIS round fills (zeroed by the previous k_mg_mark)
   int fused;                 // 1: k_round (apply + search in one kernel)
+  int mc;                    // 1: four chains per wavefront (k_round_mc) where it applies
+  // k_round_mc runs chains of one class per wavefront (four chains of a wavefront take the union of their paths):
+  // k_mg_mark sorts the local chains by what the next round will ask of them -- 0 left search after a failed right
+  // search, 1 first search of a new seed, 2 search after a proposed match, 3 seed pick -- into ord[cls * K + i];
+  // ord_cnt[cls] entries each (double-buffered like needy_cnt).  Chains that are done appear in no list.
+  uint32_t *ord;
+  uint32_t *ord_cnt, *ord_cnt_next;
   Globals *glob;
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;

@@ -1245,7 +1245,11 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
     } else {
       h.prop_kind = PROP_NONE;
       h.finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
-      if (WORD && lane == 0) P.prop[cid] = (unsigned long long)PK_NOSEED << 32;
+      // the last-ranked needy chain finds nothing: every untaken read went to the chains ranked before it, so after
+      // this round the whole pool is taken -- the cursor goes to -1 (find_seed relies on "every read above the
+      // cursor is taken" AND on the cursor having passed every seed ever handed out)
+      h.cursor_writer = last;
+      if (WORD && lane == 0) P.prop[cid] = ((unsigned long long)PK_NOSEED << 32) | (last ? PK_CURSOR_BIT : 0ull);
     }
     store_hot(c, h, lane, 2, 4);
     PTW(11);
@@ -1437,7 +1441,9 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     if (!DEFER && lane == 0) {  // DEFER: every rank reads PK_NOSEED in the gathered words (k_mg_mark); the chain says PK_DONE from now on
       atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
       atomicSub(&P.glob->alive, 1u);
+      if (h.cursor_writer) P.glob->cursor = -1;  // (see search_step: the pool is exhausted)
     }
+    h.cursor_writer = 0;
     store_hot(c, h, lane);
     return false;
   }
@@ -1604,6 +1610,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   PT_FLUSH(c);
 }
 
+#include "reorder_round_mc.h"
+
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
 // prop[] now holds every rank's proposals.  All ranks run these two kernels over ALL chains and therefore keep
 // identical taken[] / resv[] / needy[] / cursor replicas; k_search and k_apply only touch the chains a rank owns.
@@ -1624,10 +1632,12 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool needy = false, alive = false;
+  int cls = -1;  // class of the chain's next round (k_round_mc), local chains that are still running only
   if (cid < P.Ktot) {
     const unsigned long long pv = P.prop[cid];
     const int pk = (int)(pv >> 32) & 7;
     alive = pk != PK_DONE;
+    if (alive && cid >= P.c0 && cid - P.c0 < P.K) cls = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv & PK_WILLNEED_BIT) ? 3 : 0) : 3;
     if (pk == PK_MATCH || pk == PK_SEED) {
       const uint32_t rid = (uint32_t)pv;
       const bool won = P.resv[rid] == cid;
@@ -1639,8 +1649,11 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
       }
       if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)rid - 1;  // every seed proposed this round ends up taken
       needy = pk == PK_SEED && !won;
+      if (pk == PK_SEED && won && cls >= 0) cls = 1;
     } else if (pk == PK_NONE) {
       needy = (pv & PK_WILLNEED_BIT) != 0;
+    } else if (pk == PK_NOSEED && (pv & PK_CURSOR_BIT)) {
+      P.glob->cursor = -1;  // the last-ranked needy chain found nothing: the pool is exhausted (search_step)
     }
   }
   const uint64_t nb = __ballot(needy);
@@ -1655,6 +1668,31 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   }
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
+  if (P.ord) {  // class lists: a slot per chain, one global atomic per class and block (the order inside a class is free)
+    __shared__ uint32_t s_cnt[4], s_base[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t m = __ballot(cls == k);
+      uint32_t wbase = 0;
+      if (m && lane == 0) wbase = atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
+      wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+      if (cls == k) off = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&P.ord_cnt_next[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (cls >= 0) P.ord[(size_t)cls * P.K + s_base[cls] + off] = cid - P.c0;
+    if (cid < 4) P.ord_cnt[cid] = 0;
+  }
+}
+// first round: every chain in class 2
+__global__ void k_init_ord(DevParams P) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P.K) P.ord[(size_t)2 * P.K + i] = i;
+  if (i < 4) { P.ord_cnt[i] = i == 2 ? P.K : 0u; P.ord_cnt_next[i] = 0u; }
 }
 
 // ------------------------------------------------------------ K7 finalize / emit
@@ -1796,6 +1834,7 @@ void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_
 void launch_init_chains(hipStream_t st, const DevParams &P) {
   if (P.Ktot) hipLaunchKernelGGL(k_init_seeds, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
   if (!P.K) return;
+  if (P.ord) hipLaunchKernelGGL(k_init_ord, GRID1(P.K, 256), dim3(256), 0, st, P);
 #define CALL(N) hipLaunchKernelGGL(k_init_chains<N>, dim3((P.K + 3) / 4), dim3(256), 0, st, P)
   NP_DISPATCH(CALL);
 #undef CALL
@@ -1834,6 +1873,19 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   if (!P.K) return;
   const dim3 g(P.K), b(64);
   const size_t dyn = (size_t)P.dbg_search_lds;
+  // four chains per wavefront (k_round_mc) unless the run needs what only the one-chain kernel has: the
+  // reference-equivalent work counters, or the deep-bin machinery (tail trimming, balanced scan, resumed searches)
+  if (P.mc && !stats && !P.deep_bins) {
+    const dim3 g4((P.K + 3) / 4 + 3);  // (every class list is rounded up to whole wavefronts)
+    if (P.Lpad <= 192) {
+      if (mg) hipLaunchKernelGGL((k_round_mc<3, true>), g4, b, 0, st, P);
+      else hipLaunchKernelGGL((k_round_mc<3, false>), g4, b, 0, st, P);
+    } else {
+      if (mg) hipLaunchKernelGGL((k_round_mc<8, true>), g4, b, 0, st, P);
+      else hipLaunchKernelGGL((k_round_mc<8, false>), g4, b, 0, st, P);
+    }
+    return;
+  }
 #ifdef SR_DEV_PROD_ONLY
   if (stats || mg || P.deep_bins || P.Lpad > 192) abort();
   hipLaunchKernelGGL((k_round<3, false, false, false>), g, b, dyn, st, P);

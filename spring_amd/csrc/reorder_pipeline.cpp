@@ -138,6 +138,7 @@ struct spring_reorder_ctx {
   uint64_t nrec = 0, nsing = 0, cap = 0;
   bool mg = false;
   uint32_t *cnt_buf[2] = {nullptr, nullptr};  // needy_cnt double buffer (reorder_device.h)
+  uint32_t *ord_cnt[2] = {nullptr, nullptr};  // class-list sizes, double buffer
   uint64_t round_no = 0;
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
@@ -989,7 +990,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   DMALLOC(P.glob, sizeof(Globals));
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
-  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t));
+  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t) + 64);  // (k_round_mc reads whole quads: up to 12 bytes past a column)
   // append buffers: n records + one partly filled CHUNK per chain
   const size_t cap = (size_t)n + (size_t)K * CHUNK;
   if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
@@ -999,6 +1000,8 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   DMALLOC(P.s_rec, cap * 4); DMALLOC(P.s_chunk, nchunk * sizeof(uint2));
   P.K = K; P.c0 = c0; P.Ktot = Ktot;
   P.fused = fused ? 1 : 0;
+  P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
+  if (const char *e = getenv("SPRING_REORDER_MC")) P.mc = atoi(e) != 0;  // A/B runs of the tools (same results)
   P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
   ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
   if (fused) {  // the rounds whose shared state k_mg_mark keeps: proposal words + double-buffered counters
@@ -1011,6 +1014,13 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     HIPCHK(hipMemsetAsync(ctx->cnt_buf[0], 0, 2 * nblk * 4, st));
     HIPCHK(hipMemsetAsync(P.alive_wave, 0, ((size_t)Ktot + 63) / 64 * 4, st));
     P.needy_cnt = ctx->cnt_buf[1];  // what the first round reads: nobody needs a seed yet
+    DMALLOC(P.ord, (size_t)4 * std::max<uint32_t>(K, 1) * 4);
+    DMALLOC(ctx->ord_cnt[0], 64);
+    ctx->ord_cnt[1] = ctx->ord_cnt[0] + 8;
+    P.ord_cnt = ctx->ord_cnt[1];  // what the first round reads (k_init_ord: every chain in class 2)
+    P.ord_cnt_next = ctx->ord_cnt[0];
+  } else {
+    P.ord = nullptr; P.ord_cnt = P.ord_cnt_next = nullptr;
   }
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   launch_init_taken(st, P.taken, nwords, n, P.ublk);
@@ -1038,6 +1048,8 @@ static void set_round_buffers(spring_reorder_ctx *ctx) {
   const int w = (int)(ctx->round_no & 1);
   P.needy_cnt = ctx->cnt_buf[w ^ 1];
   P.needy_cnt_next = ctx->cnt_buf[w];
+  P.ord_cnt = ctx->ord_cnt[w ^ 1];
+  P.ord_cnt_next = ctx->ord_cnt[w];
 
 }
 
@@ -1109,6 +1121,12 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
       HIPCHK(hipStreamSynchronize(st));
     }
     HIPCHK(hipGetLastError());
+    if (getenv("SPRING_REORDER_DEBUG") && P.ord) {  // progress on stderr, no effect on results
+      uint32_t oc[4] = {0, 0, 0, 0};
+      (void)hipMemcpy(oc, P.ord_cnt_next, 16, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[chains] rounds %llu running %u | next round: left %u fresh %u match %u seed %u\n",
+              (unsigned long long)rounds, *h_alive, oc[0], oc[1], oc[2], oc[3]);
+    }
     if (timed) {
       for (int r = 0; r < R; r++) {
         float ms = 0;

@@ -1,0 +1,663 @@
+// spring_amd/csrc/reorder_round_mc.h -- included by reorder_kernels.hip (inside namespace sr, after the probe helpers).
+//
+// k_round_mc: the fused round (phase B of round t-1 + phase A of round t, see k_round) with FOUR chains per
+// wavefront: chain = one 16-lane DPP row.  Same schedule, same results, other mapping of work to lanes.
+//
+// Why: with one chain per wavefront almost every instruction of a step is wave-uniform bookkeeping or runs with a
+// few active lanes (a candidate compare: one lane; a first probe batch: 32), and the round kernel sits at 64 VGPRs
+// x 8 waves per SIMD with its vector ALU ~65 % busy and its memory steps queueing behind each other (DESIGN.md
+// section 6).  Here every instruction serves four chains, the kernel runs 4 waves per SIMD with a 128-VGPR budget
+// (16 chains per SIMD in flight instead of 8) and a lane keeps several independent table fetches in flight.
+// The code is plain SIMT over a 16-lane group: values that are uniform per chain are ordinary per-lane variables,
+// branches on them are group-uniform, cross-lane traffic is width-16 shuffles / ballots shifted to the row.
+//
+// Scope: shallow dictionaries (no tail trimming / balanced scan), no reference-equivalent work counters; the
+// one-chain-per-wavefront k_round keeps those variants (deep-coverage pools, collect_stats).
+#ifndef SPRING_REORDER_ROUND_MC_H_
+#define SPRING_REORDER_ROUND_MC_H_
+
+namespace mc {
+
+constexpr int G = 16;        // lanes per chain
+constexpr int CPW = 64 / G;  // chains per wavefront
+
+struct GLds {                       // per chain
+  uint64_t refs[2][LDS_LIMBS];      // ref / revref, LDS_PAD zero limbs either side (lds_window)
+  uint64_t rd[18];                  // the read being merged, one zero limb either side
+  uint64_t nref[16];                // the speculative update's consensus, 4 bases per byte (= the limb format)
+  uint8_t pres[128];                // probe_tail: "the other dictionary may hold this window", by probe code
+  uint32_t best;                    // lowest priority code that has hit in the running batch (eval_probe)
+  uint32_t pad[3];
+};
+
+__device__ __forceinline__ int gmin_i(int v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, G));
+  return v;
+}
+__device__ __forceinline__ int gsum_i(int v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+__device__ __forceinline__ int gincl_scan_i(int v, int gl) {
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) {
+    const int t = __shfl_up(v, o, G);
+    if (gl >= o) v += t;
+  }
+  return v;
+}
+// ballot over the 16 lanes of this lane's group
+__device__ __forceinline__ uint32_t gballot(bool p, int lane) {
+  return (uint32_t)(__ballot(p) >> (lane & ~(G - 1))) & 0xffffu;
+}
+__device__ __forceinline__ uint64_t gshfl_u64(uint64_t v, int src) {
+  const uint32_t lo = __shfl((uint32_t)v, src, G), hi = __shfl((uint32_t)(v >> 32), src, G);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// 8 bits at bit `bitpos` of the staged read (S.rd, limb 0 at index 1; bitpos >= -64)
+__device__ __forceinline__ uint32_t rd_bits8(const uint64_t *rd, int bitpos) {
+  const int bp = bitpos + 64, li = bp >> 6, off = bp & 63;
+  uint64_t v = rd[li] >> off;
+  if (off > 56) v |= rd[li + 1] << (64 - off);
+  return (uint32_t)v & 0xffu;
+}
+
+typedef uint32_t u32x4a_t __attribute__((ext_vector_type(4), aligned(4)));
+
+// updaterefcount (reorder.h:110-220) for one chain by its 16 lanes; see wave_update_compute for the case analysis.
+// Lane gl owns the position quads q = gl + 16 k (positions 4q .. 4q+3).  Fast path (byte counts in, byte counts
+// out, no in-place aliasing): one 16-byte load (at the shifted source position), four packed-byte additions, one
+// 16-byte store per quad; the new consensus goes to S.nref four bases per byte -- the limb format itself.
+// Anything else (wide counts, the aliasing case of the reference) takes the generic per-position path.
+template <int NQ>
+__device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds &S, uint32_t rid, int n, bool reset,
+                                         bool rev, int shift, int R, int cb, bool cur_wide, bool out_wide,
+                                         bool &overflow, int gl) {
+  const int M = P.L, W = P.W;
+  const int4 *__restrict__ cur = P.cnt + ((uint64_t)li * 2 + cb) * P.Lpad;
+  int4 *__restrict__ nxt = P.cnt + ((uint64_t)li * 2 + (cb ^ 1)) * P.Lpad;
+  const uint32_t *__restrict__ cur8 = P.cnt8 + ((uint64_t)li * 2 + cb) * P.Lpad;
+  uint32_t *__restrict__ nxt8 = P.cnt8 + ((uint64_t)li * 2 + (cb ^ 1)) * P.Lpad;
+  int hiP, cpy_hi, src_off, add_lo, add_hi, Rn, d = 0;
+  bool alias = false;
+  if (reset) { hiP = M; cpy_hi = 0; src_off = 0; add_lo = 0; add_hi = n; Rn = n; }
+  else if (!rev) { Rn = max(R - shift, n); hiP = Rn; cpy_hi = R - shift; src_off = shift; add_lo = 0; add_hi = n; }
+  else if (n - shift >= R) { Rn = n; hiP = n; cpy_hi = R; src_off = 0; add_lo = 0; add_hi = n; d = n - shift - R; alias = d > 0; }
+  else if (R + shift <= M) { Rn = R + shift; hiP = Rn; cpy_hi = R; src_off = 0; add_lo = R - n + shift; add_hi = Rn; }
+  else { Rn = M; hiP = M; cpy_hi = M - shift; src_off = R + shift - M; add_lo = M - n; add_hi = M; }
+  const bool fast = !alias && !cur_wide && !out_wide;
+
+  // issue the loads first: the read's limbs and (fast path) this lane's source quads
+  const uint64_t myl = gl < W ? P.reads[(uint64_t)rid * P.S + gl] : 0ull;
+  u32x4a_t old[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int p0 = 4 * (gl + G * k);
+    old[k] = (u32x4a_t)(0u);
+    if (fast && p0 < cpy_hi) old[k] = *reinterpret_cast<const u32x4a_t *>(cur8 + p0 + src_off);
+  }
+  S.rd[1 + gl] = myl;
+  wave_sync();
+  const uint64_t *rd = S.rd;
+
+  bool ovf = false;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) {
+    const int q = gl + G * k, p0 = 4 * q;
+    if (p0 >= P.Lpad) continue;
+    uint32_t codes = 0;  // four 2-bit consensus codes
+    if (fast) {
+      // the four bases this quad adds, 2 bits each, element 0 in bits 0-1 (only meaningful inside [add_lo, add_hi))
+      const int i0 = p0 - add_lo;
+      uint32_t b8 = 0;
+      if (i0 > -4 && i0 < n) {
+        if (!rev) b8 = rd_bits8(rd, 2 * i0);
+        else {
+          const uint32_t x = ~rd_bits8(rd, 2 * (n - 4 - i0)) & 0xffu;  // complement; then reverse the four groups
+          b8 = ((x & 3u) << 6) | ((x & 0xcu) << 2) | ((x >> 2) & 0xcu) | (x >> 6);
+        }
+      }
+      u32x4a_t t4;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int p = p0 + e;
+        uint32_t t = p < cpy_hi ? old[k][e] : 0u;
+        const uint32_t code = (b8 >> (2 * e)) & 3u;
+        uint32_t cdx = code;
+        if (p >= add_lo && p < add_hi) {
+          const uint32_t sh = (0x10081800u >> (8 * code)) & 31u;  // SPRING code A0 G1 C2 T3 -> count byte A0 C1 T2 G3
+          ovf = ovf || ((t >> sh) & 255u) == 255u;
+          t += 1u << sh;
+        }
+        if (p >= hiP) t = 0u;
+        t4[e] = t;
+        if (!reset) {  // reorder.h:204-212: strict >, A,C,T,G order (the earlier row wins a tie; no count: A)
+          const uint32_t ka = ((t & 255u) << 2) | 3u, kc = (((t >> 8) & 255u) << 2) | 2u,
+                         kt = (((t >> 16) & 255u) << 2) | 1u, kg = (t >> 24) << 2;
+          const uint32_t ind = 3u - (max(max(ka, kc), max(kt, kg)) & 3u);
+          cdx = (0x1320u >> (4 * ind)) & 3u;  // count row -> SPRING code
+        }
+        if (p < Rn) codes |= cdx << (2 * e);
+      }
+      if (p0 < hiP) *reinterpret_cast<uint4 *>(nxt8 + p0) = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+    } else {
+#define MC_LOAD_CNT(I) (cur_wide ? cur[(I)] : unpack8(cur8[(I)]))
+      for (int e = 0; e < 4; e++) {
+        const int p = p0 + e;
+        if (p >= hiP) continue;
+        int4 t = make_int4(0, 0, 0, 0);
+        int code = 0;
+        if (!alias) {
+          if (p < cpy_hi) t = MC_LOAD_CNT(p + src_off);
+          if (p >= add_lo && p < add_hi) {
+            code = cur_base(rd + 1, p - add_lo, n, rev);
+            add_hot(t, cidx_of_code(code));
+          }
+        } else {  // reverse case 1 with d > 0 (reorder.h:159-174), closed form of the in-place loop
+          if (p >= d && p < n - shift) {
+            t = MC_LOAD_CNT(p % d);
+            for (int qq = p % d + d; qq <= p; qq += d) add_hot(t, cidx_of_code(cur_base(rd + 1, qq, n, rev)));
+          } else {
+            add_hot(t, cidx_of_code(cur_base(rd + 1, p, n, rev)));
+          }
+        }
+        if (out_wide) nxt[p] = t; else nxt8[p] = pack8(t);
+        ovf = ovf || max(max(t.x, t.y), max(t.z, t.w)) > 255;
+        if (p < Rn) codes |= (uint32_t)(reset ? code : argmax_code(t)) << (2 * e);
+      }
+#undef MC_LOAD_CNT
+    }
+    if (q < 128) reinterpret_cast<uint8_t *>(S.nref)[q] = (uint8_t)codes;
+  }
+  overflow = gballot(ovf, (int)threadIdx.x) != 0;
+  return Rn;
+}
+
+// commit of a speculative update: S.nref -> ref (LDS + global), revref = its reverse complement (LDS + global)
+__device__ __forceinline__ void commit_consensus(const DevParams &P, GLds &S, Chain *c, int R, int gl) {
+  wave_sync();
+  const bool in = gl < P.W;
+  const uint64_t limb = in ? S.nref[gl] : 0ull;
+  S.refs[0][LDS_PAD + gl] = limb;
+  if (in) c->ref[gl] = limb;
+  wave_sync();
+  uint64_t rl = 0;
+  if (in && 32 * gl < R) {
+    // bases [32 gl, 32 gl + 32) of the reverse complement = ref bases R-1-32gl downwards, complemented
+    const uint64_t w = lds_window(S.refs[0] + LDS_PAD, 2 * (R - 32 - 32 * gl));
+    uint64_t x = __builtin_bitreverse64(w);
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    const int nv = R - 32 * gl;
+    rl = ~x & (nv >= 32 ? ~0ull : ((1ull << (2 * nv)) - 1));
+  }
+  S.refs[1][LDS_PAD + gl] = rl;
+  if (in) c->revref[gl] = rl;
+  wave_sync();
+}
+
+__device__ __forceinline__ uint32_t take_slot_mc(uint32_t &slot, uint32_t *alloc, uint2 *chunk, uint32_t li, uint32_t next_seq, int gl) {
+  const uint32_t s0 = slot;
+  uint32_t nx = s0 + 1;
+  if ((nx & (CHUNK - 1)) == 0) {
+    uint32_t got = 0;
+    if (gl == 0) {
+      got = atomicAdd(alloc, CHUNK);
+      chunk[got / CHUNK] = make_uint2(li, next_seq);
+    }
+    nx = (uint32_t)__shfl((int)got, 0, G);
+  }
+  slot = nx;
+  return s0;
+}
+__device__ __forceinline__ void emit_rec_mc(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid, char rc, char flag,
+                                            long long pos, int gl) {
+  const uint32_t seq = h.n_emit;
+  h.n_emit = seq + 1;
+  uint32_t slot = h.e_slot;
+  const uint32_t idx = take_slot_mc(slot, &P.glob->e_alloc, P.e_chunk, li, seq + 1, gl);
+  h.e_slot = slot;
+  if (gl == 0)
+    P.e_rec[idx] = make_uint4(rid, (uint32_t)(uint8_t)rc | ((uint32_t)(uint8_t)flag << 8), (uint32_t)pos,
+                              (uint32_t)((unsigned long long)pos >> 32));
+}
+__device__ __forceinline__ void emit_single_mc(const DevParams &P, ChainHot &h, uint32_t li, uint32_t rid, int gl) {
+  const uint32_t seq = h.n_single;
+  h.n_single = seq + 1;
+  uint32_t slot = h.s_slot;
+  const uint32_t idx = take_slot_mc(slot, &P.glob->s_alloc, P.s_chunk, li, seq + 1, gl);
+  h.s_slot = slot;
+  if (gl == 0) P.s_rec[idx] = rid;
+}
+
+// phase B of one chain (apply_step with the shared state deferred to k_mg_mark).  false: the chain is done.
+template <int NQ>
+__device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, GLds &S, int gl) {
+  const int kind = h.prop_kind;
+  if (kind == PROP_FRESH) return true;  // first round: nothing proposed yet
+  if (h.finishing) {  // seed-needing chain found the pool empty
+    if (h.prev_unmatched) emit_single_mc(P, h, li, h.prev, gl);
+    h.done = 1; h.finishing = 0;
+    store_hot(c, h, gl);
+    return false;
+  }
+  const uint32_t owner = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;  // in flight while the update is computed
+  const bool fail_path = kind == PROP_NONE && h.mode == MODE_SEARCH;
+  bool do_upd = false, ureset = false, urev = false;
+  uint32_t urid = 0;
+  int ushift = 0;
+  if (kind == PROP_MATCH) { do_upd = true; urid = h.prop_rid; urev = h.prop_rev & 1; ushift = (int)h.prop_shift; }
+  else if (kind == PROP_SEED) { do_upd = true; urid = h.prop_rid; ureset = true; }
+  else if (fail_path && !h.left_search) { do_upd = true; urid = h.first_rid; ureset = true; urev = true; }  // reorder.h:567
+  int n = P.L, R_new = h.ref_len;
+  const int R_old = h.ref_len;
+  bool nw = false;
+  if (do_upd) {
+    if (!P.uniform_len) n = (int)P.lens[urid];
+    R_new = update_mc<NQ>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, false, nw, gl);
+    if (nw) {  // a count would pass 255: redo in the wide format
+      bool o2;
+      wave_sync();
+      R_new = update_mc<NQ>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, true, o2, gl);
+    }
+  }
+  if (owner != cid) {  // lost the read: retry, nothing committed
+    if (h.mode == MODE_SEARCH) h.retrying = 1;
+    store_hot(c, h, gl, 3, 4);
+    if (gl == 0) atomicAdd((unsigned long long *)&c->st_lost, 1ull);
+    return true;
+  }
+  if (do_upd) {
+    commit_consensus(P, S, c, R_new, gl);
+    h.ref_len = R_new;
+    h.cnt_buf ^= 1;
+    h.cnt_wide = nw;
+  }
+  if (kind == PROP_MATCH) {
+    const uint32_t rid = h.prop_rid;
+    const int shift = ushift;
+    const bool left = h.left_search;
+    long long ref_pos = h.ref_pos, cur_pos;
+    char rcch;
+    if (!urev) {  // reorder.h:490-497, :508
+      if (!left) { cur_pos = ref_pos + shift; ref_pos = cur_pos; }
+      else { cur_pos = ref_pos + R_old - shift - n; ref_pos = ref_pos + R_old - shift - R_new; }
+      rcch = left ? 'r' : 'd';
+    } else {  // reorder.h:528-535, :546
+      if (!left) { cur_pos = ref_pos + R_old + shift - n; ref_pos = ref_pos + R_old + shift - R_new; }
+      else { cur_pos = ref_pos - shift; ref_pos = cur_pos; }
+      rcch = left ? 'd' : 'r';
+    }
+    if (h.prev_unmatched) emit_rec_mc(P, h, li, h.prev, 'd', '0', 0, gl);
+    emit_rec_mc(P, h, li, rid, rcch, '1', cur_pos, gl);
+    h.prev_unmatched = 0; h.ref_pos = ref_pos; h.retrying = 0;
+  } else if (kind == PROP_SEED) {  // reorder.h:580-587, :600-613
+    const uint32_t rid = h.prop_rid;
+    if (gl == 0) atomicAdd((unsigned long long *)&c->n_unmatched, 1ull);
+    if (h.prev_unmatched) emit_single_mc(P, h, li, h.prev, gl);
+    h.prev_unmatched = 1; h.first_rid = rid; h.prev = rid;
+    h.ref_pos = 0; h.mode = MODE_SEARCH;
+  } else if (fail_path) {  // search failed (reorder.h:559-575)
+    h.retrying = 0;
+    h.num_unmatched_past++;
+    if (!h.left_search) { h.left_search = 1; h.ref_pos = 0; }
+    else { h.left_search = 0; h.mode = MODE_NEED_SEED; }  // (k_mg_mark put the chain on the needy bitmap: PK_WILLNEED)
+  }
+  store_hot(c, h, gl);
+  return true;
+}
+
+// find_seed for a 16-lane group (fused rounds: needy_cnt is kept by k_mg_mark).  See find_seed.
+__device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t cid, int gl, bool *is_last) {
+  int r = 0, tot = 0;
+  const long long top = P.glob->cursor;
+  const uint32_t nw = (P.Ktot + 31) / 32, myw = cid >> 5;
+  const uint32_t nblk = (nw + 63) / 64, myblk = myw >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // the 64 bitmap words of this chain's own block of 2048 chains
+    const uint32_t w = myblk * 64 + 4 * gl + k;
+    const uint32_t v = w < nw ? P.needy[w] : 0u;
+    if (w < myw) r += __popc(v);
+    else if (w == myw) r += __popc(v & ((1u << (cid & 31)) - 1u));
+  }
+  for (uint32_t b = gl; b < nblk; b += G) {
+    const uint32_t v = P.needy_cnt[b];
+    tot += (int)v;
+    if (b < myblk) r += (int)v;
+  }
+  const uint32_t rank = (uint32_t)gsum_i(r), nneedy = (uint32_t)gsum_i(tot);
+  *is_last = rank + 1 == nneedy;
+  uint32_t need = rank + 1;
+  if (top < 0) return -1;
+  constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // 256 bitmap words per block, 16 per lane
+  // the need-th highest untaken read of block blk (it holds at least that many)
+  auto pick = [&](long long blk, uint32_t want) -> long long {
+    const long long wtop = blk * WPB_ + (WPB_ - 1);
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cnt += __popcll(~P.taken[wtop - 16 * gl - k]);
+    const int inc = gincl_scan_i(cnt, gl);
+    const uint32_t m = gballot((uint32_t)inc >= want, (int)threadIdx.x);
+    const int wl = __ffs((int)m) - 1;
+    const uint32_t want2 = want - (uint32_t)__shfl(inc - cnt, wl, G);
+    // lane wl's sixteen words, one per lane
+    const long long wbase = wtop - 16 * wl;
+    const uint64_t u = ~P.taken[wbase - gl];
+    const int c1 = __popcll(u);
+    const int inc1 = gincl_scan_i(c1, gl);
+    const uint32_t m1 = gballot((uint32_t)inc1 >= want2, (int)threadIdx.x);
+    const int wk = __ffs((int)m1) - 1;
+    int kth = (int)want2 - __shfl(inc1 - c1, wk, G);
+    uint64_t v = gshfl_u64(u, wk);
+    for (int t = 1; t < kth; t++) v &= ~(1ull << (63 - __clzll(v)));
+    return (wbase - wk) * 64 + (63 - __clzll(v));
+  };
+  const long long bt = top >> UBLK_SHIFT;
+  {
+    const long long wtop = bt * WPB_ + (WPB_ - 1);
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cnt += __popcll(~P.taken[wtop - 16 * gl - k]);
+    const uint32_t tot0 = (uint32_t)gsum_i(cnt);
+    if (tot0 >= need) return pick(bt, need);
+    need -= tot0;
+  }
+  for (long long b0 = bt - 1; b0 >= 0; b0 -= G) {
+    const long long bb = b0 - gl;
+    const int u = bb >= 0 ? (int)P.ublk[bb] : 0;
+    const int incl = gincl_scan_i(u, gl);
+    const uint32_t total = (uint32_t)__shfl(incl, G - 1, G);
+    if (total < need) { need -= total; continue; }
+    const uint32_t mb = gballot((uint32_t)incl >= need, (int)threadIdx.x);
+    const int wb = __ffs((int)mb) - 1;
+    need -= (uint32_t)__shfl(incl - u, wb, G);
+    return pick(b0 - wb, need);
+  }
+  return -1;
+}
+
+constexpr int INF_CODE = 0x7fffffff;
+
+// quick verdict on a fetched tag quad: can dictionary l hold the key (a slot with its fingerprint, or a full
+// bucket whose run may continue in the next one)?  `other`: same question for the other dictionary.
+__device__ __forceinline__ bool tags_may_hold(const uint4 &t, uint64_t hsh, int l, bool &other) {
+  const uint32_t mine = (fp30_of(hsh) << 2) | ((uint32_t)l << 1), theirs = mine ^ 2u;
+  const bool full = t.w != 0;
+  other = (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || (t.w & ~1u) == theirs || full;
+  return (t.x & ~1u) == mine || (t.y & ~1u) == mine || (t.z & ~1u) == mine || (t.w & ~1u) == mine || full;
+}
+
+// probes with priority codes [c_lo, c_hi) (code = shift << 2 | rev << 1 | dict; at most 4 * G of them): lane gl takes
+// codes c_lo + gl + 16 i, fetches the tag quads of all of them first, and only walks into eval_probe where the
+// quad does not already prove the key absent (2 % of the probes).  Winner = lowest code that hit.
+__device__ __forceinline__ void batch_mc(const DevParams &P, GLds &S, lds_u32_t *stage, int c_lo, int c_hi, int ref_len,
+                                         int lane, int gl, int &wcode, uint32_t &wrid) {
+  const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
+  const int klen2 = 2 * P.wl;
+  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
+  lds_u32_t *s_best = (lds_u32_t *)&S.best;
+  if (gl == 0) *s_best = (uint32_t)INF_CODE;
+  wave_sync();
+  uint4 tg[4];
+  uint64_t key[4];
+  bool val[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int code = c_lo + gl + G * i;
+    const int l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
+    val[i] = code < c_hi && probe_valid(P, l, rev, shift, ref_len);
+    key[i] = 0;
+    tg[i] = make_uint4(0, 0, 0, 0);
+    if (val[i]) {
+      const int ds = l ? P.dstart[1] : P.dstart[0];
+      key[i] = lds_window(rev ? srev : sref, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
+      tg[i] = P.fpt[bucket_of(mix64(key[i]), P.bshift) * 2];
+    }
+  }
+  // which of this lane's probes need a closer look; `pres` for the tail
+  uint32_t pend = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int code = c_lo + gl + G * i;
+    bool other = false;
+    if (val[i] && tags_may_hold(tg[i], mix64(key[i]), code & 1, other)) pend |= 1u << i;
+    if (code < c_hi && code < 128) S.pres[code] = other ? 1 : 0;
+  }
+  // the closer looks of all lanes run together, one per lane and pass, lowest code first (a pass is a chain of
+  // dependent loads: record / taken bit / candidate read -- four chains' worth of them in flight at once)
+  int best = INF_CODE;
+  uint32_t brid = 0;
+  while (__ballot(pend != 0)) {
+    if (pend) {
+      const int i = __ffs((int)pend) - 1;
+      pend &= pend - 1;
+      const int code = c_lo + gl + G * i;
+      const int l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
+      const uint64_t k = i == 0 ? key[0] : i == 1 ? key[1] : i == 2 ? key[2] : key[3];
+      if (!(*(volatile lds_u32_t *)s_best < (uint32_t)code)) {
+        bool hit = false, keyok = false, other = false;
+        uint32_t rid = 0, ncand = 0;
+        eval_probe<false>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k), hit, rid, keyok, ncand, other, s_best, stage, lane);
+        if (other && code < 128) S.pres[code] = 1;
+        if (hit) { best = code; brid = rid; pend = 0; }
+      } else pend = 0;  // a lower code has hit: nothing of this lane can win any more
+    }
+  }
+  wcode = gmin_i(best);
+  const uint32_t wm = gballot(best == wcode, lane);
+  wrid = (uint32_t)__shfl((int)brid, __ffs((int)wm) - 1, G);
+}
+
+// every remaining probe (shifts [t0, maxshift)), one table fetch per distinct consensus window (see probe_tail)
+__device__ __forceinline__ void tail_mc(const DevParams &P, GLds &S, lds_u32_t *stage, int t0, int ref_len, int lane, int gl,
+                                        int &wcode, uint32_t &wrid) {
+  const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
+  const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
+  const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
+  lds_u32_t *s_best = (lds_u32_t *)&S.best;
+  if (gl == 0) *s_best = (uint32_t)INF_CODE;
+  wave_sync();
+  const int nF = wl + ms - t0;
+  int best = INF_CODE;
+  uint32_t brid = 0;
+  for (int base = 0; base < 2 * nF; base += 4 * G) {
+    uint4 tg[4];
+    uint64_t key[4];
+    uint32_t desc[4];  // bit 31 rev, 30 v1, 29 v0, low bits i
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = base + gl + G * k;
+      bool v0 = false, v1 = false;
+      int rev = 0, i = 0;
+      if (idx < 2 * nF) {
+        rev = idx >= nF;
+        i = rev ? idx - nF : idx;
+        if (!rev) {
+          const int sh0 = t0 + i, sh1 = sh0 - wl;
+          v0 = probe_valid(P, 0, 0, sh0, ref_len);
+          v1 = sh1 >= t0 && probe_valid(P, 1, 0, sh1, ref_len);
+          if (v0 && sh1 >= 0 && sh1 < t0) v0 = S.pres[4 * sh1 + 1] != 0;
+        } else {
+          const int sh1 = t0 + i, sh0 = sh1 - wl;
+          v1 = probe_valid(P, 1, 1, sh1, ref_len);
+          v0 = sh0 >= t0 && probe_valid(P, 0, 1, sh0, ref_len);
+          if (v1 && sh0 >= 0 && sh0 < t0) v1 = S.pres[4 * sh0 + 2] != 0;
+        }
+      }
+      desc[k] = ((uint32_t)rev << 31) | ((uint32_t)v1 << 30) | ((uint32_t)v0 << 29) | (uint32_t)i;
+      key[k] = 0;
+      tg[k] = make_uint4(0, 0, 0, 0);
+      if (v0 || v1) {
+        const int off = rev ? s1 - (t0 + i) : s0 + t0 + i;
+        key[k] = lds_window(rev ? srev : sref, 2 * off) & kmask;
+        tg[k] = P.fpt[bucket_of(mix64(key[k]), P.bshift) * 2];
+      }
+    }
+    // pending (window, dictionary) pairs of this lane: bit 2k + j, j = 0 the probe with the lower priority code of
+    // window k (forward: dictionary 1, its shift is wl lower; reverse: dictionary 0)
+    uint32_t pend = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t e = desc[k];
+      if (!(e & (3u << 29))) continue;
+      const int rev = (int)(e >> 31);
+      const uint64_t hsh = mix64(key[k]);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int l = rev ? j : 1 - j;
+        bool other = false;
+        if (((e >> (29 + l)) & 1u) && tags_may_hold(tg[k], hsh, l, other)) pend |= 1u << (2 * k + j);
+      }
+    }
+    while (__ballot(pend != 0)) {
+      if (pend) {
+        const int b = __ffs((int)pend) - 1;
+        pend &= pend - 1;
+        const int k = b >> 1, j = b & 1;
+        const uint32_t e = k == 0 ? desc[0] : k == 1 ? desc[1] : k == 2 ? desc[2] : desc[3];
+        const uint64_t ky = k == 0 ? key[0] : k == 1 ? key[1] : k == 2 ? key[2] : key[3];
+        const int rev = (int)(e >> 31), i = (int)(e & 0xfffffu);
+        const int l = rev ? j : 1 - j;
+        const int sh0 = rev ? t0 + i - wl : t0 + i, sh1 = rev ? t0 + i : t0 + i - wl;
+        const int sh = l ? sh1 : sh0, code = probe_code(sh, rev, l);
+        if (code < best && !(*(volatile lds_u32_t *)s_best < (uint32_t)code)) {
+          bool hit = false, keyok = false, other = false;
+          uint32_t rid = 0, ncand = 0;
+          eval_probe<false>(P, rev ? srev : sref, l, rev, sh, ref_len, ky, mix64(ky), hit, rid, keyok, ncand, other, s_best, stage, lane);
+          if (hit) { best = code; brid = rid; }
+        }
+      }
+    }
+  }
+  wcode = gmin_i(best);
+  const uint32_t wm = gballot(best == wcode, lane);
+  wrid = (uint32_t)__shfl((int)brid, __ffs((int)wm) - 1, G);
+}
+
+// phase A of one chain (search_step: proposal word + direct reservation unless MG)
+template <bool MG>
+__device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds &S, lds_u32_t *stage,
+                                          int lane, int gl) {
+  if (h.mode == MODE_NEED_SEED) {
+    bool is_last;
+    const long long seed = find_seed_mc(P, cid, gl, &is_last);
+    if (seed >= 0) {
+      h.prop_kind = PROP_SEED;
+      h.prop_rid = (uint32_t)seed;
+      h.cursor_writer = is_last;  // the last-ranked needy chain proposes the lowest seed of the round
+      if (gl == 0) {
+        P.prop[cid] = ((unsigned long long)PK_SEED << 32) | (uint32_t)seed | (is_last ? PK_CURSOR_BIT : 0ull);
+        if (!MG) atomicMin(&P.resv[seed], cid);
+      }
+    } else {
+      h.prop_kind = PROP_NONE;
+      h.finishing = 1;  // no reads left (reorder.h:593-599); applied in phase B
+      // (the last-ranked chain finding nothing means the pool is exhausted: k_mg_mark sends the cursor to -1)
+      if (gl == 0) P.prop[cid] = ((unsigned long long)PK_NOSEED << 32) | (is_last ? PK_CURSOR_BIT : 0ull);
+    }
+    store_hot(c, h, gl, 2, 4);
+    return;
+  }
+  if (!h.retrying) {  // iteration start bookkeeping (reorder.h:433-439), once per iteration
+    if (h.num_reads_thr % 1000000u == 0) {
+      if ((float)h.num_unmatched_past > 0.5f * 1000000) h.stop_searching = 1;
+      h.num_unmatched_past = 0;
+    }
+    h.num_reads_thr++;
+  }
+  if (h.stop_searching) {
+    h.prop_kind = PROP_NONE;
+    store_hot(c, h, gl, 2, 4);
+    if (gl == 0) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
+    return;
+  }
+  const int ref_len = h.ref_len;
+  const int wide = (h.prev_unmatched && P.seed_wide) ? 1 : 0;
+  int wcode = INF_CODE, t0 = 0;
+  uint32_t wrid = 0;
+  for (int ph = 0; ph < 6 && t0 < P.maxshift; ph++) {
+    const int w = wide ? P.plan[1][ph] : P.plan[0][ph];
+    if (w <= 0) break;
+    batch_mc(P, S, stage, 4 * t0, 4 * (t0 + w), ref_len, lane, gl, wcode, wrid);
+    t0 += w;
+    if (wcode != INF_CODE) break;
+  }
+  if (wcode == INF_CODE && t0 < P.maxshift) {
+    wave_sync();  // pres
+    tail_mc(P, S, stage, t0, ref_len, lane, gl, wcode, wrid);
+  }
+  if (wcode != INF_CODE) {
+    h.prop_rid = wrid;
+    h.prop_shift = (uint32_t)(wcode >> 2);
+    h.prop_rev = (uint32_t)(((wcode >> 1) & 1) | ((wcode & 1) << 1));  // rev | dict << 1
+    h.prop_kind = PROP_MATCH;
+    if (gl == 0) {
+      P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid;
+      if (!MG) atomicMin(&P.resv[wrid], cid);
+    }
+  } else {
+    h.prop_kind = PROP_NONE;
+    // a failed left search sends the chain for a new seed (apply step): k_mg_mark puts it on the needy bitmap
+    if (gl == 0) P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
+  }
+  store_hot(c, h, gl, 2, 4);
+}
+
+}  // namespace mc
+
+// NQ = position quads per lane: 4 * 16 * NQ >= Lpad (3: reads up to 192 bases, 8: up to 511)
+template <int NQ, bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round_mc(DevParams P) {
+  __shared__ mc::GLds s_g[mc::CPW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
+  const int lane = threadIdx.x, g = lane >> 4, gl = lane & (mc::G - 1);
+  // this wavefront's chains: four entries of one class list (classes in the order 0, 1, 2, 3: the long rounds first)
+  uint32_t li;
+  {
+    const uint32_t n0 = P.ord_cnt[0], n1 = P.ord_cnt[1], n2 = P.ord_cnt[2], n3 = P.ord_cnt[3];
+    const uint32_t w0 = (n0 + 3) / 4, w1 = w0 + (n1 + 3) / 4, w2 = w1 + (n2 + 3) / 4, w3 = w2 + (n3 + 3) / 4;
+    const uint32_t b = blockIdx.x;
+    if (b >= w3) return;
+    const uint32_t cls = b < w0 ? 0u : b < w1 ? 1u : b < w2 ? 2u : 3u;
+    const uint32_t base = cls == 0 ? 0u : cls == 1 ? w0 : cls == 2 ? w1 : w2;
+    const uint32_t cnt = cls == 0 ? n0 : cls == 1 ? n1 : cls == 2 ? n2 : n3;
+    const uint32_t j = (b - base) * mc::CPW + (uint32_t)g;
+    if (j >= cnt) return;  // (whole groups leave; the others never wait for them: no block barriers below)
+    li = P.ord[(size_t)cls * P.K + j];
+  }
+  const uint32_t cid = P.c0 + li;
+  Chain *c = &P.chains[li];
+  mc::GLds &S = s_g[g];
+  ChainHot h;
+  {
+    const uint4 *hq = reinterpret_cast<const uint4 *>(&c->h);
+    const uint4 q0 = hq[0], q1 = hq[1], q2 = hq[2], q3 = hq[3];
+    for (int i = gl; i < LDS_LIMBS; i += mc::G) {
+      const int k = i - LDS_PAD;
+      const bool in = k >= 0 && k < P.W;
+      S.refs[0][i] = in ? c->ref[k] : 0ull;
+      S.refs[1][i] = in ? c->revref[k] : 0ull;
+    }
+    if (gl < 2) S.rd[gl ? 17 : 0] = 0ull;
+    h.ref_pos = (long long)(((unsigned long long)q0.y << 32) | q0.x);
+    h.ref_len = (int32_t)q0.z; h.e_slot = q0.w;
+    h.prev = q1.x; h.first_rid = q1.y; h.n_emit = q1.z; h.n_single = q1.w;
+    h.s_slot = q2.x; h.num_reads_thr = q2.y; h.num_unmatched_past = q2.z; h.prop_rid = q2.w;
+    h.flags = q3.x;
+    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+  }
+  wave_sync();
+  if (h.done) {
+    if (gl == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+    return;
+  }
+  if (!mc::apply_mc<NQ>(P, c, cid, li, h, S, gl)) {
+    if (gl == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
+    return;
+  }
+  mc::search_mc<MG>(P, c, cid, h, S, (lds_u32_t *)s_stage, lane, gl);
+}
+
+#endif

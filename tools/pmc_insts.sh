@@ -3,7 +3,7 @@
 out=$1; n=${2:-100000000}; export TMPDIR=/tmp; mkdir -p $out
 [ -n "$3" ] && export SPRING_AMD_LIB=$3
 run() { name=$1; shift
-  timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -o pmc -- python tools/scale_probe.py $n,150,0 > $out/$name.log 2>&1
+  timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -o pmc -- python tools/scale_probe.py $n,150,65536 > $out/$name.log 2>&1
 }
 run i1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES
 run i2 SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
