@@ -13,6 +13,8 @@ constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
 constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
 constexpr uint32_t DEEP_BIN = 16;   // bins with at least this many reads are tail-trimmed between rounds
 constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
+constexpr uint32_t MARK_BLOCK = 256; // chains per block of k_mg_mark = per class-list segment (k_round_mc)
+constexpr uint32_t MC_WAVES_PER_BLOCK = MARK_BLOCK / 4 + 3;  // wavefronts of four chains a segment can need (each class rounded up)
 constexpr int UBLK_SHIFT = 14;      // DevParams::ublk counts untaken reads per 2^14 reads (256 bitmap words)
 constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in LDS
 constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
@@ -105,12 +107,13 @@ struct DevParams {
   uint32_t *needy_cnt_next;  // the buffer k_mg_mark of THIS round fills (zeroed by the previous k_mg_mark)
   int fused;                 // 1: k_round (apply + search in one kernel)
   int mc;                    // 1: four chains per wavefront (k_round_mc) where it applies
-  // k_round_mc runs chains of one class per wavefront (four chains of a wavefront take the union of their paths):
-  // k_mg_mark sorts the local chains by what the next round will ask of them -- 0 left search after a failed right
-  // search, 1 first search of a new seed, 2 search after a proposed match, 3 seed pick -- into ord[cls * K + i];
-  // ord_cnt[cls] entries each (double-buffered like needy_cnt).  Chains that are done appear in no list.
+  // k_round_mc runs chains of one class per wavefront (the four chains of a wavefront take the union of their
+  // paths): k_mg_mark sorts the running local chains of every block of MARK_BLOCK consecutive chain ids by what the
+  // next round will ask of them -- 0 left search after a failed right search, 1 first search of a new seed, 2 search
+  // after a proposed match, 3 seed pick -- into ord[block * MARK_BLOCK ...] (local chain indices, class 0 first) and
+  // writes the four class sizes to ord_cnt[block].  No atomics, rewritten every round; done chains are in no list.
   uint32_t *ord;
-  uint32_t *ord_cnt, *ord_cnt_next;
+  uint4 *ord_cnt;
   Globals *glob;
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;

@@ -1668,31 +1668,43 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   }
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
-  if (P.ord) {  // class lists: a slot per chain, one global atomic per class and block (the order inside a class is free)
-    __shared__ uint32_t s_cnt[4], s_base[4];
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t off = 0;
+  if (P.ord) {  // class lists of this block's chains (k_round_mc): class 0 first, no atomics
+    static_assert(MARK_BLOCK == 256, "k_mg_mark runs 256 chains per block");
+    __shared__ uint32_t s_wc[4][4];  // [wave][class]
+    const int wv = threadIdx.x >> 6;
+    uint32_t mypos = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint64_t m = __ballot(cls == k);
-      uint32_t wbase = 0;
-      if (m && lane == 0) wbase = atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
-      wbase = (uint32_t)__shfl((int)wbase, 0, 64);
-      if (cls == k) off = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+      if (lane == 0) s_wc[wv][k] = (uint32_t)__popcll(m);
+      if (cls == k) mypos = (uint32_t)__popcll(m & ((1ull << lane) - 1));
     }
     __syncthreads();
-    if (threadIdx.x < 4) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&P.ord_cnt_next[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
-    __syncthreads();
-    if (cls >= 0) P.ord[(size_t)cls * P.K + s_base[cls] + off] = cid - P.c0;
-    if (cid < 4) P.ord_cnt[cid] = 0;
+    if (cls >= 0) {
+      uint32_t base = 0;
+      for (int k = 0; k < cls; k++) base += s_wc[0][k] + s_wc[1][k] + s_wc[2][k] + s_wc[3][k];
+      for (int w = 0; w < wv; w++) base += s_wc[w][cls];
+      P.ord[(size_t)blockIdx.x * MARK_BLOCK + base + mypos] = cid - P.c0;
+    }
+    if (threadIdx.x == 0)
+      P.ord_cnt[blockIdx.x] = make_uint4(s_wc[0][0] + s_wc[1][0] + s_wc[2][0] + s_wc[3][0], s_wc[0][1] + s_wc[1][1] + s_wc[2][1] + s_wc[3][1],
+                                         s_wc[0][2] + s_wc[1][2] + s_wc[2][2] + s_wc[3][2], s_wc[0][3] + s_wc[1][3] + s_wc[2][3] + s_wc[3][3]);
   }
 }
-// first round: every chain in class 2
+// first round: every local chain in class 2
 __global__ void k_init_ord(DevParams P) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < P.K) P.ord[(size_t)2 * P.K + i] = i;
-  if (i < 4) { P.ord_cnt[i] = i == 2 ? P.K : 0u; P.ord_cnt_next[i] = 0u; }
+  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;  // global chain id; block = k_mg_mark's block
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const bool local = cid >= P.c0 && cid - P.c0 < P.K;
+  const uint64_t m = __ballot(local);
+  uint32_t wbase = 0;
+  if ((threadIdx.x & 63) == 0 && m) wbase = atomicAdd(&s_n, (uint32_t)__popcll(m));
+  wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+  if (local) P.ord[(size_t)blockIdx.x * MARK_BLOCK + wbase + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = cid - P.c0;
+  __syncthreads();
+  if (threadIdx.x == 0) P.ord_cnt[blockIdx.x] = make_uint4(0u, 0u, s_n, 0u);
 }
 
 // ------------------------------------------------------------ K7 finalize / emit
@@ -1834,7 +1846,7 @@ void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_
 void launch_init_chains(hipStream_t st, const DevParams &P) {
   if (P.Ktot) hipLaunchKernelGGL(k_init_seeds, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
   if (!P.K) return;
-  if (P.ord) hipLaunchKernelGGL(k_init_ord, GRID1(P.K, 256), dim3(256), 0, st, P);
+  if (P.ord) hipLaunchKernelGGL(k_init_ord, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 #define CALL(N) hipLaunchKernelGGL(k_init_chains<N>, dim3((P.K + 3) / 4), dim3(256), 0, st, P)
   NP_DISPATCH(CALL);
 #undef CALL
@@ -1876,7 +1888,9 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   // four chains per wavefront (k_round_mc) unless the run needs what only the one-chain kernel has: the
   // reference-equivalent work counters, or the deep-bin machinery (tail trimming, balanced scan, resumed searches)
   if (P.mc && !stats && !P.deep_bins) {
-    const dim3 g4((P.K + 3) / 4 + 3);  // (every class list is rounded up to whole wavefronts)
+    // one class-list segment per block of MARK_BLOCK chain ids that holds local chains, a fixed number of wavefronts each
+    const uint32_t nseg = (P.c0 + P.K + MARK_BLOCK - 1) / MARK_BLOCK - P.c0 / MARK_BLOCK;
+    const dim3 g4(nseg * MC_WAVES_PER_BLOCK);
     if (P.Lpad <= 192) {
       if (mg) hipLaunchKernelGGL((k_round_mc<3, true>), g4, b, 0, st, P);
       else hipLaunchKernelGGL((k_round_mc<3, false>), g4, b, 0, st, P);

@@ -138,7 +138,6 @@ struct spring_reorder_ctx {
   uint64_t nrec = 0, nsing = 0, cap = 0;
   bool mg = false;
   uint32_t *cnt_buf[2] = {nullptr, nullptr};  // needy_cnt double buffer (reorder_device.h)
-  uint32_t *ord_cnt[2] = {nullptr, nullptr};  // class-list sizes, double buffer
   uint64_t round_no = 0;
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
@@ -1014,13 +1013,11 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     HIPCHK(hipMemsetAsync(ctx->cnt_buf[0], 0, 2 * nblk * 4, st));
     HIPCHK(hipMemsetAsync(P.alive_wave, 0, ((size_t)Ktot + 63) / 64 * 4, st));
     P.needy_cnt = ctx->cnt_buf[1];  // what the first round reads: nobody needs a seed yet
-    DMALLOC(P.ord, (size_t)4 * std::max<uint32_t>(K, 1) * 4);
-    DMALLOC(ctx->ord_cnt[0], 64);
-    ctx->ord_cnt[1] = ctx->ord_cnt[0] + 8;
-    P.ord_cnt = ctx->ord_cnt[1];  // what the first round reads (k_init_ord: every chain in class 2)
-    P.ord_cnt_next = ctx->ord_cnt[0];
+    const size_t nmark = ((size_t)Ktot + MARK_BLOCK - 1) / MARK_BLOCK;  // blocks of k_mg_mark = class-list segments
+    DMALLOC(P.ord, nmark * MARK_BLOCK * 4);
+    DMALLOC(P.ord_cnt, nmark * sizeof(uint4));
   } else {
-    P.ord = nullptr; P.ord_cnt = P.ord_cnt_next = nullptr;
+    P.ord = nullptr; P.ord_cnt = nullptr;
   }
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   launch_init_taken(st, P.taken, nwords, n, P.ublk);
@@ -1048,8 +1045,6 @@ static void set_round_buffers(spring_reorder_ctx *ctx) {
   const int w = (int)(ctx->round_no & 1);
   P.needy_cnt = ctx->cnt_buf[w ^ 1];
   P.needy_cnt_next = ctx->cnt_buf[w];
-  P.ord_cnt = ctx->ord_cnt[w ^ 1];
-  P.ord_cnt_next = ctx->ord_cnt[w];
 
 }
 
@@ -1121,12 +1116,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
       HIPCHK(hipStreamSynchronize(st));
     }
     HIPCHK(hipGetLastError());
-    if (getenv("SPRING_REORDER_DEBUG") && P.ord) {  // progress on stderr, no effect on results
-      uint32_t oc[4] = {0, 0, 0, 0};
-      (void)hipMemcpy(oc, P.ord_cnt_next, 16, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[chains] rounds %llu running %u | next round: left %u fresh %u match %u seed %u\n",
-              (unsigned long long)rounds, *h_alive, oc[0], oc[1], oc[2], oc[3]);
-    }
+    if (getenv("SPRING_REORDER_DEBUG")) fprintf(stderr, "[chains] rounds %llu running %u\n", (unsigned long long)rounds, *h_alive);
     if (timed) {
       for (int r = 0; r < R; r++) {
         float ms = 0;

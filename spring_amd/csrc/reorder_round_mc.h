@@ -608,24 +608,28 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
 }  // namespace mc
 
 // NQ = position quads per lane: 4 * 16 * NQ >= Lpad (3: reads up to 192 bases, 8: up to 511)
+#ifndef SR_MC_WAVES
+#define SR_MC_WAVES 5  // waves per SIMD the kernel is compiled for (512 / SR_MC_WAVES VGPRs)
+#endif
 template <int NQ, bool MG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round_mc(DevParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES, SR_MC_WAVES))) void k_round_mc(DevParams P) {
   __shared__ mc::GLds s_g[mc::CPW];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
   const int lane = threadIdx.x, g = lane >> 4, gl = lane & (mc::G - 1);
-  // this wavefront's chains: four entries of one class list (classes in the order 0, 1, 2, 3: the long rounds first)
+  // this wavefront's chains: four entries of one class of one list segment (classes in the order 0, 1, 2, 3)
   uint32_t li;
   {
-    const uint32_t n0 = P.ord_cnt[0], n1 = P.ord_cnt[1], n2 = P.ord_cnt[2], n3 = P.ord_cnt[3];
-    const uint32_t w0 = (n0 + 3) / 4, w1 = w0 + (n1 + 3) / 4, w2 = w1 + (n2 + 3) / 4, w3 = w2 + (n3 + 3) / 4;
-    const uint32_t b = blockIdx.x;
+    const uint32_t seg = P.c0 / MARK_BLOCK + blockIdx.x / MC_WAVES_PER_BLOCK, b = blockIdx.x % MC_WAVES_PER_BLOCK;
+    const uint4 n = P.ord_cnt[seg];
+    const uint32_t w0 = (n.x + 3) / 4, w1 = w0 + (n.y + 3) / 4, w2 = w1 + (n.z + 3) / 4, w3 = w2 + (n.w + 3) / 4;
     if (b >= w3) return;
     const uint32_t cls = b < w0 ? 0u : b < w1 ? 1u : b < w2 ? 2u : 3u;
-    const uint32_t base = cls == 0 ? 0u : cls == 1 ? w0 : cls == 2 ? w1 : w2;
-    const uint32_t cnt = cls == 0 ? n0 : cls == 1 ? n1 : cls == 2 ? n2 : n3;
-    const uint32_t j = (b - base) * mc::CPW + (uint32_t)g;
+    const uint32_t wbase = cls == 0 ? 0u : cls == 1 ? w0 : cls == 2 ? w1 : w2;
+    const uint32_t cnt = cls == 0 ? n.x : cls == 1 ? n.y : cls == 2 ? n.z : n.w;
+    const uint32_t lbase = cls == 0 ? 0u : cls == 1 ? n.x : cls == 2 ? n.x + n.y : n.x + n.y + n.z;
+    const uint32_t j = (b - wbase) * mc::CPW + (uint32_t)g;
     if (j >= cnt) return;  // (whole groups leave; the others never wait for them: no block barriers below)
-    li = P.ord[(size_t)cls * P.K + j];
+    li = P.ord[(size_t)seg * MARK_BLOCK + lbase + j];
   }
   const uint32_t cid = P.c0 + li;
   Chain *c = &P.chains[li];
