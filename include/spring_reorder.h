@@ -48,7 +48,8 @@ typedef struct {
   int32_t search_wpb;     /* chains (wavefronts) per block of the search kernel: 1 / 2 / 4                 */
   int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per search block  */
   int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
-  int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (k_round: apply + search) + mark  */
+  int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (apply + search) + mark; 2: the fused round
+                             always with one chain per wavefront (k_round) instead of four (k_round_mc) where that applies */
   int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
 } spring_reorder_opts;
 
@@ -63,6 +64,8 @@ typedef struct {
   double ms_search_kernel;
   uint64_t search_launches;
   uint64_t device_bytes;   /* bytes of HBM the context holds */
+  uint64_t chains;         /* K the chain phase ran with (opts.num_chains, or what the default rule chose) */
+  uint64_t deep_pool;      /* 1: the dictionary averages >= 1.3 reads per key (the deep-coverage default applies) */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);
@@ -117,6 +120,10 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx);
 /* reorder() (reorder.h:320-641): the greedy chain search, K chains in
  * lock-step rounds (search_match reorder.h:246-318, updaterefcount :110-220). */
 int spring_reorder_run_chains(spring_reorder_ctx *ctx);
+/* The chain count run_chains() uses when opts.num_chains = 0 (valid after build_dict): n / 1024, or n / 128 when the
+ * dictionary averages >= 1.3 reads per key (*deep = 1), at most 65536.  A multi-GPU caller that wants the pool to equal
+ * the single-GPU default passes this value (rounded up to a multiple of the world size) to mg_begin / mg_run. */
+int spring_reorder_auto_chains(spring_reorder_ctx *ctx, uint32_t *chains, int32_t *deep);
 
 /* ---- FASTQ front end.  The sequence side of preprocess() (src/preprocess.cpp:186-214,:293-304;
  * read_fastq_block src/util.cpp:31-54; write_dna_in_bits / write_dnaN_in_bits src/util.cpp:269-294,:322-348) on

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("SPRING_AMD_LIB") or os.path.join(HERE, "lib", "libspr
 EXPORTS = [
     "spring_reorder_default_opts", "spring_reorder_last_error", "spring_reorder_trim_pool", "spring_reorder_run", "spring_reorder_create",
     "spring_reorder_destroy", "spring_reorder_load_dna", "spring_reorder_load_dna_device",
-    "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_finalize",
+    "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_auto_chains", "spring_reorder_finalize",
     "spring_reorder_mg_begin", "spring_reorder_mg_search", "spring_reorder_mg_slice", "spring_reorder_mg_apply",
     "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
     "spring_mg_rccl_unique_id", "spring_mg_comm_create_rccl", "spring_mg_comm_create_host", "spring_mg_comm_destroy",
@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 + [("numkeys", C.c_uint64 * 2), ("dict_numreads", C.c_uint64 * 2)]
                 + [(k, C.c_double) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize", "ms_total",
                                              "ms_search_kernel")]
-                + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64)])
+                + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64), ("chains", C.c_uint64),
+                   ("deep_pool", C.c_uint64)])
 
     def asdict(self):
         d = {}
@@ -97,6 +98,7 @@ def lib():
     L.spring_reorder_load_dna_device.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int32]
     L.spring_reorder_build_dict.argtypes = [vp]
     L.spring_reorder_run_chains.argtypes = [vp]
+    L.spring_reorder_auto_chains.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.spring_reorder_finalize.argtypes = [vp]
     L.spring_reorder_mg_begin.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.spring_reorder_mg_search.argtypes = [vp]

@@ -1060,6 +1060,15 @@ static int running_chains(spring_reorder_ctx *ctx, std::vector<uint32_t> &buf, u
   return 0;
 }
 
+int spring_reorder_auto_chains(spring_reorder_ctx *ctx, uint32_t *chains, int32_t *deep) {
+  if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  if (ctx->stage < ST_DICT) return fail(SPRING_REORDER_E_STATE, "auto_chains: build_dict first");
+  const bool d = dict_is_deep(ctx);
+  if (chains) *chains = auto_chains(ctx->n, d);
+  if (deep) *deep = d ? 1 : 0;
+  return 0;
+}
+
 int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "run_chains: build_dict first");
@@ -1072,6 +1081,8 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   const bool literal = ctx->o.force_literal_update != 0;
   // one chain kernel per round (k_round + k_mg_mark) unless the literal consensus path or the two-kernel round is asked for
   const bool fused = !literal && ctx->o.fused >= 0;
+  ctx->stats.chains = K;
+  ctx->stats.deep_pool = dict_is_deep(ctx) ? 1 : 0;
   int r0 = setup_chains(ctx, K, 0, K, fused, nullptr);
   if (r0) return r0;
   DevParams &P = ctx->P;
@@ -1153,6 +1164,8 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   if (ctx->o.force_literal_update) return fail(SPRING_REORDER_E_ARG, "mg_begin: the literal consensus path only exists in the two-kernel round");
   HIPCHK(hipSetDevice(ctx->dev));
   const uint32_t K = total_chains / world;
+  ctx->stats.chains = total_chains;
+  ctx->stats.deep_pool = dict_is_deep(ctx) ? 1 : 0;
   int r = setup_chains(ctx, K, rank * K, total_chains, true, d_prop);
   if (r) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));

@@ -36,7 +36,7 @@ class ReorderOpts:
     search_wpb: int = 0
     dbg_search_lds: int = 0
     dbg_apply_lds: int = 0
-    fused: int = 0            # -1: the two-kernel round
+    fused: int = 0            # -1: the two-kernel round; 2: fused round with one chain per wavefront everywhere
     deep_bins: int = 0        # 1 / -1: force the bin-trimming kernel variant on / off (0 = from the dictionary)
 
     def to_c(self):
@@ -131,6 +131,12 @@ class ReorderStage:
 
     def run_chains(self):  # reorder() (reorder.h:320-641)
         _chk(self._L.spring_reorder_run_chains(self._h))
+
+    def auto_chains(self):
+        """-> (chains, deep): what run_chains() uses for num_chains = 0 (after build_dict)."""
+        k, d = C.c_uint32(0), C.c_int32(0)
+        _chk(self._L.spring_reorder_auto_chains(self._h, C.byref(k), C.byref(d)))
+        return k.value, bool(d.value)
 
     def finalize(self):
         _chk(self._L.spring_reorder_finalize(self._h))

@@ -66,6 +66,16 @@ def test_fuzz_gpu_equals_oracle(block):
             ser = po.reorder_serial(read, ln, L)
             for k in KEYS:
                 assert np.array_equal(got[k], ser[k]), ("seed", seed, "serial", k)
+        # the production build (no counters): four chains per wavefront on shallow dictionaries; with the deep-bin
+        # variant forced on, the balanced scan and the resumed searches; and the one-chain-per-wavefront round
+        rng = np.random.default_rng(seed + 77)
+        kw = dict(deep_bins=int(rng.choice([0, 1, -1])), fused=int(rng.choice([0, 0, 2])))
+        got2 = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, **kw))
+        for k in KEYS:
+            assert np.array_equal(got2[k], want[k]), ("seed", seed, "no-stats", kw, "n", n, "L", L, "K", K, "T", T, k)
+        assert np.array_equal(got2["tid_off"], want["tid_off"]), ("seed", seed, "no-stats", kw)
+        for k in ("lost", "unmatched"):
+            assert got2["stats"][k] == want["stats"][k], ("seed", seed, "no-stats", kw, k)
 
 
 @pytest.mark.parametrize("block", range(2))

@@ -409,3 +409,75 @@ def test_parity_10M_reads():
     assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
     for k in ("probes", "keyok", "cands", "hits", "unmatched", "iterations", "lost"):
         assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
+
+
+def test_1M_150bp_k1_reference_counters_on_the_gpu():
+    """SURVEY.md section 8(c), second data set (1 M x 150 bp, default_rng(11), G = 6 Mb): the counters the surveyor
+    recorded from the real reference at -t 1, reproduced by the GPU's K = 1 path (and its streams == serial oracle)."""
+    sa = _sa()
+    n, L = 1_000_000, 150
+    dna = rs.pack_fixed(rs.np_reads(11, 6_000_000, n, L, 0.01))
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_serial(read, ln, L)
+    got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=1, collect_stats=True))
+    _same(got, want, "1M150-k1")
+    st = got["stats"]
+    assert st["unmatched"] == 137_664 and len(got["order_s"]) == 127_731
+    assert st["probes"] == 92_923_476 and st["cands"] == 996_385
+
+
+def _early_stop_set():
+    """40 k reads of a small genome (25x) in the middle of 525 k unrelated random reads.  Chain 0 starts at read 0
+    (unrelated) and new seeds come from the top of the pool, so 520 k unrelated reads -- two failed searches each --
+    are consumed first: at iteration 1 000 000 more than half of the last million were unmatched and the search
+    stops (reorder.h:433-439) before the related reads are reached."""
+    L = 100
+    rng = np.random.default_rng(2024)
+    rel = rs.np_reads(5, 40_000 * L // 25, 40_000, L, 0.01)
+    unrel = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (525_000, L))]
+    a = np.concatenate([unrel[:5000], rel, unrel[5000:]]).astype(np.uint8)
+    return rs.pack_fixed(a), a.shape[0], L, rs.pack_fixed(rel)
+
+
+def test_early_stop_fires_on_both_sides():
+    """STOP_CRITERIA_REORDER (reorder.h:433-439, params.h): K = 1, > 50 % of the first million iterations unmatched
+    -> stop_searching; every read left after that is emitted as a singleton without a search."""
+    sa = _sa()
+    dna, n, L, rel_dna = _early_stop_set()
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_serial(read, ln, L)
+    # the stop fired in the oracle: exactly one million iterations searched (50 shifts x 2 directions each), and the
+    # related reads, which cluster when they are on their own, all came out as singletons
+    assert want["stats"]["search_calls"] == 100_000_000 and len(want["order"]) == 0 and len(want["order_s"]) == n
+    cread, cln = po.load_dna(rel_dna, 40_000, L)
+    assert len(po.reorder_serial(cread, cln, L)["order_s"]) < 8_000
+    for kw in (dict(collect_stats=True), dict()):
+        got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=1, **kw))
+        _same(got, want, "early-stop")
+        assert got["stats"]["unmatched"] == n
+
+
+def test_default_chain_count_on_a_deep_pool_vs_oracle():
+    """num_chains = 0 on a deep-coverage pool: the library picks n / 128 (dictionary >= 1.3 reads per key), says so
+    in its statistics, and the result equals the rounds oracle at that K."""
+    sa = _sa()
+    n, L, T = 300_000, 100, 3
+    dna = sa.synth_dna_host(n, L, n * L // 400, 21, 10000)
+    read, ln = po.load_dna(dna, n, L)
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=0, num_thr=T)) as s:
+        s.load_dna(dna, n, L)
+        s.build_dict()
+        K, deep = s.auto_chains()
+        s.run_chains()
+        s.finalize()
+        got = s.streams()
+    assert deep and K == n >> 7
+    assert got["stats"]["chains"] == K and got["stats"]["deep_pool"] == 1
+    want = po.reorder_rounds(read, ln, L, K, T)
+    _same(got, want, "auto-deep")
+    # a shallow pool takes n / 1024
+    dna2 = sa.synth_dna_host(n, L, n * L // 25, 22, 10000)
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=0, num_thr=T)) as s:
+        s.load_dna(dna2, n, L)
+        s.build_dict()
+        assert s.auto_chains() == (n >> 10, False)
