@@ -51,6 +51,15 @@ typedef struct {
   int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (apply + search) + mark; 2: the fused round
                              always with one chain per wavefront (k_round) instead of four (k_round_mc) where that applies */
   int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
+  /* ---- spring_reorder_run / spring_reorder_encode_run on several GPUs of one node (one read pool):
+   * num_devices >= 2 runs the stage on devices[0 .. num_devices) -- one host thread and one context per entry inside
+   * the library, the reads loaded on every device, the chains sharded, one RCCL all-gather per round -- and writes the
+   * merged per-tid file set.  The output equals the single-device output with the same num_chains (the default chain
+   * count is rounded up to a multiple of num_devices).  0 / 1: `device` alone.  An entry may repeat a device (tests on a
+   * one-GPU box): the exchange then goes through host memory, as it does with mg_host_transport = 1. */
+  int32_t num_devices;
+  int32_t devices[8];
+  int32_t mg_host_transport;
 } spring_reorder_opts;
 
 typedef struct {

@@ -30,7 +30,8 @@ class Opts(C.Structure):
                 ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32),
                 ("first_shifts", C.c_int32), ("seed_wide", C.c_int32), ("tab_scale", C.c_int32),
                 ("search_wpb", C.c_int32), ("dbg_search_lds", C.c_int32), ("dbg_apply_lds", C.c_int32),
-                ("fused", C.c_int32), ("deep_bins", C.c_int32)]
+                ("fused", C.c_int32), ("deep_bins", C.c_int32),
+                ("num_devices", C.c_int32), ("devices", C.c_int32 * 8), ("mg_host_transport", C.c_int32)]
 
 
 class FastqInfo(C.Structure):

@@ -133,7 +133,7 @@ struct DevParams {
 
 // launchers (reorder_kernels.hip)
 void launch_unpack(hipStream_t st, const uint8_t *dna, const uint64_t *off, uint32_t n, int L, int W, int S,
-                   uint32_t rec_fixed, uint64_t *reads, uint16_t *lens);
+                   uint32_t rec_fixed, uint64_t *reads, uint16_t *lens, uint32_t *bad_len = nullptr);
 void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int dend, uint32_t *flag);
 void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, const uint32_t *slot, uint32_t n,
                  int S, int dstart, int dend, uint64_t *keys, uint32_t *vals);

@@ -7,18 +7,28 @@
 // reference's operator interface (call_reorder.h).
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <hip/hip_runtime.h>
+
 #include "call_reorder.h"
+#include "reorder_internal.h"
 #include "spring_encoder.h"
 #include "spring_reorder.h"
 
@@ -45,9 +55,8 @@ void crc_init() {
     for (int t = 1; t < 8; t++) crc_tab[t][i] = (crc_tab[t - 1][i] >> 8) ^ crc_tab[0][crc_tab[t - 1][i] & 0xff];
   crc_ready = true;
 }
-uint32_t crc32_buf(const uint8_t *p, size_t n) {
-  if (!crc_ready) crc_init();
-  uint32_t c = 0xFFFFFFFFu;
+// running CRC-32 (state = the complemented register; start with 0xFFFFFFFF, finish with ^ 0xFFFFFFFF)
+uint32_t crc32_update(uint32_t c, const uint8_t *p, size_t n) {
   while (n >= 8) {
     uint32_t a, b;
     memcpy(&a, p, 4);
@@ -59,7 +68,11 @@ uint32_t crc32_buf(const uint8_t *p, size_t n) {
     n -= 8;
   }
   while (n--) c = crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
-  return c ^ 0xFFFFFFFFu;
+  return c;
+}
+uint32_t crc32_buf(const uint8_t *p, size_t n) {
+  if (!crc_ready) crc_init();
+  return crc32_update(0xFFFFFFFFu, p, n) ^ 0xFFFFFFFFu;
 }
 
 int write_raw(const std::string &path, const void *data, size_t n) {
@@ -101,12 +114,14 @@ int write_gzip_stored(const std::string &path, const void *data, size_t n) {
 int read_file(const std::string &path, std::vector<uint8_t> &buf) {
   FILE *f = fopen(path.c_str(), "rb");
   if (!f) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
-  fseek(f, 0, SEEK_END);
-  long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  size_t old = buf.size();
-  buf.resize(old + (size_t)sz);
-  if (sz && fread(buf.data() + old, 1, (size_t)sz, f) != (size_t)sz) {
+  struct stat sb;
+  if (fstat(fileno(f), &sb) != 0 || sb.st_size < 0) {
+    fclose(f);
+    return fail(SPRING_REORDER_E_IO, "cannot size %s", path.c_str());
+  }
+  const size_t sz = (size_t)sb.st_size, old = buf.size();
+  buf.resize(old + sz);
+  if (sz && fread(buf.data() + old, 1, sz, f) != sz) {
     fclose(f);
     return fail(SPRING_REORDER_E_IO, "short read from %s", path.c_str());
   }
@@ -115,24 +130,233 @@ int read_file(const std::string &path, std::vector<uint8_t> &buf) {
 }
 
 int file_size(const std::string &path, size_t *sz) {
-  FILE *f = fopen(path.c_str(), "rb");
-  if (!f) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
-  fseek(f, 0, SEEK_END);
-  *sz = (size_t)ftell(f);
-  fclose(f);
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
+  if (sb.st_size < 0) return fail(SPRING_REORDER_E_IO, "cannot size %s", path.c_str());
+  *sz = (size_t)sb.st_size;
   return 0;
-}
-int read_into(const std::string &path, uint8_t *dst, size_t sz) {
-  FILE *f = fopen(path.c_str(), "rb");
-  if (!f) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
-  const bool ok = !sz || fread(dst, 1, sz, f) == sz;
-  fclose(f);
-  return ok ? 0 : fail(SPRING_REORDER_E_IO, "short read from %s", path.c_str());
 }
 
 struct CtxGuard {
   spring_reorder_ctx *c = nullptr;
   ~CtxGuard() { spring_reorder_destroy(c); }
+};
+
+// ---- input: input_clean_1.dna (+ input_clean_2.dna) as ONE record stream read piecewise with pread, from as many
+// threads as the uploader runs (sr::load_dna_source): file 2's records follow file 1's (reorder.h:233-242)
+struct FilePair {
+  int fd[2] = {-1, -1};
+  size_t sz[2] = {0, 0};
+  std::string name[2];
+  void close_all() { for (int k = 0; k < 2; k++) if (fd[k] >= 0) { close(fd[k]); fd[k] = -1; } }
+  ~FilePair() { close_all(); }
+  static int fill(void *self, size_t off, void *dst, size_t len) {
+    FilePair *f = (FilePair *)self;
+    uint8_t *d = (uint8_t *)dst;
+    while (len) {
+      const int k = off < f->sz[0] ? 0 : 1;
+      const size_t o = k ? off - f->sz[0] : off, take = std::min(len, f->sz[k] - o);
+      size_t got = 0;
+      while (got < take) {
+        const ssize_t g = pread(f->fd[k], d + got, take - got, (off_t)(o + got));
+        if (g < 0 && errno == EINTR) continue;
+        if (g <= 0) return fail(SPRING_REORDER_E_IO, "short read from %s", f->name[k].c_str());
+        got += (size_t)g;
+      }
+      d += take; off += take; len -= take;
+    }
+    return 0;
+  }
+};
+
+// ---- output: the streams go device -> pinned chunk -> file, one writer thread per tid (at most 16), so that the
+// copies of the next stream run while the previous ones are still being framed, checksummed and written
+struct Slot { void *pin = nullptr; hipEvent_t ev = nullptr; };
+class Ring {  // a bounded set of pinned chunks + their "copy done" events
+ public:
+  explicit Ring(int n) : cap_(n) {}
+  ~Ring() { for (auto &s : all_) { if (s.ev) (void)hipEventDestroy(s.ev); sr::pinned_put(s.pin); } }
+  bool acquire(Slot *out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      if (!free_.empty()) { *out = free_.back(); free_.pop_back(); return true; }
+      if ((int)all_.size() < cap_) {
+        Slot s;
+        s.pin = sr::pinned_get();
+        if (!s.pin || hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { sr::pinned_put(s.pin); return false; }
+        all_.push_back(s);
+        *out = s;
+        return true;
+      }
+      cv_.wait(lk);
+    }
+  }
+  void release(const Slot &s) {
+    { std::lock_guard<std::mutex> lk(mu_); free_.push_back(s); }
+    cv_.notify_one();
+  }
+ private:
+  int cap_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Slot> all_, free_;
+};
+
+struct Msg {
+  enum Kind { OPEN_RAW, OPEN_GZ, DATA, BYTES, CLOSE, STOP } kind = STOP;
+  std::string path;
+  Slot slot;
+  size_t len = 0;
+  std::vector<uint8_t> bytes;  // BYTES: small host data
+};
+class Writer {
+ public:
+  explicit Writer(Ring *ring) : ring_(ring) {}
+  void start() { th_ = std::thread([this] { run(); }); }
+  void push(Msg &&m) {
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(m)); }
+    cv_.notify_one();
+  }
+  void finish() {
+    if (!th_.joinable()) return;
+    Msg m;
+    m.kind = Msg::STOP;
+    push(std::move(m));
+    th_.join();
+  }
+  ~Writer() { finish(); }
+  int rc = 0;
+  std::string err;
+ private:
+  void bad(const char *what, const std::string &path) {
+    if (!rc) { rc = SPRING_REORDER_E_IO; err = std::string(what) + " " + path + ": " + strerror(errno); }
+  }
+  void put(const uint8_t *p, size_t n) {
+    if (!f_ || rc) return;
+    if (!gz_) { if (n && fwrite(p, 1, n, f_) != n) bad("short write to", path_); return; }
+    crc_ = crc32_update(crc_, p, n);
+    isize_ += n;
+    while (n) {  // stored deflate blocks, none of them final: the final (empty) one is written when the stream closes
+      const size_t blk = n > 65535 ? 65535 : n;
+      const uint8_t bh[5] = {0, (uint8_t)(blk & 0xff), (uint8_t)(blk >> 8), (uint8_t)(~blk & 0xff), (uint8_t)((~blk >> 8) & 0xff)};
+      if (fwrite(bh, 1, 5, f_) != 5 || fwrite(p, 1, blk, f_) != blk) { bad("short write to", path_); return; }
+      p += blk; n -= blk;
+    }
+  }
+  void run() {
+    for (;;) {
+      Msg m;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        m = std::move(q_.front());
+        q_.pop_front();
+      }
+      switch (m.kind) {
+        case Msg::STOP: if (f_) fclose(f_); return;
+        case Msg::OPEN_RAW: case Msg::OPEN_GZ: {
+          path_ = m.path; gz_ = m.kind == Msg::OPEN_GZ; crc_ = 0xFFFFFFFFu; isize_ = 0;
+          f_ = rc ? nullptr : fopen(path_.c_str(), "wb");
+          if (!f_ && !rc) bad("cannot open for writing", path_);
+          if (f_) setvbuf(f_, nullptr, _IOFBF, 1 << 20);
+          if (f_ && gz_) {
+            const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255};
+            if (fwrite(hdr, 1, 10, f_) != 10) bad("short write to", path_);
+          }
+          break;
+        }
+        case Msg::DATA:
+          if (hipEventSynchronize(m.slot.ev) != hipSuccess && !rc) { rc = SPRING_REORDER_E_HIP; err = "device to host copy failed"; }
+          put((const uint8_t *)m.slot.pin, m.len);
+          ring_->release(m.slot);
+          break;
+        case Msg::BYTES: put(m.bytes.data(), m.bytes.size()); break;
+        case Msg::CLOSE:
+          if (f_ && gz_ && !rc) {
+            const uint8_t fin[5] = {1, 0, 0, 0xff, 0xff};  // final stored block, empty
+            const uint32_t crc = crc_ ^ 0xFFFFFFFFu, isz = (uint32_t)isize_;
+            uint8_t tr[8];
+            memcpy(tr, &crc, 4); memcpy(tr + 4, &isz, 4);
+            if (fwrite(fin, 1, 5, f_) != 5 || fwrite(tr, 1, 8, f_) != 8) bad("short write to", path_);
+          }
+          if (f_ && fclose(f_) != 0) bad("close failed for", path_);
+          f_ = nullptr;
+          break;
+      }
+    }
+  }
+  Ring *ring_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Msg> q_;
+  FILE *f_ = nullptr;
+  bool gz_ = false;
+  uint32_t crc_ = 0;
+  uint64_t isize_ = 0;
+  std::string path_;
+};
+
+void w_open(Writer &w, const std::string &path, bool gz) {
+  Msg m;
+  m.kind = gz ? Msg::OPEN_GZ : Msg::OPEN_RAW;
+  m.path = path;
+  w.push(std::move(m));
+}
+void w_close(Writer &w) {
+  Msg m;
+  m.kind = Msg::CLOSE;
+  w.push(std::move(m));
+}
+// bytes [d, d + n) of device `dev` (ordered on stream st) -> the writer's open file
+int w_device(Writer &w, Ring &ring, int dev, hipStream_t st, const void *d, size_t n) {
+  if (!n) return 0;
+  if (hipSetDevice(dev) != hipSuccess) return fail(SPRING_REORDER_E_HIP, "hipSetDevice(%d) failed", dev);
+  for (size_t off = 0; off < n; off += sr::PIN_CHUNK) {
+    const size_t len = std::min(sr::PIN_CHUNK, n - off);
+    Msg m;
+    m.kind = Msg::DATA;
+    m.len = len;
+    if (!ring.acquire(&m.slot)) return fail(SPRING_REORDER_E_HIP, "cannot pin a staging chunk for the output streams");
+    if (hipMemcpyAsync(m.slot.pin, (const uint8_t *)d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipEventRecord(m.slot.ev, st) != hipSuccess) {
+      ring.release(m.slot);
+      return fail(SPRING_REORDER_E_HIP, "device to host copy of an output stream failed");
+    }
+    w.push(std::move(m));
+  }
+  return 0;
+}
+
+// in-process all-gather between the rank threads of one pool (host transport: repeated devices, or asked for)
+struct HostGather {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint8_t> buf;
+  uint32_t world = 1, arrived = 0, gen = 0;
+  bool failed = false;
+  void barrier(std::unique_lock<std::mutex> &lk) {
+    const uint32_t g = gen;
+    if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g || failed; });
+  }
+  static int fn(void *host_buf, size_t off, size_t bytes, size_t total, void *user) {
+    HostGather *h = (HostGather *)user;
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->failed) return 1;
+    if (h->buf.size() < total) h->buf.resize(total);
+    memcpy(h->buf.data() + off, (const uint8_t *)host_buf + off, bytes);
+    h->barrier(lk);  // every slice is in
+    if (h->failed) return 1;
+    memcpy(host_buf, h->buf.data(), total);
+    h->barrier(lk);  // everybody has read: the buffer may be overwritten by the next round
+    return h->failed ? 1 : 0;
+  }
+  void abort_all() {
+    std::lock_guard<std::mutex> lk(mu);
+    failed = true;
+    cv.notify_all();
+  }
 };
 
 }  // namespace
@@ -152,92 +376,187 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
   spring_reorder_opts o;
   if (opts) o = *opts; else spring_reorder_default_opts(&o);
   o.num_thr = num_thr;
+  if (o.num_devices < 0 || o.num_devices > 8) return fail(SPRING_REORDER_E_ARG, "num_devices must be 0..8");
+  const int world = o.num_devices >= 2 ? o.num_devices : 1;
   const std::string base(temp_dir);
-  const std::string in1 = base + "/input_clean_1.dna", in2 = base + "/input_clean_2.dna";  // reorder.h:738-739
   const uint64_t ntot = (uint64_t)n0 + (paired_end ? n1 : 0);                              // reorder.h:761
   if (ntot > 4294967290ull) return fail(SPRING_REORDER_E_ARG, "too many reads");           // params.h:24
   const uint32_t n = (uint32_t)ntot;
-
-  // both input files into one buffer that is not zero-filled first (4 GB at 100 M reads)
-  size_t sz1 = 0, sz2 = 0;
-  int r = file_size(in1, &sz1);
-  if (r) return r;
-  if (paired_end && (r = file_size(in2, &sz2))) return r;
-  std::unique_ptr<uint8_t[]> dna(new uint8_t[sz1 + sz2 + 1]);
-  if ((r = read_into(in1, dna.get(), sz1))) return r;
-  if (paired_end && (r = read_into(in2, dna.get() + sz1, sz2))) return r;  // file-2 reads follow in the same pool (reorder.h:233-242)
-  lap("read input files");
-  CtxGuard g;
-  r = spring_reorder_create(&g.c, &o);
-  if (r) return r;
-  r = spring_reorder_load_dna(g.c, dna.get(), sz1 + sz2, n, max_readlen);
-  if (r) return r;
-  dna.reset();
-  lap("create + load (H2D)");
-  remove(in1.c_str());  // the stage consumes its inputs (reorder.h:232,241)
-  if (paired_end) remove(in2.c_str());
-  if ((r = spring_reorder_build_dict(g.c))) return r;
-  if ((r = spring_reorder_run_chains(g.c))) return r;
-  if ((r = spring_reorder_finalize(g.c))) return r;
-  spring_reorder_stats st;
-  if ((r = spring_reorder_get_stats(g.c, &st))) return r;
-  lap("dict + chains + final");
-
-  const size_t nm = st.n_matched, ns = st.n_single;
-  // not zero-filled: the download overwrites every byte (1.6 GB at 100 M reads)
-  std::unique_ptr<uint32_t[]> order(new uint32_t[nm + 1]), order_s(new uint32_t[ns + 1]);
-  std::unique_ptr<char[]> rc(new char[nm + 1]), flag(new char[nm + 1]);
-  std::unique_ptr<int64_t[]> pos(new int64_t[nm + 1]);
-  std::unique_ptr<uint16_t[]> rlen(new uint16_t[nm + 1]);
-  std::vector<uint64_t> toff(num_thr + 1), toff_s(num_thr + 1);
-  r = spring_reorder_download(g.c, order.get(), rc.get(), flag.get(), pos.get(), rlen.get(), order_s.get(),
-                              toff.data(), toff_s.data());
-  if (r) return r;
-  lap("download streams");
-  // temp.dna.<tid> / temp.dna.singleton are built on the device (reverse complement + repack), one stream after the
-  // other; the file sets are then written by one host thread per tid (CRC-32 + file system, the slow half)
-  std::vector<std::vector<uint8_t>> dna_t(num_thr + 1);
-  for (int t = 0; t <= num_thr; t++) {
-    const int32_t which = t < num_thr ? t : -1;
-    size_t nb = 0;
-    if ((r = spring_reorder_emit_dna(g.c, which, nullptr, 0, &nb))) return r;
-    dna_t[t].resize(nb ? nb : 1);
-    if ((r = spring_reorder_emit_dna(g.c, which, dna_t[t].data(), nb, &nb))) return r;
-    dna_t[t].resize(nb);
-  }
-  lap("emit temp.dna (D2H)");
-  if (!crc_ready) crc_init();
-  std::vector<int> trc(num_thr, 0);
-  std::vector<std::string> terr(num_thr);
-  auto write_tid = [&](int t) {  // all six files must exist for every tid (encoder.h:147-175)
-    const std::string ts = "." + std::to_string(t);
-    const size_t a = toff[t], c = toff[t + 1] - toff[t];
-    int e;
-    if ((e = write_raw(base + "/read_order.bin" + ts, order.get() + a, c * 4)) ||
-        (e = write_gzip_stored(base + "/read_rev.txt" + ts, rc.get() + a, c)) ||
-        (e = write_gzip_stored(base + "/tempflag.txt" + ts, flag.get() + a, c)) ||
-        (e = write_gzip_stored(base + "/temppos.txt" + ts, pos.get() + a, c * 8)) ||
-        (e = write_gzip_stored(base + "/read_lengths.bin" + ts, rlen.get() + a, c * 2)) ||
-        (e = write_raw(base + "/temp.dna" + ts, dna_t[t].data(), dna_t[t].size()))) {
-      trc[t] = e;
-      terr[t] = spring_reorder_last_error();  // the message is thread-local
+  try {
+    // ---- input (reorder.h:738-739)
+    FilePair in;
+    in.name[0] = base + "/input_clean_1.dna";
+    in.name[1] = base + "/input_clean_2.dna";
+    int r;
+    for (int k = 0; k < (paired_end ? 2 : 1); k++) {
+      if ((r = file_size(in.name[k], &in.sz[k]))) return r;
+      in.fd[k] = open(in.name[k].c_str(), O_RDONLY);
+      if (in.fd[k] < 0) return fail(SPRING_REORDER_E_IO, "cannot open %s: %s", in.name[k].c_str(), strerror(errno));
     }
-  };
-  {
-    std::vector<std::thread> th;
-    for (int t = 1; t < num_thr; t++) th.emplace_back(write_tid, t);
-    write_tid(0);
-    for (auto &x : th) x.join();
+    sr::DnaSource src;
+    src.nbytes = in.sz[0] + in.sz[1];
+    src.fill = &FilePair::fill;
+    src.self = &in;
+
+    // ---- the stage: one context per device; with several, one pool (reads on every device, chains sharded)
+    std::vector<CtxGuard> g((size_t)world);
+    std::vector<int> devs((size_t)world, o.device);
+    bool repeated = false;
+    for (int k = 0; k < world && world > 1; k++) {
+      devs[(size_t)k] = o.devices[k];
+      for (int j = 0; j < k; j++) repeated = repeated || o.devices[j] == o.devices[k];
+    }
+    for (int k = 0; k < world; k++) {
+      spring_reorder_opts ok = o;
+      ok.device = devs[(size_t)k];
+      if ((r = spring_reorder_create(&g[(size_t)k].c, &ok))) return r;
+    }
+    if (world == 1) {
+      if ((r = sr::load_dna_source(g[0].c, src, n, max_readlen))) return r;
+      lap("read + H2D + unpack");
+      if ((r = spring_reorder_build_dict(g[0].c))) return r;
+      if ((r = spring_reorder_run_chains(g[0].c))) return r;
+      if ((r = spring_reorder_finalize(g[0].c))) return r;
+    } else {
+      const bool host_transport = repeated || o.mg_host_transport != 0;
+      HostGather hg;
+      hg.world = (uint32_t)world;
+      uint8_t id[SPRING_RCCL_ID_BYTES];
+      if (!host_transport && (r = spring_mg_rccl_unique_id(id))) return r;
+      std::vector<int> rcs((size_t)world, 0);
+      std::vector<std::string> errs((size_t)world);
+      // phase 1: load + dictionaries on every device; phase 2 (needs the default chain count of rank 0): the pool
+      std::vector<uint32_t> autok((size_t)world, 0);
+      auto phase1 = [&](int k) {
+        int e = sr::load_dna_source(g[(size_t)k].c, src, n, max_readlen);
+        if (!e) e = spring_reorder_build_dict(g[(size_t)k].c);
+        if (!e) e = spring_reorder_auto_chains(g[(size_t)k].c, &autok[(size_t)k], nullptr);
+        if (e) { rcs[(size_t)k] = e; errs[(size_t)k] = spring_reorder_last_error(); }
+      };
+      {
+        std::vector<std::thread> th;
+        for (int k = 1; k < world; k++) th.emplace_back(phase1, k);
+        phase1(0);
+        for (auto &x : th) x.join();
+      }
+      for (int k = 0; k < world; k++) if (rcs[(size_t)k]) return fail(rcs[(size_t)k], "%s", errs[(size_t)k].c_str());
+      lap("read + H2D + dictionaries");
+      uint32_t Ktot = o.num_chains ? o.num_chains : autok[0];
+      Ktot = (Ktot + (uint32_t)world - 1) / (uint32_t)world * (uint32_t)world;
+      auto phase2 = [&](int k) {
+        spring_mg_comm *comm = nullptr;
+        int e = host_transport ? spring_mg_comm_create_host(&comm, &HostGather::fn, &hg, (uint32_t)k, (uint32_t)world)
+                               : spring_mg_comm_create_rccl(&comm, devs[(size_t)k], id, (uint32_t)k, (uint32_t)world);
+        if (!e) e = spring_reorder_mg_run(g[(size_t)k].c, comm, Ktot);
+        if (!e) e = spring_reorder_finalize(g[(size_t)k].c);
+        if (e) { rcs[(size_t)k] = e; errs[(size_t)k] = spring_reorder_last_error(); hg.abort_all(); }
+        spring_mg_comm_destroy(comm);
+      };
+      {
+        std::vector<std::thread> th;
+        for (int k = 1; k < world; k++) th.emplace_back(phase2, k);
+        phase2(0);
+        for (auto &x : th) x.join();
+      }
+      for (int k = 0; k < world; k++) if (rcs[(size_t)k]) return fail(rcs[(size_t)k], "%s", errs[(size_t)k].c_str());
+    }
+    lap("dict + chains + final");
+    in.close_all();
+    remove((base + "/input_clean_1.dna").c_str());  // the stage consumes its inputs (reorder.h:232,241)
+    if (paired_end) remove((base + "/input_clean_2.dna").c_str());
+
+    // ---- output: tid t of the job = every rank's tid-t segment, ranks ascending (chain c -> tid c % num_thr)
+    std::vector<sr::ReorderView> v((size_t)world);
+    uint64_t unmatched = 0, nsing_total = 0;
+    for (int k = 0; k < world; k++) {
+      if ((r = sr::reorder_view_any(g[(size_t)k].c, &v[(size_t)k]))) return r;
+      spring_reorder_stats st;
+      if ((r = spring_reorder_get_stats(g[(size_t)k].c, &st))) return r;
+      unmatched += st.unmatched;
+      nsing_total += v[(size_t)k].nsing;
+    }
+    if (!crc_ready) crc_init();
+    const int nw = std::min(num_thr, 16);
+    Ring ring(24);  // 24 x 32 MiB in flight at most
+    std::vector<std::unique_ptr<Writer>> W;
+    for (int i = 0; i < nw; i++) W.emplace_back(new Writer(&ring));
+    try {
+      for (auto &w : W) w->start();
+    } catch (const std::system_error &) {
+      return fail(SPRING_REORDER_E_IO, "cannot start the writer threads");
+    }
+    int ret = 0;
+    auto stream_of = [&](int t, const char *name, bool gz, size_t elem, auto ptr_of) {
+      Writer &w = *W[(size_t)(t % nw)];
+      w_open(w, base + "/" + name + "." + std::to_string(t), gz);
+      for (int k = 0; k < world && !ret; k++) {
+        const sr::ReorderView &vk = v[(size_t)k];
+        const uint64_t a = vk.tid_off[t], c = vk.tid_off[t + 1] - a;
+        ret = w_device(w, ring, vk.dev, vk.st, (const uint8_t *)ptr_of(vk) + a * elem, c * elem);
+      }
+      w_close(w);
+    };
+    for (int t = 0; t < num_thr && !ret; t++) {  // all six files must exist for every tid (encoder.h:147-175)
+      stream_of(t, "read_order.bin", false, 4, [](const sr::ReorderView &x) { return (const void *)x.f_order; });
+      stream_of(t, "read_rev.txt", true, 1, [](const sr::ReorderView &x) { return (const void *)x.f_rc; });
+      stream_of(t, "tempflag.txt", true, 1, [](const sr::ReorderView &x) { return (const void *)x.f_flag; });
+      stream_of(t, "temppos.txt", true, 8, [](const sr::ReorderView &x) { return (const void *)x.f_pos; });
+      stream_of(t, "read_lengths.bin", true, 2, [](const sr::ReorderView &x) { return (const void *)x.f_len; });
+      // temp.dna.<tid>: built on the device (reverse complement + repack), rank by rank
+      Writer &w = *W[(size_t)(t % nw)];
+      w_open(w, base + "/temp.dna." + std::to_string(t), false);
+      for (int k = 0; k < world && !ret; k++) {
+        uint8_t *d = nullptr;
+        size_t nb = 0;
+        if ((ret = sr::emit_dna_device(g[(size_t)k].c, t, &d, &nb))) break;
+        ret = w_device(w, ring, v[(size_t)k].dev, v[(size_t)k].st, d, nb);
+        sr::emit_dna_free(g[(size_t)k].c, d);  // (waits for the stream: the copies above have left the buffer)
+      }
+      w_close(w);
+    }
+    if (!ret) {  // reorder.h:699-728; the singleton streams are in tid order too (rank by rank inside a tid)
+      Writer &w = *W[0];
+      w_open(w, base + "/temp.dna.singleton", false);
+      for (int t = 0; t < num_thr && !ret; t++)
+        for (int k = 0; k < world && !ret; k++) {
+          const sr::ReorderView &vk = v[(size_t)k];
+          const uint64_t a = vk.tid_off_s[t], c = vk.tid_off_s[t + 1] - a;
+          if (!c) continue;
+          uint8_t *d = nullptr;
+          size_t nb = 0;
+          if ((ret = sr::emit_dna_device(g[(size_t)k].c, -1, &d, &nb, a, c))) break;
+          ret = w_device(w, ring, vk.dev, vk.st, d, nb);
+          sr::emit_dna_free(g[(size_t)k].c, d);
+        }
+      w_close(w);
+      Writer &w1 = *W[(size_t)(1 % nw)];
+      w_open(w1, base + "/read_order.bin.singleton", false);
+      for (int t = 0; t < num_thr && !ret; t++)
+        for (int k = 0; k < world && !ret; k++) {
+          const sr::ReorderView &vk = v[(size_t)k];
+          const uint64_t a = vk.tid_off_s[t], c = vk.tid_off_s[t + 1] - a;
+          ret = w_device(w1, ring, vk.dev, vk.st, vk.f_order_s + a, (size_t)c * 4);
+        }
+      w_close(w1);
+      w_open(w1, base + "/temp.dna.singleton.count", false);
+      Msg m;
+      m.kind = Msg::BYTES;
+      const uint32_t numreads_s = (uint32_t)nsing_total;
+      m.bytes.assign((const uint8_t *)&numreads_s, (const uint8_t *)&numreads_s + 4);
+      w1.push(std::move(m));
+      w_close(w1);
+    }
+    for (auto &w : W) w->finish();
+    if (ret) return ret;
+    for (auto &w : W) if (w->rc) return fail(w->rc, "%s", w->err.c_str());
+    lap("D2H + write files");
+    printf("Reordering done, %llu were unmatched\n", (unsigned long long)unmatched);  // reorder.h:633-635
+    return 0;
+  } catch (const std::bad_alloc &) {
+    return fail(SPRING_REORDER_E_IO, "out of host memory in the reorder stage");
+  } catch (const std::system_error &e) {
+    return fail(SPRING_REORDER_E_IO, "reorder stage: %s", e.what());
   }
-  for (int t = 0; t < num_thr; t++)
-    if (trc[t]) return fail(trc[t], "%s", terr[t].c_str());
-  if ((r = write_raw(base + "/temp.dna.singleton", dna_t[num_thr].data(), dna_t[num_thr].size()))) return r;  // reorder.h:704-728
-  if ((r = write_raw(base + "/read_order.bin.singleton", order_s.get(), ns * 4))) return r;
-  const uint32_t numreads_s = (uint32_t)ns;
-  if ((r = write_raw(base + "/temp.dna.singleton.count", &numreads_s, 4))) return r;  // reorder.h:699-701
-  lap("write files");
-  printf("Reordering done, %llu were unmatched\n", (unsigned long long)st.unmatched);  // reorder.h:633-635
-  return 0;
 }
 
 namespace {

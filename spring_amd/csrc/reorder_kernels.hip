@@ -184,15 +184,21 @@ __shared__ uint32_t g_pt_lds[66];  // k_round: one wavefront per block.  [k] clo
 
 // ------------------------------------------------------- K1 unpack (readDnaFile)
 // reorder.h:222-244: u16 len + ceil(len/4) raw bytes -> zero padded limbs.
+// bad_len (may be null; fixed-record streams): set when a record's length field is not L -- the stream is then
+// not the fixed-length stream its size suggested and the host falls back to walking the records.
 __global__ void k_unpack(const uint8_t *__restrict__ dna, const uint64_t *__restrict__ off, uint32_t n,
                          int L, int W, int S, uint32_t rec_fixed, uint64_t *__restrict__ reads,
-                         uint16_t *__restrict__ lens) {
+                         uint16_t *__restrict__ lens, uint32_t *__restrict__ bad_len) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t i = t / (uint32_t)S;
   int j = (int)(t % (uint32_t)S);
   if (i >= n) return;
   uint64_t o = off ? off[i] : i * (uint64_t)rec_fixed;
   uint32_t len = (uint32_t)dna[o] | ((uint32_t)dna[o + 1] << 8);
+  if (bad_len && !off && len != (uint32_t)L) {
+    if (j == 0) *bad_len = 1u;
+    len = (uint32_t)L;  // (stay inside the record; the result is discarded)
+  }
   if (j == 0) lens[i] = (uint16_t)len;
   uint32_t nb = (len + 3) / 4;
   uint64_t v = 0;
@@ -1792,10 +1798,10 @@ __global__ void k_synth(uint8_t *__restrict__ dst, uint32_t n, uint32_t L, uint6
 #define GRID1(n, bs) dim3((unsigned)(((uint64_t)(n) + (bs) - 1) / (bs)))
 
 void launch_unpack(hipStream_t st, const uint8_t *dna, const uint64_t *off, uint32_t n, int L, int W, int S,
-                   uint32_t rec_fixed, uint64_t *reads, uint16_t *lens) {
+                   uint32_t rec_fixed, uint64_t *reads, uint16_t *lens, uint32_t *bad_len) {
   if (!n) return;
   uint64_t tot = (uint64_t)n * S;
-  hipLaunchKernelGGL(k_unpack, GRID1(tot, 256), dim3(256), 0, st, dna, off, n, L, W, S, rec_fixed, reads, lens);
+  hipLaunchKernelGGL(k_unpack, GRID1(tot, 256), dim3(256), 0, st, dna, off, n, L, W, S, rec_fixed, reads, lens, bad_len);
 }
 void launch_flag_in_dict(hipStream_t st, const uint16_t *lens, uint32_t n, int dend, uint32_t *flag) {
   hipLaunchKernelGGL(k_flag_in_dict, GRID1(n, 256), dim3(256), 0, st, lens, n, dend, flag);

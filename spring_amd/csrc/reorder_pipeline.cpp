@@ -10,6 +10,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <system_error>
+#include <thread>
+#include <memory>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +21,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -139,6 +145,7 @@ struct spring_reorder_ctx {
   bool mg = false;
   uint32_t *cnt_buf[2] = {nullptr, nullptr};  // needy_cnt double buffer (reorder_device.h)
   uint64_t round_no = 0;
+  bool in_source_fallback = false;  // load_dna <-> load_dna_source recursion guard
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
   uint32_t *d_orderN[2] = {nullptr, nullptr};
@@ -177,13 +184,17 @@ struct spring_reorder_ctx {
 
 namespace sr {
 int reorder_view(spring_reorder_ctx *ctx, ReorderView *v) {
+  if (ctx && ctx->mg) return fail(SPRING_REORDER_E_STATE, "single-pool multi-GPU contexts hold partial streams");
+  return reorder_view_any(ctx, v);
+}
+int reorder_view_any(spring_reorder_ctx *ctx, ReorderView *v) {
   if (!ctx || !v) return fail(SPRING_REORDER_E_ARG, "NULL argument");
   if (ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "reorder context is not finalized");
-  if (ctx->mg) return fail(SPRING_REORDER_E_STATE, "single-pool multi-GPU contexts hold partial streams");
   v->dev = ctx->dev; v->st = ctx->st; v->n = ctx->n; v->L = ctx->L; v->W = ctx->W; v->S = ctx->S;
   v->reads = ctx->d_reads; v->lens = ctx->d_lens; v->nrec = ctx->nrec; v->nsing = ctx->nsing;
   v->f_order = ctx->P.f_order; v->f_order_s = ctx->P.f_order_s; v->f_rc = ctx->P.f_rc; v->f_flag = ctx->P.f_flag;
   v->f_pos = ctx->P.f_pos; v->f_len = ctx->P.f_len; v->tid_off = ctx->tid_off.data(); v->num_thr = ctx->o.num_thr;
+  v->tid_off_s = ctx->tid_off_s.data();
   for (int j = 0; j < 2; j++) {  // reads with N kept by the FASTQ front end (none when the reads came as .dna records)
     v->N_dna[j] = ctx->d_N[j]; v->N_off[j] = ctx->d_offN[j]; v->N_order[j] = ctx->d_orderN[j];
     v->N_count[j] = ctx->fq.num_reads_N[j]; v->N_bytes[j] = ctx->N_bytes[j];
@@ -259,7 +270,42 @@ void spring_reorder_default_opts(spring_reorder_opts *o) {
 
 const char *spring_reorder_last_error(void) { return g_err.c_str(); }
 
+extern "C++" {
+namespace {
+struct PinCache {
+  std::mutex mu;
+  std::vector<void *> free_chunks;
+};
+PinCache g_pin;
+}  // namespace
+namespace sr {
+void *pinned_get() {
+  {
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    if (!g_pin.free_chunks.empty()) {
+      void *p = g_pin.free_chunks.back();
+      g_pin.free_chunks.pop_back();
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, PIN_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void pinned_put(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pin.mu);
+  g_pin.free_chunks.push_back(p);
+}
+}  // namespace sr
+}  // extern "C++"
+
 void spring_reorder_trim_pool(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    for (void *p : g_pin.free_chunks) (void)hipHostFree(p);
+    g_pin.free_chunks.clear();
+  }
   for (int d = 0; d < 16; d++) {
     DevPool &p = g_pool[d];
     std::lock_guard<std::mutex> lk(p.mu);
@@ -324,22 +370,138 @@ static int setup_geometry(spring_reorder_ctx *ctx, uint32_t n, uint32_t max_read
   return 0;
 }
 
-static int unpack_on_device(spring_reorder_ctx *ctx) {
-  DMALLOC(ctx->d_reads, (size_t)std::max<uint32_t>(ctx->n, 1) * ctx->S * sizeof(uint64_t));
-  DMALLOC(ctx->d_lens, (size_t)std::max<uint32_t>(ctx->n, 1) * sizeof(uint16_t));
+static int unpack_on_device(spring_reorder_ctx *ctx, uint32_t *d_bad_len = nullptr) {
+  if (!ctx->d_reads) DMALLOC(ctx->d_reads, (size_t)std::max<uint32_t>(ctx->n, 1) * ctx->S * sizeof(uint64_t));
+  if (!ctx->d_lens) DMALLOC(ctx->d_lens, (size_t)std::max<uint32_t>(ctx->n, 1) * sizeof(uint16_t));
   HIPCHK(hipEventRecord(ctx->ev[0], ctx->st));
   const uint32_t rec = 2u + ((uint32_t)ctx->L + 3u) / 4u;
-  launch_unpack(ctx->st, ctx->d_dna, ctx->d_off, ctx->n, ctx->L, ctx->W, ctx->S, rec, ctx->d_reads, ctx->d_lens);
+  launch_unpack(ctx->st, ctx->d_dna, ctx->d_off, ctx->n, ctx->L, ctx->W, ctx->S, rec, ctx->d_reads, ctx->d_lens, d_bad_len);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[1], ctx->st));
   ctx->stage = ST_LOADED;
   return 0;
 }
 
+// Host -> device copy of `nbytes` produced piecewise by `fill` (thread-safe): up to 8 host threads, each with its
+// own stream and two pinned chunks, fill one chunk while the other is on its way (pageable memory or a file never
+// goes through the runtime's own staging: that path runs at ~8 GB/s on a link that does ~50).
+static int upload_chunked(spring_reorder_ctx *ctx, uint8_t *d_dst, size_t nbytes,
+                          int (*fill)(void *, size_t, void *, size_t), void *self) {
+  if (!nbytes) return 0;
+  const size_t nchunks = (nbytes + PIN_CHUNK - 1) / PIN_CHUNK;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nthr = (int)std::min<size_t>(std::min<size_t>(8, hw), nchunks);
+  std::atomic<size_t> next{0};
+  std::atomic<int> rc{0};
+  std::vector<std::string> errs((size_t)nthr);
+  auto worker = [&](int ti) {
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    bool used[2] = {false, false};
+    auto bail = [&](int code, const char *what) {
+      int zero = 0;
+      if (rc.compare_exchange_strong(zero, code)) errs[(size_t)ti] = what;
+    };
+    if (hipSetDevice(ctx->dev) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      bail(SPRING_REORDER_E_HIP, "upload: cannot create a copy stream");
+    } else {
+      for (int k = 0; k < 2 && !rc.load(); k++) {
+        pin[k] = pinned_get();
+        if (!pin[k] || hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) bail(SPRING_REORDER_E_HIP, "upload: cannot pin a staging chunk");
+      }
+      for (int k = 0; !rc.load(); k ^= 1) {
+        const size_t i = next.fetch_add(1);
+        if (i >= nchunks) break;
+        const size_t off = i * PIN_CHUNK, len = std::min(PIN_CHUNK, nbytes - off);
+        if (used[k] && hipEventSynchronize(ev[k]) != hipSuccess) { bail(SPRING_REORDER_E_HIP, "upload: event wait failed"); break; }
+        if (fill(self, off, pin[k], len)) { bail(SPRING_REORDER_E_IO, g_err.c_str()); break; }
+        if (hipMemcpyAsync(d_dst + off, pin[k], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipEventRecord(ev[k], st) != hipSuccess) { bail(SPRING_REORDER_E_HIP, "upload: hipMemcpyAsync failed"); break; }
+        used[k] = true;
+      }
+      (void)hipStreamSynchronize(st);
+    }
+    for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); pinned_put(pin[k]); }
+    if (st) (void)hipStreamDestroy(st);
+  };
+  std::vector<std::thread> th;
+  try {
+    for (int t = 1; t < nthr; t++) th.emplace_back(worker, t);
+  } catch (const std::system_error &) {  // fewer helpers than hoped for: the calling thread does the rest
+  }
+  worker(0);
+  for (auto &x : th) x.join();
+  (void)hipGetLastError();
+  if (rc.load()) {
+    for (auto &e : errs) if (!e.empty()) return fail(rc.load(), "%s", e.c_str());
+    return fail(rc.load(), "upload failed");
+  }
+  return 0;
+}
+
+static int scan_records(const uint8_t *dna, size_t nbytes, uint32_t n, int L, bool &uniform, std::vector<uint64_t> &off);
+
+extern "C++" {
+namespace sr {
+int load_dna_source(spring_reorder_ctx *ctx, const DnaSource &src, uint32_t n, uint32_t max_readlen) {
+  if (!ctx || !src.fill) return fail(SPRING_REORDER_E_ARG, "NULL argument");
+  if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_dna: context already loaded");
+  HIPCHK(hipSetDevice(ctx->dev));
+  int r = setup_geometry(ctx, n, max_readlen);
+  if (r) return r;
+  const size_t rec = 2u + (max_readlen + 3u) / 4u, nbytes = src.nbytes;
+  if (n && nbytes == (size_t)n * rec) {  // the size of a fixed-length stream: upload, unpack, verify on the device
+    ctx->uniform = true;
+    ctx->dna_bytes = nbytes;
+    DMALLOC(ctx->d_dna, nbytes + 16);
+    if ((r = upload_chunked(ctx, ctx->d_dna, nbytes, src.fill, src.self))) return r;
+    uint32_t *d_bad = nullptr, bad = 0;
+    DMALLOC(d_bad, 16);
+    HIPCHK(hipMemsetAsync(d_bad, 0, 4, ctx->st));
+    if ((r = unpack_on_device(ctx, d_bad))) return r;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    ctx->dfree(d_bad);
+    if (!bad) return 0;
+    ctx->stage = ST_CREATED;  // same size, other lengths: walk the records after all
+    ctx->dfree(ctx->d_dna); ctx->d_dna = nullptr;
+  }
+  // variable-length (or malformed) stream: the record starts are sequentially dependent -> a host image is walked
+  std::unique_ptr<uint8_t[]> img;
+  try { img.reset(new uint8_t[nbytes + 1]); } catch (const std::bad_alloc &) { return fail(SPRING_REORDER_E_IO, "out of host memory for a %zu-byte record stream", nbytes); }
+  {
+    const size_t CH = (size_t)64 << 20, nch = (nbytes + CH - 1) / CH;
+    const int nthr = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(nch, 1));
+    std::atomic<size_t> next{0};
+    std::atomic<int> rc{0};
+    std::string err;
+    std::mutex emu;
+    auto worker = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= nch || rc.load()) break;
+        const size_t off = i * CH, len = std::min(CH, nbytes - off);
+        if (src.fill(src.self, off, img.get() + off, len)) { std::lock_guard<std::mutex> lk(emu); rc = SPRING_REORDER_E_IO; err = g_err; }
+      }
+    };
+    std::vector<std::thread> th;
+    try { for (int t = 1; t < nthr; t++) th.emplace_back(worker); } catch (const std::system_error &) {}
+    worker();
+    for (auto &x : th) x.join();
+    if (rc.load()) return fail(rc.load(), "%s", err.c_str());
+  }
+  ctx->in_source_fallback = true;
+  r = spring_reorder_load_dna(ctx, img.get(), nbytes, n, max_readlen);
+  ctx->in_source_fallback = false;
+  return r;
+}
+}  // namespace sr
+}  // extern "C++"
+
 // walks the record stream once on the host: validates it and decides whether
 // every read has len == max_readlen (then no offset array is needed).
-static int scan_records(const uint8_t *dna, size_t nbytes, uint32_t n, int L, bool &uniform,
-                        std::vector<uint64_t> &off) {
+static int scan_records(const uint8_t *dna, size_t nbytes, uint32_t n, int L, bool &uniform, std::vector<uint64_t> &off) {
   uniform = true;
   off.resize(n);
   size_t p = 0;
@@ -361,6 +523,18 @@ int spring_reorder_load_dna(spring_reorder_ctx *ctx, const uint8_t *dna, size_t 
   if (ctx->stage != ST_CREATED) return fail(SPRING_REORDER_E_STATE, "load_dna: context already loaded");
   if (n && !dna) return fail(SPRING_REORDER_E_ARG, "dna is NULL");
   HIPCHK(hipSetDevice(ctx->dev));
+  if (max_readlen && max_readlen <= (uint32_t)MAX_READ_LEN && n && nbytes == (size_t)n * (2u + (max_readlen + 3u) / 4u) &&
+      !ctx->in_source_fallback) {
+    // the size of a fixed-length stream: no serial walk over the records on the host, the device verifies the lengths
+    DnaSource src;
+    src.nbytes = nbytes;
+    src.self = const_cast<uint8_t *>(dna);
+    src.fill = [](void *self, size_t o, void *dst, size_t len) -> int { memcpy(dst, (const uint8_t *)self + o, len); return 0; };
+    ctx->in_source_fallback = true;  // (load_dna_source comes back here when the lengths turn out to vary)
+    const int rs = load_dna_source(ctx, src, n, max_readlen);
+    ctx->in_source_fallback = false;
+    return rs;
+  }
   int r = setup_geometry(ctx, n, max_readlen);
   if (r) return r;
   std::vector<uint64_t> off;
@@ -368,15 +542,13 @@ int spring_reorder_load_dna(spring_reorder_ctx *ctx, const uint8_t *dna, size_t 
   if (r) return r;
   ctx->dna_bytes = nbytes;
   DMALLOC(ctx->d_dna, nbytes + 16);
-  if (nbytes) HIPCHK(hipMemcpyAsync(ctx->d_dna, dna, nbytes, hipMemcpyHostToDevice, ctx->st));
+  auto mem_fill = [](void *self, size_t o, void *dst, size_t len) -> int { memcpy(dst, (const uint8_t *)self + o, len); return 0; };
+  if ((r = upload_chunked(ctx, ctx->d_dna, nbytes, mem_fill, const_cast<uint8_t *>(dna)))) return r;
   if (!ctx->uniform) {
     DMALLOC(ctx->d_off, (size_t)n * sizeof(uint64_t));
-    HIPCHK(hipMemcpyAsync(ctx->d_off, off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->st));
+    if ((r = upload_chunked(ctx, (uint8_t *)ctx->d_off, (size_t)n * sizeof(uint64_t), mem_fill, off.data()))) return r;
   }
-  r = unpack_on_device(ctx);
-  if (r) return r;
-  HIPCHK(hipStreamSynchronize(ctx->st));  // `off` (host) must outlive the copy
-  return 0;
+  return unpack_on_device(ctx);
 }
 
 int spring_reorder_load_dna_device(spring_reorder_ctx *ctx, const void *d_dna, size_t nbytes, uint32_t n,
@@ -505,33 +677,51 @@ static int gunzip_if_needed(const uint8_t *&p, size_t &n, std::vector<uint8_t> &
   z_stream z;
   memset(&z, 0, sizeof(z));
   if (inflateInit2(&z, 15 + 16) != Z_OK) return fail(SPRING_REORDER_E_IO, "zlib: inflateInit2 failed");
-  buf.clear();
-  buf.reserve(n * 4);
-  size_t in_pos = 0;
-  std::vector<uint8_t> tmp(1 << 22);
-  int zr = Z_OK;
-  for (;;) {
-    if (z.avail_in == 0 && in_pos < n) {
-      const size_t take = std::min<size_t>(n - in_pos, 1u << 30);
-      z.next_in = const_cast<uint8_t *>(p + in_pos);
-      z.avail_in = (uInt)take;
-      in_pos += take;
+  // nothing thrown in here may cross the C ABI: allocation failures come back as an error code.  The output buffer
+  // starts modest and grows geometrically (std::vector), whatever the compressed size is.
+  try {
+    buf.clear();
+    buf.reserve(std::min<size_t>(n * 4, (size_t)1 << 30));
+    size_t in_pos = 0;
+    std::vector<uint8_t> tmp(1 << 22);
+    int zr = Z_OK;
+    for (;;) {
+      if (z.avail_in == 0 && in_pos < n) {
+        const size_t take = std::min<size_t>(n - in_pos, 1u << 30);
+        z.next_in = const_cast<uint8_t *>(p + in_pos);
+        z.avail_in = (uInt)take;
+        in_pos += take;
+      }
+      z.next_out = tmp.data();
+      z.avail_out = (uInt)tmp.size();
+      zr = inflate(&z, Z_NO_FLUSH);
+      if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) {
+        inflateEnd(&z);
+        return fail(SPRING_REORDER_E_IO, "gzip error in the FASTQ input (zlib %d)", zr);
+      }
+      buf.insert(buf.end(), tmp.data(), tmp.data() + (tmp.size() - z.avail_out));
+      if (zr == Z_STREAM_END) {
+        if (z.avail_in == 0 && in_pos >= n) break;  // last member
+        // what follows the member: another member, or zero padding up to the end of the image (tape / block
+        // padding; gzip(1) ignores it too) -- anything else is an error below
+        const uint8_t *rest = z.next_in;
+        size_t nrest = z.avail_in;
+        bool zeros = true;
+        for (size_t i = 0; i < nrest && zeros; i++) zeros = rest[i] == 0;
+        for (size_t i = in_pos; i < n && zeros; i++) zeros = p[i] == 0;
+        if (zeros) break;
+        if (inflateReset(&z) != Z_OK) { inflateEnd(&z); return fail(SPRING_REORDER_E_IO, "zlib: inflateReset failed"); }
+      } else if (zr == Z_BUF_ERROR && z.avail_in == 0 && in_pos >= n) {
+        inflateEnd(&z);
+        return fail(SPRING_REORDER_E_IO, "gzip error in the FASTQ input (truncated member)");
+      }
     }
-    z.next_out = tmp.data();
-    z.avail_out = (uInt)tmp.size();
-    zr = inflate(&z, Z_NO_FLUSH);
-    if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) {
-      inflateEnd(&z);
-      return fail(SPRING_REORDER_E_IO, "gzip error in the FASTQ input (zlib %d)", zr);
-    }
-    buf.insert(buf.end(), tmp.data(), tmp.data() + (tmp.size() - z.avail_out));
-    if (zr == Z_STREAM_END) {
-      if (z.avail_in == 0 && in_pos >= n) break;  // last member
-      if (inflateReset(&z) != Z_OK) { inflateEnd(&z); return fail(SPRING_REORDER_E_IO, "zlib: inflateReset failed"); }
-    } else if (zr == Z_BUF_ERROR && z.avail_in == 0 && in_pos >= n) {
-      inflateEnd(&z);
-      return fail(SPRING_REORDER_E_IO, "gzip error in the FASTQ input (truncated member)");
-    }
+  } catch (const std::bad_alloc &) {
+    inflateEnd(&z);
+    return fail(SPRING_REORDER_E_IO, "out of host memory while inflating the gzip FASTQ input");
+  } catch (const std::length_error &) {
+    inflateEnd(&z);
+    return fail(SPRING_REORDER_E_IO, "gzip FASTQ input inflates beyond what one buffer can hold");
   }
   inflateEnd(&z);
   p = buf.data();
@@ -1095,6 +1285,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   uint32_t *h_alive = nullptr;
   std::vector<uint32_t> alive_tmp;
   HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
+  struct HostFree { void *p; ~HostFree() { if (p) (void)hipHostFree(p); } } h_alive_guard{h_alive};  // (every early return below)
   uint64_t rounds = 0;
   double ms_search = 0;
   uint64_t launches = 0;
@@ -1139,7 +1330,6 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   }
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   HIPCHK(hipStreamSynchronize(st));
-  (void)hipHostFree(h_alive);
   for (auto &e : tev) (void)hipEventDestroy(e);
   ctx->stats.rounds = rounds;
   ctx->stats.ms_search_kernel = ms_search;
@@ -1303,7 +1493,11 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
   std::vector<uint32_t> alive_tmp;
   void *h_stage = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_alive, sizeof(uint32_t), hipHostMallocDefault));
-  if (comm->host_fn) HIPCHK(hipHostMalloc(&h_stage, total, hipHostMallocDefault));
+  if (comm->host_fn && hipHostMalloc(&h_stage, total, hipHostMallocDefault) != hipSuccess) {
+    (void)hipHostFree(h_alive);
+    (void)spring_reorder_mg_end(ctx);
+    return fail(SPRING_REORDER_E_HIP, "mg_run: cannot pin the exchange staging buffer");
+  }
   int ret = 0;
   *h_alive = 1;
   while (*h_alive && !ret) {
@@ -1342,7 +1536,15 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
   }
   (void)hipHostFree(h_alive);
   if (h_stage) (void)hipHostFree(h_stage);
-  if (ret) return ret;
+  if (ret) {
+    // a failed rank leaves the pool: its peers are stuck in the exchange until the caller tears the communicator
+    // down (RCCL) or makes its all-gather callback fail (host transport) -- the context itself is left consistent
+    const std::string keep = g_err;
+    (void)hipStreamSynchronize(st);
+    (void)spring_reorder_mg_end(ctx);
+    g_err = keep;
+    return ret;
+  }
   return spring_reorder_mg_end(ctx);
 }
 
@@ -1466,7 +1668,9 @@ int spring_reorder_download(spring_reorder_ctx *ctx, uint32_t *order, char *rc, 
   return 0;
 }
 
-int spring_reorder_emit_dna(spring_reorder_ctx *ctx, int32_t tid, uint8_t *dst, size_t cap, size_t *nbytes) {
+extern "C++" {
+namespace sr {
+int emit_dna_device(spring_reorder_ctx *ctx, int32_t tid, uint8_t **d_out, size_t *nbytes, uint64_t s_first, uint64_t s_cnt) {
   if (!ctx || ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "emit_dna: finalize first");
   if (tid < -1 || tid >= ctx->o.num_thr) return fail(SPRING_REORDER_E_ARG, "tid out of range");
   HIPCHK(hipSetDevice(ctx->dev));
@@ -1475,8 +1679,13 @@ int spring_reorder_emit_dna(spring_reorder_ctx *ctx, int32_t tid, uint8_t *dst, 
   const uint32_t *order;
   const char *rc;
   uint64_t cnt;
-  if (tid < 0) { order = P.f_order_s; rc = nullptr; cnt = ctx->nsing; }
-  else {
+  if (tid < 0) {
+    order = P.f_order_s; rc = nullptr; cnt = ctx->nsing;
+    if (s_cnt != ~0ull) {
+      if (s_first > cnt || s_cnt > cnt - s_first) return fail(SPRING_REORDER_E_ARG, "emit_dna: singleton range out of bounds");
+      order += s_first; cnt = s_cnt;
+    }
+  } else {
     const uint64_t a = ctx->tid_off[tid], b = ctx->tid_off[tid + 1];
     order = P.f_order + a; rc = P.f_rc + a; cnt = b - a;
   }
@@ -1502,21 +1711,36 @@ int spring_reorder_emit_dna(spring_reorder_ctx *ctx, int32_t tid, uint8_t *dst, 
     total = last_off + last_sz;
   }
   if (nbytes) *nbytes = total;
-  int ret = 0;
-  if (dst && total) {
-    if (cap < total) ret = fail(SPRING_REORDER_E_ARG, "emit_dna: buffer too small (%zu < %llu)", cap, (unsigned long long)total);
-    else {
+  if (d_out) {
+    *d_out = nullptr;
+    if (total) {
       uint8_t *d_dst = nullptr;
       DMALLOC(d_dst, total);
       launch_emit_dna(st, ctx->d_reads, ctx->d_lens, ctx->S, order, rc, cnt, d_off, rec, d_dst);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(dst, d_dst, total, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      ctx->dfree(d_dst);
+      *d_out = d_dst;
     }
   }
-  ctx->dfree(d_sz); ctx->dfree(d_off); ctx->dfree(d_tmp);
-  return ret;
+  ctx->dfree(d_sz); ctx->dfree(d_off); ctx->dfree(d_tmp);  // (dfree waits for the stream: the kernel above has run)
+  return 0;
+}
+void emit_dna_free(spring_reorder_ctx *ctx, uint8_t *d) { if (ctx && d) ctx->dfree(d); }
+}  // namespace sr
+}  // extern "C++"
+
+int spring_reorder_emit_dna(spring_reorder_ctx *ctx, int32_t tid, uint8_t *dst, size_t cap, size_t *nbytes) {
+  size_t total = 0;
+  uint8_t *d = nullptr;
+  int r = emit_dna_device(ctx, tid, dst ? &d : nullptr, &total);
+  if (r) return r;
+  if (nbytes) *nbytes = total;
+  if (dst && total) {
+    if (cap < total) r = fail(SPRING_REORDER_E_ARG, "emit_dna: buffer too small (%zu < %llu)", cap, (unsigned long long)total);
+    else if (hipStreamSynchronize(ctx->st) != hipSuccess || hipMemcpy(dst, d, total, hipMemcpyDeviceToHost) != hipSuccess)
+      r = fail(SPRING_REORDER_E_HIP, "emit_dna: device to host copy failed");
+  }
+  emit_dna_free(ctx, d);
+  return r;
 }
 
 }  // extern "C"

@@ -481,3 +481,69 @@ def test_default_chain_count_on_a_deep_pool_vs_oracle():
         s.load_dna(dna2, n, L)
         s.build_dict()
         assert s.auto_chains() == (n >> 10, False)
+
+
+def _read_file_set(d, T):
+    """-> the per-tid streams of a call_reorder output directory, concatenated in tid order (+ per-tid counts)"""
+    out = {k: [] for k in ("order", "rc", "flag", "pos", "rlen", "dna")}
+    cnt = []
+    for t in range(T):
+        o = np.fromfile(d / ("read_order.bin.%d" % t), np.uint32)
+        cnt.append(len(o))
+        out["order"].append(o.tobytes())
+        out["rc"].append(gzip.open(d / ("read_rev.txt.%d" % t)).read())
+        out["flag"].append(gzip.open(d / ("tempflag.txt.%d" % t)).read())
+        out["pos"].append(gzip.open(d / ("temppos.txt.%d" % t)).read())
+        out["rlen"].append(gzip.open(d / ("read_lengths.bin.%d" % t)).read())
+        out["dna"].append((d / ("temp.dna.%d" % t)).read_bytes())
+    res = {k: b"".join(v) for k, v in out.items()}
+    res["cnt"] = cnt
+    res["order_s"] = np.fromfile(d / "read_order.bin.singleton", np.uint32)
+    res["dna_s"] = (d / "temp.dna.singleton").read_bytes()
+    res["count_s"] = np.fromfile(d / "temp.dna.singleton.count", np.uint32).tolist()
+    return res
+
+
+def _check_file_set(got, want, read, ln, L, T):
+    assert got["order"] == want["order"].tobytes() and got["rc"] == want["rc"].tobytes()
+    assert got["flag"] == want["flag"].tobytes() and got["pos"] == want["pos"].tobytes()
+    assert got["rlen"] == want["rlen"].tobytes()
+    assert got["cnt"] == np.diff(want["tid_off"]).tolist()
+    assert got["dna"] == po.write_dna_stream(read, ln, L, want["order"], want["rc"])
+    assert np.array_equal(got["order_s"], want["order_s"]) and got["count_s"] == [len(want["order_s"])]
+    assert got["dna_s"] == po.write_dna_stream(read, ln, L, want["order_s"], None)
+
+
+@pytest.mark.parametrize("devices", [(), (0, 0), (0, 0, 0)])
+def test_call_reorder_many_chains_and_device_list(tmp_path, devices):
+    """The drop-in on a device list (SURVEY 8(b) `opts`): one pool over the listed devices inside ONE call -- host
+    threads, contexts and the exchange live in the library -- writes the same merged per-tid file set as one device
+    (here the entries repeat device 0, so the exchange goes through host memory).  200 k reads of 100 bp: the input is
+    several pinned chunks, the outputs cross the 64 KiB stored-block size many times."""
+    sa = _sa()
+    from spring_amd.reorder import CompressionParams
+    n, L, K, T = 200_000, 100, 510, 5
+    dna = sa.synth_dna_host(n, L, n * L // 25, 31, 10000)
+    (tmp_path / "input_clean_1.dna").write_bytes(dna)
+    sa.call_reorder(str(tmp_path), CompressionParams(L, [n, 0], num_thr=T), sa.ReorderOpts(num_chains=K, num_thr=T, devices=devices))
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, T)
+    _check_file_set(_read_file_set(tmp_path, T), want, read, ln, L, T)
+
+
+def test_call_reorder_lengths_that_hide_in_a_fixed_size_stream(tmp_path):
+    """Reads of 97..100 bases all take 2 + 25 bytes: the stream has the size of a fixed-length one, the device-side
+    length check notices, and the stage falls back to walking the records."""
+    sa = _sa()
+    from spring_amd.reorder import CompressionParams
+    reads = rs.var_length_reads(77, 9000, 3000, 97, 100, 0.01)
+    assert len(set(len(r) for r in reads)) > 1
+    dna, n, L = rs.pack_var(reads), len(reads), 100
+    assert len(dna) == n * 27
+    (tmp_path / "input_clean_1.dna").write_bytes(dna)
+    sa.call_reorder(str(tmp_path), CompressionParams(L, [n, 0], num_thr=2), sa.ReorderOpts(num_chains=16, num_thr=2))
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, 16, 2)
+    _check_file_set(_read_file_set(tmp_path, 2), want, read, ln, L, 2)
+    got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=16, num_thr=2))  # the in-memory entry takes the same path
+    _same(got, want, "same-size")
