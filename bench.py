@@ -3,14 +3,16 @@
 
 One "step" = one pass of the whole stage (unpack -> dictionaries -> chains -> streams) over one
 batch of synthetic reads that is already resident in HBM as a .dna record stream when the timed
-region starts.  N=1 workload = BASELINE configs[2]: 100 M x 150 bp single-end.  For N>1 the job is ONE
-shared read pool of 50 M x N reads (N=8: BASELINE configs[4], 400 M x 150 bp) with 65536 x N chains sharded
+region starts.  N=1 workload = BASELINE configs[2]: 100 M x 150 bp single-end.  For every N>1 the job is the SAME
+shared read pool -- BASELINE configs[4], 400 M x 150 bp, which also fits one GPU (108 GB) -- with the chains sharded
 over the GPUs and one RCCL all-gather of the proposal words per round, issued by the library on its own stream
-(spring_reorder_mg_run); `value` = pool reads / wall-clock; see DESIGN.md "Multi-GPU".  --lanes switches the
-N>1 run to independent lanes (one read set per GPU, no data-path collective).
+(spring_reorder_mg_run): total work is fixed, `"scaling": "strong"`, `value` = pool reads / wall-clock, and rank 0
+also runs that pool alone so the line carries the single-GPU rate it is to be compared with; see DESIGN.md
+"Multi-GPU".  --lanes switches the N>1 run to independent lanes (one read set per GPU, no data-path collective).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-search kernel and `cpu_baseline` (the C oracle timed on a bounded sample of the same workload).
+round kernel, `cpu_baseline` (the C oracle timed on a bounded sample of the same workload) and `compression_cost`
+(what the default chain count costs in compressed size, real BSC).
 """
 import argparse
 import ctypes as C
@@ -18,6 +20,8 @@ import json
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,13 +46,17 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lanes", action="store_true",
                     help="N>1: independent lanes (every rank its own read set) instead of one shared pool")
-    ap.add_argument("--pool-reads-per-gpu", type=int, default=50_000_000,
-                    help="N>1: the shared pool holds this many reads per GPU (N=8: 400 M, BASELINE configs[4])")
+    ap.add_argument("--pool-reads", type=int, default=400_000_000,
+                    help="N>1: reads in the shared pool (BASELINE configs[4]: 400 M), the same for every N")
+    ap.add_argument("--pool-chains", type=int, default=524_288, help="N>1: chains of the pool, the same for every N")
+    ap.add_argument("--no-single", action="store_true", help="N>1: skip rank 0's single-GPU pass over the same pool")
+    ap.add_argument("--cost-sample", type=int, default=4_000_000,
+                    help="reads in the compression_cost leg (same coverage and error rate; 0 = skip)")
     ap.add_argument("--force-pool", action="store_true",
                     help="run the shared-pool path even at N=1 (a 1-rank RCCL communicator): exercises the in-library "
                          "ncclAllGather on a single-GPU box")
-    ap.add_argument("--files-sample", type=int, default=20_000_000,
-                    help="reads in the file-contract leg (stage_incl_files); 0 = skip")
+    ap.add_argument("--files-sample", type=int, default=100_000_000,
+                    help="reads in the file-contract leg (stage_incl_files): the whole workload by default; 0 = skip")
     return ap.parse_args()
 
 
@@ -66,11 +74,57 @@ def algorithmic_bytes_apply(st):
     return 2 * n * 12 + n * 16
 
 
+def compression_cost(spring_amd, a, dev):
+    """bits per base of the reorder + encoder output after BSC (the reference's, oracle/_ref/ref_bsc) for K = default
+    and K = num_thr on a sample with the workload's coverage and error rate (encoder.cpp:111-156 is where SPRING
+    hands these streams to BSC)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from oracle import pyoracle as po
+    from spring_amd.encoder import EncoderStage
+    bsc_bin = po.ref_bsc_bin()
+    if not bsc_bin:
+        return {"error": "oracle/_ref/ref_bsc is not built (make -C oracle ref, needs the reference sources)"}
+    n, L = a.cost_sample, a.readlen
+    G = max(n * L // a.coverage, 2 * L)
+
+    def bsc(b):
+        if not len(b):
+            return 0
+        with tempfile.TemporaryDirectory() as d:
+            fi, fo = os.path.join(d, "in"), os.path.join(d, "out")
+            open(fi, "wb").write(b)
+            subprocess.run([bsc_bin, fi, fo], check=True, stdout=subprocess.DEVNULL)
+            return os.path.getsize(fo)
+
+    res = {}
+    for name, K in (("default", a.chains), ("num_thr", a.num_thr)):
+        with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=K, num_thr=1)) as st:
+            st.load_synth(n, L, G, 5, a.err_ppm)
+            st.run()
+            sst = st.stats()
+            with EncoderStage(dev) as enc:
+                info = enc.encode(st)
+                e = enc.streams()
+                packed, _ = enc.seq_packed()
+        dpos = np.diff(e["pos"].astype(np.int64), prepend=0).astype(np.int32)
+        tot = (bsc(packed) + bsc(dpos.tobytes()) + bsc(bytes(e["noise"])) + bsc(e["noisepos"].tobytes())
+               + bsc(e["rc"].tobytes()) + bsc(bytes(e["unaligned"])))
+        res[name] = {"chains": int(sst["chains"]), "contigs": int(info["num_contigs"]), "bytes": int(tot),
+                     "bits_per_base": round(tot * 8.0 / (n * L), 4), "chains_stage_ms": round(sst["ms_chains"], 1)}
+    d, r = res["default"], res["num_thr"]
+    return {"sample_reads": n, "read_len": L, "coverage": a.coverage, "default_chains": d, "reference_granularity": r,
+            "size_ratio_default_vs_num_thr": round(d["bytes"] / r["bytes"], 4),
+            "what": "read streams (consensus, positions, noise, noise positions, orientation, unaligned) after the reference's "
+                    "BSC; reads per chain %d (default) vs %d (K = num_thr = %d)" % (n // max(d["chains"], 1), n // max(r["chains"], 1), a.num_thr)}
+
+
 def kernels_sha():
     """Identity of the kernels a PMC summary belongs to (profiles/pmc_latest.json carries the same stamp)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("reorder_kernels.hip", "reorder_device.h"):
+    for f in ("reorder_kernels.hip", "reorder_device.h", "reorder_round_mc.h"):
         h.update(open(os.path.join(ROOT, "spring_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -97,9 +151,9 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
     world, rank = lanes.world, lanes.rank
     dev = torch.cuda.current_device()
     L = a.readlen
-    n = a.pool_reads_per_gpu * world
+    n = a.pool_reads
     G = max(n * L // a.coverage, 2 * L)
-    Ktot = (a.chains or 65536) * world
+    Ktot = (a.pool_chains + world - 1) // world * world
     nb = L_.spring_synth_dna_bytes(n, L)
     buf = torch.empty(nb, dtype=torch.uint8, device="cuda")     # every rank holds the whole pool (replicated)
     assert L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 13, a.err_ppm) == 0, L_.spring_reorder_last_error()
@@ -131,8 +185,8 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
         comm = PoolComm(GroupView(dist, gl, "gloo"), torch.device("cuda", dev), transport="host")
         exchange = "host-staged all-gather over gloo (RCCL communicator unavailable)"
 
-    def one_pass():
-        dp = DistPool(comm, Ktot, num_thr=a.num_thr)
+    def one_pass(**kw):
+        dp = DistPool(comm, Ktot, num_thr=a.num_thr, **kw)
         st = dp.run(lambda s: s.load_dna_device(buf.data_ptr(), nb, n, L, True))
         st["local_matched"], st["local_single"] = st["n_matched"], st["n_single"]
         dp.close()
@@ -141,24 +195,57 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
     el, st = lanes.timed_steps(one_pass, a.steps, a.warmup)
     tot_matched = lanes.sum_over_ranks(st["local_matched"])
     tot_single = lanes.sum_over_ranks(st["local_single"])
+    # one more pass with HIP events around the three pieces of a round (outside the timed region): where a round goes
+    stt = one_pass(time_search=True)
+    rounds = max(stt["search_launches"], 1)
+    budget = {"rounds": stt["rounds"],
+              "round_kernel_us": round(stt["ms_search_kernel"] * 1e3 / rounds, 1),
+              "exchange_us": round(stt["ms_exchange"] * 1e3 / rounds, 1),
+              "resolve_and_mark_us": round(stt["ms_resolve_mark"] * 1e3 / rounds, 1),
+              "replicated_ms": {"unpack": round(stt["ms_unpack"], 1), "dictionaries": round(stt["ms_dict"], 1),
+                                "finalize": round(stt["ms_finalize"], 1)},
+              "chains_ms": round(stt["ms_chains"], 1),
+              "what": "rank 0, per round: k_round over the rank's own chains | all-gather of the proposal words | "
+                      "k_mg_resolve + k_mg_mark over ALL chains (replicated work, grows with N); replicated_ms is work every "
+                      "rank repeats for the whole pool"}
+    # the single-GPU rate on the SAME pool and chain count (rank 0 alone, the others wait): what `value` is to be divided by
+    single = None
+    if world > 1 and not a.no_single:
+        lanes.barrier()
+        if rank == 0:
+            try:
+                t0 = time.perf_counter()
+                s1 = spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=Ktot, num_thr=a.num_thr))
+                s1.load_dna_device(buf.data_ptr(), nb, n, L, True)
+                s1.run()
+                s1s = s1.stats()
+                s1.close()
+                t1 = time.perf_counter() - t0
+                single = {"value": round(n / t1 / 1e6, 3), "unit": "Mreads/s", "seconds": round(t1, 3), "rounds": s1s["rounds"],
+                          "what": "the same pool and chain count on rank 0's GPU alone (one pass incl. allocations)"}
+            except Exception as e:  # noqa: BLE001
+                single = {"error": repr(e)}
+        lanes.barrier()
     out = {
         "metric": "Mreads/s through reorder stage", "value": round(n * a.steps / el / 1e6, 3), "unit": "Mreads/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": "ONE shared pool of %d x %d bp single-end synthetic reads (%d per GPU; uniform genome %d bp, %dx "
-                        "coverage, %.1f%% substitutions, 50%% reverse-complemented), resident in HBM on every GPU as .dna "
-                        "records; %d chains sharded over %d GPUs, one RCCL all-gather of %d proposal bytes per round "
+            "workload": "ONE shared pool of %d x %d bp single-end synthetic reads, the same for every N (uniform genome "
+                        "%d bp, %dx coverage, %.1f%% substitutions, 50%% reverse-complemented), resident in HBM on every GPU "
+                        "as .dna records; %d chains sharded over %d GPUs, one RCCL all-gather of %d proposal bytes per round "
                         "issued by the library on its stream"
-                        % (n, L, a.pool_reads_per_gpu, G, a.coverage, a.err_ppm / 1e4, Ktot, world, Ktot * 8),
-            "exchange": exchange, "pool_reads": n, "reads_per_gpu": a.pool_reads_per_gpu, "read_len": L, "chains": Ktot, "num_thr": a.num_thr,
+                        % (n, L, G, a.coverage, a.err_ppm / 1e4, Ktot, world, Ktot * 8),
+            "exchange": exchange, "pool_reads": n, "read_len": L, "chains": Ktot, "num_thr": a.num_thr,
             "parallelism": "1 process per GPU, single shared pool: reads + dictionaries replicated, chains sharded, "
                            "all-gather per round (DESIGN.md section 7)",
             "stage_ms_rank0": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},
             "rounds": st["rounds"], "reads_emitted_all_ranks": int(tot_matched + tot_single),
-            "note": "weak scaling: the pool and the chain count grow with N, the per-GPU share is fixed; at N=1 the "
-                    "bench runs BASELINE configs[2] (100 M reads) instead",
+            "note": "strong scaling: pool and chain count are the same for every N > 1; at N=1 the bench runs BASELINE "
+                    "configs[2] (100 M reads) instead, so compare with single_gpu_same_pool, not with the N=1 line",
         },
+        "round_budget": budget,
+        "single_gpu_same_pool": single,
     }
     if rank == 0:
         assert int(tot_matched + tot_single) == n, "the ranks' streams do not add up to the pool"
@@ -244,7 +331,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             # only a summary taken from THESE kernels counts (the stamp is the hash of the kernel sources)
             if pmc.get("reads") == n and pmc.get("read_len") == L and pmc.get("kernels_sha") == kernels_sha():
-                ks = pmc["kernels"]["sr::k_round"]
+                ks = pmc["kernels"].get("sr::k_round_mc") or pmc["kernels"]["sr::k_round"]
                 traffic = round(ks["fetch_bytes_per_launch"] + ks["write_bytes_per_launch"], 1)
         except Exception:
             traffic = None
@@ -253,7 +340,7 @@ def main():
         # (tools/random_gather_bench.hip, profiles/r01_pmc_calibration_random_gather.csv), not 8 TB/s / 64 B
         req = None
         try:
-            fetch = pmc["kernels"]["sr::k_round"]["fetch_bytes_per_launch"] if traffic is not None else None
+            fetch = ks["fetch_bytes_per_launch"] if traffic is not None else None
             if fetch:
                 rate = fetch / 64.0 / (ms * 1e-3 / launches) / 1e9
                 req = {"achieved": round(rate, 2), "peak": RANDOM_REQ_PEAK_G, "unit": "G random 64-byte requests/s",
@@ -263,7 +350,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_kernels_sha": kernels_sha(),
-            "kernel": "sr::k_round (one chain per wavefront: apply of the last proposal + Hamming search)",
+            "kernel": "sr::k_round_mc (four chains per wavefront: apply of the last proposal + Hamming search)",
             "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
             "algorithmic_bytes_per_launch": round(alg / launches, 1),
             "algorithmic_bytes_per_read": round(alg / n, 1),
@@ -271,6 +358,11 @@ def main():
                                        "the chain state the kernel also moves (counts, consensus) is not counted",
             "work": {"probes": sr["probes"], "keyok": sr["keyok"], "cands": sr["cands"], "hits": sr["hits"]},
             "random_request_ceiling": req,
+            # from the same PMC summary: the share of the launch during which a SIMD's vector ALU is issuing
+            # (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)), and the instruction mix per wavefront
+            "valu_issue_frac": ks.get("valu_issue_frac") if traffic is not None else None,
+            "insts_per_wavefront": ks.get("insts_per_wave") if traffic is not None else None,
+            "hbm_write_bytes_per_launch": round(ks["write_bytes_per_launch"], 1) if traffic is not None else None,
         }
         ms2, l2 = st_2k["ms_search_kernel"], max(st_2k["search_launches"], 1)
         if ms2 > 0:
@@ -315,8 +407,8 @@ def main():
             s.close()
             t_pcie = time.perf_counter() - t0
             out["stage_incl_pcie"] = {"value": round(n / t_pcie / 1e6, 2), "unit": "Mreads/s", "seconds": round(t_pcie, 3),
-                                      "what": "host .dna buffer (%.1f GB, pageable) -> HBM -> stage -> every output stream back "
-                                              "in host arrays (%.1f GB)" % (nb / 1e9, sum(v.nbytes for v in res.values() if hasattr(v, "nbytes")) / 1e9)}
+                                      "what": "host .dna buffer (%.1f GB, pageable; through pinned chunks) -> HBM -> stage -> "
+                                              "every output stream back in host arrays (%.1f GB)" % (nb / 1e9, sum(v.nbytes for v in res.values() if hasattr(v, "nbytes")) / 1e9)}
             del res, host
         except Exception as e:
             out["stage_incl_pcie"] = {"error": repr(e)}
@@ -400,6 +492,51 @@ def main():
             "single_thread": {"value": round(ns1 / t1 / 1e6, 4), "sample_reads": ns1, "seconds": round(t1, 1)},
             "host_cpus": os.cpu_count(),
         }
+    if rank == 0 and world == 1 and a.cpu_sample > 0 and "cpu_baseline" in out:
+        # the reference's own span ("Time for this step", spring.cpp:152-160): input_clean_1.dna from disk, load,
+        # dictionaries, reorder, and the per-tid output files written -- the CPU twin of stage_incl_files
+        try:
+            import shutil
+            import tempfile
+            td = tempfile.mkdtemp(prefix="spring_bench_cpu_")
+            fn = os.path.join(td, "input_clean_1.dna")
+            with open(fn, "wb") as f:
+                f.write(dna)
+            os.sync()
+            t0 = time.perf_counter()
+            raw = np.fromfile(fn, np.uint8).tobytes()
+            os.remove(fn)
+            readf, lnf = po.load_dna(raw, ns, L)
+            res = po.reorder_omp(readf, lnf, L, T)
+            toff = res["tid_off"]
+            for t in range(len(toff) - 1):
+                a0, a1 = int(toff[t]), int(toff[t + 1])
+                res["order"][a0:a1].tofile(os.path.join(td, "read_order.bin.%d" % t))
+                for k, nm in (("rc", "read_rev.txt"), ("flag", "tempflag.txt"), ("pos", "temppos.txt"), ("rlen", "read_lengths.bin")):
+                    res[k][a0:a1].tofile(os.path.join(td, "%s.%d" % (nm, t)))
+                with open(os.path.join(td, "temp.dna.%d" % t), "wb") as f:
+                    f.write(po.write_dna_stream(readf, lnf, L, res["order"][a0:a1], res["rc"][a0:a1]))
+            with open(os.path.join(td, "temp.dna.singleton"), "wb") as f:
+                f.write(po.write_dna_stream(readf, lnf, L, res["order_s"], None))
+            res["order_s"].tofile(os.path.join(td, "read_order.bin.singleton"))
+            tf = time.perf_counter() - t0
+            shutil.rmtree(td, ignore_errors=True)
+            out["cpu_baseline"]["stage_incl_files_value"] = round(ns / tf / 1e6, 4)
+            out["cpu_baseline"]["stage_incl_files_what"] = (
+                "the same port and sample through the reference's span: read + delete input_clean_1.dna, load, dictionaries, "
+                "reorder at %d threads, write the per-tid and singleton files (uncompressed), %.1f s" % (T, tf))
+            del res, readf, lnf, raw
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"]["stage_incl_files_value"] = None
+            out["cpu_baseline"]["stage_incl_files_error"] = repr(e)
+    if rank == 0 and world == 1 and a.cost_sample > 0 and not a.no_roofline:
+        # what the speed costs: compressed size of the encoder's output streams after the REFERENCE'S OWN BSC (src/libbsc
+        # compiled in place, test infrastructure oracle/_ref/ref_bsc, outside any timed region) for the default chain
+        # count against the reference's own granularity K = num_thr, same reads
+        try:
+            out["compression_cost"] = compression_cost(spring_amd, a, dev)
+        except Exception as e:  # noqa: BLE001
+            out["compression_cost"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     lanes.close()

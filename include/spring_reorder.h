@@ -73,6 +73,10 @@ typedef struct {
   double ms_search_kernel;
   uint64_t search_launches;
   uint64_t device_bytes;   /* bytes of HBM the context holds */
+  /* multi-GPU pools with time_search = 1: summed durations of the per-round exchange (all-gather of the proposal
+   * words) and of the kernels every rank runs over ALL chains after it (k_mg_resolve + k_mg_mark); ms_search_kernel is
+   * the round kernel over the rank's own chains */
+  double ms_exchange, ms_resolve_mark;
   uint64_t chains;         /* K the chain phase ran with (opts.num_chains, or what the default rule chose) */
   uint64_t deep_pool;      /* 1: the dictionary averages >= 1.3 reads per key (the deep-coverage default applies) */
 } spring_reorder_stats;

@@ -59,7 +59,8 @@ class Stats(C.Structure):
                 + [("numkeys", C.c_uint64 * 2), ("dict_numreads", C.c_uint64 * 2)]
                 + [(k, C.c_double) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize", "ms_total",
                                              "ms_search_kernel")]
-                + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64), ("chains", C.c_uint64),
+                + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64),
+                   ("ms_exchange", C.c_double), ("ms_resolve_mark", C.c_double), ("chains", C.c_uint64),
                    ("deep_pool", C.c_uint64)])
 
     def asdict(self):

@@ -440,6 +440,58 @@ static int upload_chunked(spring_reorder_ctx *ctx, uint8_t *d_dst, size_t nbytes
   return 0;
 }
 
+// Device -> host copies of several arrays at once: the pieces (32 MiB chunks of every array) are dealt out to up to 8
+// host threads, each with its own stream and two pinned chunks -- the device-to-pinned copy of one piece runs while
+// the thread copies the previous piece out to the caller's (pageable) memory.
+struct D2HJob { void *dst; const void *src; size_t nbytes; };
+static int download_chunked(spring_reorder_ctx *ctx, const std::vector<D2HJob> &jobs) {
+  struct Piece { uint8_t *dst; const uint8_t *src; size_t len; };
+  std::vector<Piece> pieces;
+  for (const D2HJob &j : jobs)
+    for (size_t off = 0; off < j.nbytes; off += PIN_CHUNK)
+      pieces.push_back({(uint8_t *)j.dst + off, (const uint8_t *)j.src + off, std::min(PIN_CHUNK, j.nbytes - off)});
+  if (pieces.empty()) return 0;
+  HIPCHK(hipStreamSynchronize(ctx->st));  // the arrays are complete
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nthr = (int)std::min<size_t>(std::min<size_t>(8, hw), pieces.size());
+  std::atomic<size_t> next{0};
+  std::atomic<int> rc{0};
+  auto worker = [&]() {
+    void *pin[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    const Piece *pending[2] = {nullptr, nullptr};
+    if (hipSetDevice(ctx->dev) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = SPRING_REORDER_E_HIP;
+    for (int k = 0; k < 2 && !rc.load(); k++) if (!(pin[k] = pinned_get())) rc = SPRING_REORDER_E_HIP;
+    // two-deep software pipeline on one stream: issue copy k, then drain copy k-1 while k is in flight
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2 && !rc.load(); k++) if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) rc = SPRING_REORDER_E_HIP;
+    auto drain = [&](int k) {
+      if (!pending[k]) return;
+      if (hipEventSynchronize(ev[k]) != hipSuccess) rc = SPRING_REORDER_E_HIP;
+      else memcpy(pending[k]->dst, pin[k], pending[k]->len);
+      pending[k] = nullptr;
+    };
+    for (int k = 0; !rc.load(); k ^= 1) {
+      const size_t i = next.fetch_add(1);
+      if (i >= pieces.size()) break;
+      drain(k);
+      if (hipMemcpyAsync(pin[k], pieces[i].src, pieces[i].len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipEventRecord(ev[k], st) != hipSuccess) { rc = SPRING_REORDER_E_HIP; break; }
+      pending[k] = &pieces[i];
+      drain(k ^ 1);
+    }
+    drain(0); drain(1);
+    for (int k = 0; k < 2; k++) { if (ev[k]) (void)hipEventDestroy(ev[k]); pinned_put(pin[k]); }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  };
+  std::vector<std::thread> th;
+  try { for (int t = 1; t < nthr; t++) th.emplace_back(worker); } catch (const std::system_error &) {}
+  worker();
+  for (auto &x : th) x.join();
+  (void)hipGetLastError();
+  return rc.load() ? fail(SPRING_REORDER_E_HIP, "download: device to host copy failed") : 0;
+}
+
 static int scan_records(const uint8_t *dna, size_t nbytes, uint32_t n, int L, bool &uniform, std::vector<uint64_t> &off);
 
 extern "C++" {
@@ -1500,10 +1552,22 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
   }
   int ret = 0;
   *h_alive = 1;
+  // time_search: four events per round (round kernel | exchange | resolve + mark), read back at every host check
+  const bool timed = ctx->o.time_search != 0;
+  std::vector<hipEvent_t> tev;
+  if (timed) {
+    tev.resize(4 * (size_t)R);
+    for (auto &e : tev) if (hipEventCreate(&e) != hipSuccess) { ret = fail(SPRING_REORDER_E_HIP, "mg_run: hipEventCreate failed"); break; }
+  }
+  double ms_round = 0, ms_xchg = 0, ms_mark = 0;
+  uint64_t timed_rounds = 0;
   while (*h_alive && !ret) {
+    int done_rounds = 0;
     for (int i = 0; i < R && !ret; i++) {
       set_round_buffers(ctx);
+      if (timed) (void)hipEventRecord(tev[4 * i], st);
       launch_round(st, P, stats, true);
+      if (timed) (void)hipEventRecord(tev[4 * i + 1], st);
       if (comm->rccl) {  // in place: this rank's words already sit at their offset of the receive buffer
         const int e = g_rccl.AllGather(P.prop + P.c0, P.prop, P.K, RCCL_UINT64, comm->rccl, st);
         if (e) ret = fail(SPRING_REORDER_E_HIP, "ncclAllGather: %s", rccl_err(e));
@@ -1518,8 +1582,11 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
         he = hipMemcpyAsync(P.prop, h_stage, total, hipMemcpyHostToDevice, st);
         if (he != hipSuccess) { ret = fail(SPRING_REORDER_E_HIP, "staging copy failed: %s", hipGetErrorString(he)); break; }
       }
+      if (timed) (void)hipEventRecord(tev[4 * i + 2], st);
       launch_mg_resolve(st, P);
       launch_mg_mark(st, P);
+      if (timed) (void)hipEventRecord(tev[4 * i + 3], st);
+      done_rounds = i + 1;
       ctx->round_no++;
       ctx->stats.rounds++;
       if (ctx->stats.rounds % 16 == 0)
@@ -1527,6 +1594,17 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
           launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
     }
     if (ret) break;
+    if (timed) {
+      (void)hipStreamSynchronize(st);
+      for (int i = 0; i < done_rounds; i++) {
+        float a = 0, b = 0, c = 0;
+        (void)hipEventElapsedTime(&a, tev[4 * i], tev[4 * i + 1]);
+        (void)hipEventElapsedTime(&b, tev[4 * i + 1], tev[4 * i + 2]);
+        (void)hipEventElapsedTime(&c, tev[4 * i + 2], tev[4 * i + 3]);
+        ms_round += a; ms_xchg += b; ms_mark += c;
+      }
+      timed_rounds += (uint64_t)done_rounds;
+    }
     // every rank recounted the running chains from the same gathered words: the same decision everywhere
     ret = running_chains(ctx, alive_tmp, h_alive);
     if (!ret) {
@@ -1536,6 +1614,11 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
   }
   (void)hipHostFree(h_alive);
   if (h_stage) (void)hipHostFree(h_stage);
+  for (auto &e : tev) if (e) (void)hipEventDestroy(e);
+  if (timed) {
+    ctx->stats.ms_search_kernel = ms_round; ctx->stats.search_launches = timed_rounds;
+    ctx->stats.ms_exchange = ms_xchg; ctx->stats.ms_resolve_mark = ms_mark;
+  }
   if (ret) {
     // a failed rank leaves the pool: its peers are stuck in the exchange until the caller tears the communicator
     // down (RCCL) or makes its all-gather callback fail (host transport) -- the context itself is left consistent
@@ -1655,14 +1738,17 @@ int spring_reorder_download(spring_reorder_ctx *ctx, uint32_t *order, char *rc, 
   HIPCHK(hipSetDevice(ctx->dev));
   DevParams &P = ctx->P;
   const size_t nm = ctx->nrec, ns = ctx->nsing;
+  std::vector<D2HJob> jobs;
   if (nm) {
-    if (order) HIPCHK(hipMemcpy(order, P.f_order, nm * 4, hipMemcpyDeviceToHost));
-    if (rc) HIPCHK(hipMemcpy(rc, P.f_rc, nm, hipMemcpyDeviceToHost));
-    if (flag) HIPCHK(hipMemcpy(flag, P.f_flag, nm, hipMemcpyDeviceToHost));
-    if (pos) HIPCHK(hipMemcpy(pos, P.f_pos, nm * 8, hipMemcpyDeviceToHost));
-    if (rlen) HIPCHK(hipMemcpy(rlen, P.f_len, nm * 2, hipMemcpyDeviceToHost));
+    if (order) jobs.push_back({order, P.f_order, nm * 4});
+    if (rc) jobs.push_back({rc, P.f_rc, nm});
+    if (flag) jobs.push_back({flag, P.f_flag, nm});
+    if (pos) jobs.push_back({pos, P.f_pos, nm * 8});
+    if (rlen) jobs.push_back({rlen, P.f_len, nm * 2});
   }
-  if (ns && order_s) HIPCHK(hipMemcpy(order_s, P.f_order_s, ns * 4, hipMemcpyDeviceToHost));
+  if (ns && order_s) jobs.push_back({order_s, P.f_order_s, ns * 4});
+  const int rd = download_chunked(ctx, jobs);
+  if (rd) return rd;
   if (tid_off) memcpy(tid_off, ctx->tid_off.data(), ctx->tid_off.size() * 8);
   if (tid_off_s) memcpy(tid_off_s, ctx->tid_off_s.data(), ctx->tid_off_s.size() * 8);
   return 0;

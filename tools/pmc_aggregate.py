@@ -14,8 +14,10 @@ csv.field_size_limit(1 << 30)
 
 def short(name):
     n = name.split("(")[0].replace("void ", "")
+    if n.startswith("sr::k_round_mc<"):
+        return "sr::k_round_mc"   # the production instantiation is the only one scale_probe launches
     if n.startswith("sr::k_round<"):
-        return "sr::k_round"   # the production instantiation is the only one scale_probe launches
+        return "sr::k_round"
     return n
 
 
@@ -23,7 +25,7 @@ def kernels_sha():
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("reorder_kernels.hip", "reorder_device.h"):
+    for f in ("reorder_kernels.hip", "reorder_device.h", "reorder_round_mc.h"):
         h.update(open(os.path.join(root, "spring_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -31,7 +33,7 @@ def kernels_sha():
 kern = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 dur = collections.defaultdict(lambda: collections.defaultdict(float))
-for p in ("fetch", "write", "sq", "tcc", "grbm"):
+for p in ("fetch", "write", "sq", "insts", "tcc", "grbm"):
     d = os.path.join(pmc_dir, p)
     if not os.path.isdir(d):
         continue
@@ -56,6 +58,14 @@ for k, c in kern.items():
     hm = c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)
     e["l2_hit_rate"] = c.get("TCC_HIT_sum", 0) / hm if hm else None
     e["wait_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
+    # share of the launch during which a SIMD's vector ALU is issuing: SQ_ACTIVE_INST_VALU counts quad-cycles summed over
+    # the waves; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE = shader clocks of the dispatches
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+        e["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]), 4)
+        e["salu_issue_frac"] = round(c.get("SQ_ACTIVE_INST_SCA", 0) * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]), 4)
+    if c.get("SQ_WAVES") and c.get("SQ_INSTS_VALU"):
+        w = c["SQ_WAVES"]
+        e["insts_per_wave"] = {k.replace("SQ_INSTS_", "").lower(): round(c[k] / w, 1) for k in sorted(c) if k.startswith("SQ_INSTS_")}
     res["kernels"][k] = e
 json.dump(res, open(out, "w"), indent=1)
 for k, e in res["kernels"].items():
