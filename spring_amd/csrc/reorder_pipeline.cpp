@@ -1181,8 +1181,26 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.maxshift = ctx->L / 2;  // reorder.h:750
   memset(P.plan, 0, sizeof(P.plan));
   if (o.first_shifts < 0) { P.plan[0][0] = 4; P.plan[0][1] = 4; P.plan[0][2] = 8; P.plan[0][3] = 8; }  // progressive (experiment)
-  else { P.plan[0][0] = o.first_shifts > 0 ? std::min(16, o.first_shifts) : 8; P.plan[0][1] = 16; }   // one narrow batch, one wide
+  else if (o.first_shifts > 0) { P.plan[0][0] = std::min(16, o.first_shifts); P.plan[0][1] = 16; }
+  else if (o.fused >= 0 && o.fused != 2 && !o.collect_stats && !o.force_literal_update) {
+    // four chains per wavefront keep more searches in flight: a narrower first batch (fewer wasted fetches past the
+    // winner) is worth its extra dependent step there (417 vs 426 ms at 100 M x 150 bp; 8 + 16 stays for k_round)
+    P.plan[0][0] = 4; P.plan[0][1] = 8; P.plan[0][2] = 16;
+  } else { P.plan[0][0] = 8; P.plan[0][1] = 16; }   // one narrow batch, one wide
   P.plan[1][0] = 16; P.plan[1][1] = 16;
+  for (int w = 0; w < 2; w++) {  // A/B runs of the tools: SPRING_REORDER_PLAN0 / _PLAN1 = "4,4,8,16" (same results)
+    const char *e = getenv(w ? "SPRING_REORDER_PLAN1" : "SPRING_REORDER_PLAN0");
+    if (!e) continue;
+    int k = 0, sum = 0;
+    memset(P.plan[w], 0, sizeof(P.plan[w]));
+    for (const char *q = e; *q && k < 6;) {
+      const int v = atoi(q);
+      if (v <= 0 || v > 16 || sum + v > 32) break;
+      P.plan[w][k++] = v; sum += v;
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+  }
   P.seed_wide = o.seed_wide < 0 ? 0 : 1;
   P.search_wpb = (o.search_wpb == 1 || o.search_wpb == 2 || o.search_wpb == 4) ? o.search_wpb : 1;  // 1: a block is a chain; its slot frees when that chain is done
   P.dbg_search_lds = std::max(0, o.dbg_search_lds);
