@@ -120,6 +120,37 @@ def compression_cost(spring_amd, a, dev):
                     "BSC; reads per chain %d (default) vs %d (K = num_thr = %d)" % (n // max(d["chains"], 1), n // max(r["chains"], 1), a.num_thr)}
 
 
+def headline_line(a, world, el, st, G):
+    """The contract's JSON line for the lanes / single-GPU run: `el` = max-over-ranks seconds of the a.steps timed steps,
+    `st` = the statistics of the last step, every rank processed a.reads reads per step."""
+    n, L = a.reads, a.readlen
+    return {
+        "metric": "Mreads/s through reorder stage", "value": round(n * a.steps * world / el / 1e6, 3), "unit": "Mreads/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": "%d x %d bp single-end synthetic reads per GPU (uniform genome %d bp, %dx coverage, "
+                        "%.1f%% substitutions, 50%% reverse-complemented), inputs resident in HBM as .dna records"
+                        % (n, L, G, a.coverage, a.err_ppm / 1e4),
+            "reads_per_gpu": n, "read_len": L, "chains": int(st.get("chains", 0)) or (a.chains or "auto"), "num_thr": a.num_thr,
+            "parallelism": "1 process per GPU, independent lanes" if world > 1 else "single GPU",
+            "stage_ms": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},
+            "unmatched": st["unmatched"], "singletons": st["n_single"], "rounds": st["rounds"],
+        },
+    }
+
+
+def roofline_block(alg_bytes, kernel_ms, launches, traffic):
+    """`roofline` of the bench line from the algorithmic bytes of all launches, their summed duration (HIP events) and
+    the PMC traffic per launch (or None)."""
+    launches = max(int(launches), 1)
+    ach = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "launches": launches, "avg_launch_us": round(kernel_ms * 1e3 / launches, 2),
+            "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1)}
+
+
 def kernels_sha():
     """Identity of the kernels a PMC summary belongs to (profiles/pmc_latest.json carries the same stamp)."""
     import hashlib
@@ -290,23 +321,7 @@ def main():
         return st
 
     el, st = lanes.timed_steps(one_pass, a.steps, a.warmup)
-    total_reads = n * a.steps * world
-    value = total_reads / el / 1e6
-
-    out = {
-        "metric": "Mreads/s through reorder stage", "value": round(value, 3), "unit": "Mreads/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {
-            "workload": "%d x %d bp single-end synthetic reads per GPU (uniform genome %d bp, %dx coverage, "
-                        "%.1f%% substitutions, 50%% reverse-complemented), inputs resident in HBM as .dna records"
-                        % (n, L, G, a.coverage, a.err_ppm / 1e4),
-            "reads_per_gpu": n, "read_len": L, "chains": a.chains or "auto", "num_thr": a.num_thr,
-            "parallelism": "1 process per GPU, independent lanes" if world > 1 else "single GPU",
-            "stage_ms": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},
-            "unmatched": st["unmatched"], "singletons": st["n_single"], "rounds": st["rounds"],
-        },
-    }
+    out = headline_line(a, world, el, st, G)
 
     if rank == 0 and world == 1 and not a.no_roofline:
         # three extra passes: (1) the production round kernel (k_round = apply of the last proposals + search, 85 % of
@@ -347,12 +362,10 @@ def main():
                        "frac": round(rate / RANDOM_REQ_PEAK_G, 3)}
         except Exception:
             req = None
-        out["roofline"] = {
-            "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_kernels_sha": kernels_sha(),
+        out["roofline"] = roofline_block(alg, ms, launches, traffic)
+        out["roofline"].update({
+            "traffic_kernels_sha": kernels_sha(),
             "kernel": "sr::k_round_mc (four chains per wavefront: apply of the last proposal + Hamming search)",
-            "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
-            "algorithmic_bytes_per_launch": round(alg / launches, 1),
             "algorithmic_bytes_per_read": round(alg / n, 1),
             "algorithmic_bytes_model": "SURVEY 8(d): P*16 + Kv*(4+B) + C*(7+B) [search] + R*12 + E*16 [claims, emission]; "
                                        "the chain state the kernel also moves (counts, consensus) is not counted",
@@ -363,7 +376,7 @@ def main():
             "valu_issue_frac": ks.get("valu_issue_frac") if traffic is not None else None,
             "insts_per_wavefront": ks.get("insts_per_wave") if traffic is not None else None,
             "hbm_write_bytes_per_launch": round(ks["write_bytes_per_launch"], 1) if traffic is not None else None,
-        }
+        })
         ms2, l2 = st_2k["ms_search_kernel"], max(st_2k["search_launches"], 1)
         if ms2 > 0:
             a2 = alg_search / (ms2 * 1e-3) / 1e9

@@ -80,24 +80,29 @@ def test_wrong_bitset_size_raises_like_reference():
         spring_amd.call_reorder("/tmp", CompressionParams(600, [0, 0]))
 
 
-def test_committed_bench_line_keeps_the_contract():
-    """The bench line committed under profiles/ (what `python bench.py` printed on the MI355X box) carries every field
-    of the bench contract, and its derived figures are consistent with each other."""
-    import json
-    b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_100Mx150.json")))
+def test_bench_line_builders_keep_the_contract():
+    """bench.py builds its JSON line with headline_line() / roofline_block(): every field of the bench contract is
+    there and the derived figures follow from the inputs."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = types.SimpleNamespace(reads=100_000_000, readlen=150, steps=3, warmup=1, coverage=25, err_ppm=10000, chains=0, num_thr=8)
+    st = dict(ms_unpack=5.0, ms_dict=26.0, ms_chains=400.0, ms_finalize=4.0, unmatched=13958771, n_single=12719866,
+              rounds=1968, chains=65536)
+    line = bench.headline_line(a, 1, 1.35, st, 600_000_000)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in b, k
-    assert b["n_gpus"] == 1 and b["higher_is_better"] is True and b["vs_baseline"] is None and "workload" in b["config"]
-    n = b["config"]["reads"] if "reads" in b["config"] else 100_000_000
-    assert abs(b["value"] - n / (b["ms_per_step"] / 1e3) / 1e6) / b["value"] < 0.01
-    r = b["roofline"]
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 3 * 100.0 / 1.35) < 0.01 and abs(line["ms_per_step"] - 450.0) < 1e-6
+    assert bench.headline_line(a, 4, 1.35, st, 600_000_000)["value"] == pytest.approx(4 * line["value"], rel=1e-4)
+    r = bench.roofline_block(164.25e9, 428.0, 1968, 427e6)
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - 164.25e9 / 0.428 / 1e9) < 0.01
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 0.01
-    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"]
-    c = b["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    assert 0 < r["frac"] < 1 and r["traffic"] > r["algorithmic_bytes_per_launch"]
