@@ -59,10 +59,12 @@ for k, c in kern.items():
     e["l2_hit_rate"] = c.get("TCC_HIT_sum", 0) / hm if hm else None
     e["wait_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
     # share of the launch during which a SIMD's vector ALU is issuing: SQ_ACTIVE_INST_VALU counts quad-cycles summed over
-    # the waves; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE = shader clocks of the dispatches
+    # the waves; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE = busy clocks summed over the 8 XCDs (4.3 M per 217 us launch in
+    # round 2's data = 8 x 217 us x 2.5 GHz)
     if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
-        e["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]), 4)
-        e["salu_issue_frac"] = round(c.get("SQ_ACTIVE_INST_SCA", 0) * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]), 4)
+        clocks = c["GRBM_GUI_ACTIVE"] / 8.0
+        e["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * clocks), 4)
+        e["salu_issue_frac"] = round(c.get("SQ_ACTIVE_INST_SCA", 0) * 4.0 / (1024.0 * clocks), 4)
     if c.get("SQ_WAVES") and c.get("SQ_INSTS_VALU"):
         w = c["SQ_WAVES"]
         e["insts_per_wave"] = {k.replace("SQ_INSTS_", "").lower(): round(c[k] / w, 1) for k in sorted(c) if k.startswith("SQ_INSTS_")}
