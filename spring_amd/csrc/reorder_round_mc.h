@@ -616,7 +616,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES,
   __shared__ mc::GLds s_g[mc::CPW];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
   const int lane = threadIdx.x, g = lane >> 4, gl = lane & (mc::G - 1);
-  // this wavefront's chains: four entries of one class of one list segment (classes in the order 0, 1, 2, 3)
+  // this wavefront's chains: four entries of one class of one list segment (classes in the order 0, 1, 2, 3).
+  // Tried and dropped (profiles/r03_experiments.txt): one global class-major list of wavefront-loads built by an extra
+  // one-block kernel (longest classes dispatched first: 419 vs 417 ms, nothing), with empty placeholder blocks instead
+  // of the list (each empty block costs ~1.3 ns of dispatch: 547 ms), and resident wavefronts looping over the list
+  // (the loop costs the body 30 VGPRs, an occupancy step: 487-710 ms).
   uint32_t li;
   {
     const uint32_t seg = P.c0 / MARK_BLOCK + blockIdx.x / MC_WAVES_PER_BLOCK, b = blockIdx.x % MC_WAVES_PER_BLOCK;
