@@ -1,5 +1,7 @@
 #!/bin/bash
 # tools/pmc_caches.sh <outdir> <reads> -- instruction / scalar-data cache behaviour and issue cycles of the chain kernels
+set -u
+: "${1:?usage: see the header comment}"
 out=$1; n=${2:-20000000}; export TMPDIR=/tmp; mkdir -p $out
 run() { name=$1; shift
   timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -o pmc -- python tools/scale_probe.py $n,150,0 > $out/$name.log 2>&1

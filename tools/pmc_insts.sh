@@ -1,5 +1,7 @@
 #!/bin/bash
 # tools/pmc_insts.sh <outdir> <reads> [lib.so] -- dynamic instruction mix of the chain kernels (one rocprofv3 --pmc pass each)
+set -u
+: "${1:?usage: see the header comment}"
 out=$1; n=${2:-100000000}; export TMPDIR=/tmp; mkdir -p $out
 [ -n "$3" ] && export SPRING_AMD_LIB=$3
 run() { name=$1; shift

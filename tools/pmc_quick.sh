@@ -1,5 +1,7 @@
 #!/bin/bash
 # tools/pmc_quick.sh <outdir> <reads>: one PMC pass (TCC read requests + L2 hits) over scale_probe
+set -u
+: "${1:?usage: see the header comment}"
 out=$1; n=${2:-20000000}; export TMPDIR=/tmp; mkdir -p $out
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/tcc -o pmc -- python tools/scale_probe.py $n,150,65536 > $out/tcc.log 2>&1
 python - <<PY

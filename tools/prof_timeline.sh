@@ -1,5 +1,8 @@
 #!/bin/bash
 # tools/prof_timeline.sh <outdir> [scale_probe args] -- per-launch durations of the chain-phase kernels over a run (every 32nd round)
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
+: "${1:?usage: see the header comment}"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=$1; shift; mkdir -p $O
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -o p -- python tools/scale_probe.py ${@:-100000000,150,0} > $O/run.log 2>&1

@@ -1,6 +1,8 @@
 #!/bin/bash
 # tools/r2_evidence.sh -- the large one-off checks whose logs are committed under profiles/ (run through gpurun):
 # oracle parity at 10 M and 50 M reads, BASELINE config 5's pool size on ONE GPU, real-BSC sizes vs chain count.
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2_evidence; mkdir -p $O
 python tools/parity_10M.py 10000000 > $O/parity_10M.log 2>&1

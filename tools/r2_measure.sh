@@ -1,6 +1,8 @@
 #!/bin/bash
 # tools/r2_measure.sh -- the round's measurement set on one MI355X box (run through gpurun): GPU test suite, the
 # default bench line, the same command under rocprofv3 --kernel-trace --stats, and the PMC passes.
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2_measure; mkdir -p $O

@@ -1,4 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
+: "${1:?usage: see the header comment}"
 cd $GRAFT_REPO_ROOT
 ./tools/whb 8 4 65536 > gpurun_out/r2_whb.log 2>&1
 ./tools/whb 8 4 131072 >> gpurun_out/r2_whb.log 2>&1

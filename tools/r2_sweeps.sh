@@ -1,6 +1,8 @@
 #!/bin/bash
 # tools/r2_sweeps.sh -- side measurements of the round (run through gpurun): coverage sweep at 20 M reads, chain-count
 # sweep at 100 M, instruction mix of the chain kernels (two rocprofv3 --pmc passes), phase clocks of a debug build.
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2_sweeps; mkdir -p $O
