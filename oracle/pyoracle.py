@@ -49,6 +49,8 @@ def lib():
                                          C.POINTER(OrcOut), C.POINTER(OrcStats)]
         L.orc_reorder_rounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                          C.POINTER(OrcOut), C.POINTER(OrcStats)]
+        L.orc_reorder_rounds_alt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p]
         L.orc_reorder_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
                                       C.POINTER(OrcOut), C.POINTER(OrcStats)]
         L.orc_write_dna_stream.restype = C.c_size_t
@@ -170,15 +172,16 @@ def reorder_serial(read, ln, L):
     return _finish(o, arrs, st)
 
 
-def reorder_rounds(read, ln, L, num_chains, num_thr=1):
-    """Deterministic K-chain lock-step schedule (the spec the GPU path follows)."""
+def reorder_rounds(read, ln, L, num_chains, num_thr=1, alternatives=1):
+    """Deterministic K-chain lock-step schedule (the spec the GPU path follows); alternatives = candidates per match
+    proposal, resolved in as many passes (1 = a loser waits for the next round)."""
     n = len(ln)
     read = np.ascontiguousarray(read, dtype=np.uint64)
     ln = np.ascontiguousarray(ln, dtype=np.uint16)
     o, arrs = _alloc_out(n, num_thr)
     st = OrcStats()
-    rc = lib().orc_reorder_rounds(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr,
-                                  C.byref(o), C.byref(st))
+    rc = lib().orc_reorder_rounds_alt(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr, alternatives,
+                                      C.byref(o), C.byref(st))
     assert rc == 0
     return _finish(o, arrs, st)
 

@@ -647,7 +647,16 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
  *     holds resv wins and applies it; a loser retries the same iteration in
  *     the next round (in the reference a thread that loses the read_lock race
  *     keeps scanning, reorder.h:303-311; both are legal `-t K` interleavings).
- *   K = 1 degenerates to the reference's `-t 1` order exactly.
+ *   Alternatives (A > 1, orc_reorder_rounds_alt): the search also records the next A-1
+ *     candidates of the winning probe's bin that pass the Hamming test (same scan, same
+ *     1000-live-entry window -- exactly the reads the reference's thread would try next
+ *     after losing the read_lock race, reorder.h:303-311).  The proposals are resolved in
+ *     A passes: in pass p every chain that has not secured a read yet and has a p-th
+ *     candidate proposes it; a read secured in an earlier pass stays with its owner; inside
+ *     a pass the lowest chain id wins.  A chain that secures its p-th candidate applies
+ *     that read (same probe, same alignment); a chain that secures nothing retries next
+ *     round.  Seed proposals have one candidate.  A = 1 is the schedule above.
+ *   K = 1 degenerates to the reference's `-t 1` order exactly (no other chain to lose to).
  */
 
 enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
@@ -660,6 +669,8 @@ typedef struct {
   uint32_t num_reads_thr, num_unmatched_past_1M_thr, unmatched;
   int prop_kind, prop_shift, prop_rev;
   uint32_t prop_rid;
+  uint32_t alt[8]; /* further passing candidates of the winning bin, in scan order */
+  int nalt;
   outbuf_t ob;
 } chain_t;
 
@@ -673,8 +684,11 @@ typedef struct {
   orc_stats *st;
 } rctx_t;
 
-/* one full search of a chain against the round-start taken[] */
-static int rounds_search(rctx_t *x, const cons_t *c, uint32_t *k, int *oshift, int *orev) {
+/* one full search of a chain against the round-start taken[]; alt / nalt (may be null / 0 wanted): the next passing
+ * candidates of the winner's bin within the same MAX_SEARCH_REORDER window (not counted in the work counters) */
+static int rounds_search(rctx_t *x, const cons_t *c, uint32_t *k, int *oshift, int *orev, uint32_t *alt, int want_alt,
+                         int *nalt) {
+  if (nalt) *nalt = 0;
   uint64_t ref[ORC_WMAX], revref[ORC_WMAX];
   const int W = x->W;
   memcpy(ref, c->ref, sizeof(uint64_t) * W);
@@ -708,6 +722,14 @@ static int rounds_search(rctx_t *x, const cons_t *c, uint32_t *k, int *oshift, i
           if (hamming_range(r, x->read + (size_t)rid * W, W, lo, m) <= THRESH_REORDER) {
             x->st->hits++;
             *k = rid; *oshift = shift; *orev = rev;
+            for (i--; want_alt > 0 && *nalt < want_alt && i >= (int64_t)d->startpos[b] && live < MAX_SEARCH_REORDER; i--) {
+              const uint32_t r2 = d->read_id[i];
+              if (x->taken[r2]) continue;
+              live++;
+              int m2 = rev ? c->ref_len + shift : c->ref_len - shift;
+              if ((int)x->len[r2] < m2) m2 = x->len[r2];
+              if (hamming_range(r, x->read + (size_t)r2 * W, W, lo, m2) <= THRESH_REORDER) alt[(*nalt)++] = r2;
+            }
             return 1;
           }
         }
@@ -721,7 +743,12 @@ static int rounds_search(rctx_t *x, const cons_t *c, uint32_t *k, int *oshift, i
 
 int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
                        int num_thr, orc_out *out, orc_stats *st) {
-  if (K == 0 || num_thr <= 0) return -1;
+  return orc_reorder_rounds_alt(read, len, n, L, K, num_thr, 1, out, st);
+}
+
+int orc_reorder_rounds_alt(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
+                           int num_thr, int A, orc_out *out, orc_stats *st) {
+  if (K == 0 || num_thr <= 0 || A < 1 || A > 8) return -1;
   rctx_t x;
   memset(&x, 0, sizeof(x));
   memset(st, 0, sizeof(*st));
@@ -792,23 +819,47 @@ int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, in
         }
         c->num_reads_thr++;
       }
+      c->nalt = 0;
       if (!c->stop_searching) {
         uint32_t k; int sh, rv;
-        if (rounds_search(&x, &c->c, &k, &sh, &rv)) {
+        if (rounds_search(&x, &c->c, &k, &sh, &rv, c->alt, A - 1, &c->nalt)) {
           c->prop_kind = PROP_MATCH; c->prop_rid = k; c->prop_shift = sh; c->prop_rev = rv;
         }
       }
     }
-    for (uint32_t i = 0; i < K; i++)
-      if (!ch[i].done && ch[i].prop_kind != PROP_NONE && resv[ch[i].prop_rid] > i) resv[ch[i].prop_rid] = i;
+    /* resolution in A passes; resv[rid] = pass << 28 | chain of the owner (an earlier pass beats a later one, inside
+     * a pass the lowest chain id wins); secured[i] = 1 + index of the candidate chain i got */
+    for (int p = 0; p < A; p++) {
+      for (uint32_t i = 0; i < K; i++) {
+        chain_t *c = &ch[i];
+        if (c->done || c->prop_kind == PROP_NONE) continue;
+        int got = 0;
+        for (int q = 0; q < p && !got; q++) {
+          if (q > c->nalt) break;
+          const uint32_t rq = q ? c->alt[q - 1] : c->prop_rid;
+          got = resv[rq] == (((uint32_t)q << 28) | i);
+        }
+        if (got || p > c->nalt || (p > 0 && c->prop_kind != PROP_MATCH)) continue;
+        const uint32_t rp = p ? c->alt[p - 1] : c->prop_rid, key = ((uint32_t)p << 28) | i;
+        if (resv[rp] > key) resv[rp] = key;
+      }
+    }
     /* ---- phase B: resolve + apply */
     for (uint32_t i = 0; i < K; i++) {
       chain_t *c = &ch[i];
       if (c->done) continue;
-      if (c->prop_kind != PROP_NONE && resv[c->prop_rid] != i) { /* lost the read */
-        st->lost++;
-        if (c->mode == MODE_SEARCH) c->retrying = 1;
-        continue;
+      if (c->prop_kind != PROP_NONE) {
+        int got = -1;
+        for (int q = 0; q <= c->nalt && got < 0; q++) {
+          const uint32_t rq = q ? c->alt[q - 1] : c->prop_rid;
+          if (resv[rq] == (((uint32_t)q << 28) | i)) got = q;
+        }
+        if (got < 0) { /* lost every candidate */
+          st->lost++;
+          if (c->mode == MODE_SEARCH) c->retrying = 1;
+          continue;
+        }
+        if (got > 0) c->prop_rid = c->alt[got - 1]; /* same probe, same alignment, the next read of the bin */
       }
       if (c->prop_kind == PROP_MATCH) {
         const int shift = c->prop_shift;

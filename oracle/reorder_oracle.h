@@ -77,6 +77,9 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
 
 int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
                        uint32_t num_chains, int num_thr, orc_out *out, orc_stats *st);
+/* the same schedule with A candidates per match proposal resolved in A passes (A = 1: orc_reorder_rounds) */
+int orc_reorder_rounds_alt(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
+                       uint32_t num_chains, int num_thr, int alternatives, orc_out *out, orc_stats *st);
 
 /* CPU-baseline port: T free-running OpenMP threads like the reference's `-t T`; NOT deterministic
  * for T > 1 (like the reference).  Outputs laid out per thread (tid_off has T+1 entries). */

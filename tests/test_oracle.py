@@ -143,3 +143,27 @@ def test_openmp_port_invariants(name, T):
         a = po.reorder_serial(read, ln, L)
         for k in KEYS:
             assert np.array_equal(a[k], r[k]), (name, k)
+
+
+def test_alternatives_schedule_specification():
+    """orc_reorder_rounds_alt: A candidates per match proposal resolved in A passes (the costed remedy for contended
+    pools).  A = 1 is the schedule the GPU runs; for any A, K = 1 equals the serial order, the
+    output keeps every invariant, and lost proposals and rounds go down as A goes up."""
+    n, L = 20_000, 100
+    dna = rs.pack_fixed(rs.np_reads(3, n * L // 400, n, L, 0.01))
+    read, ln = po.load_dna(dna, n, L)
+    ser = po.reorder_serial(read, ln, L)
+    base = po.reorder_rounds(read, ln, L, 256, 3)
+    prev = None
+    for A in (1, 2, 4):
+        one = po.reorder_rounds(read, ln, L, 1, 1, A)
+        for k in KEYS:
+            assert np.array_equal(one[k], ser[k]), (A, k)
+        r = po.reorder_rounds(read, ln, L, 256, 3, A)
+        check_invariants(r, read, ln, L, n)
+        if A == 1:
+            for k in KEYS:
+                assert np.array_equal(r[k], base[k]), k
+        else:
+            assert r["stats"]["lost"] < prev["stats"]["lost"] and r["stats"]["rounds"] <= prev["stats"]["rounds"]
+        prev = r
