@@ -409,6 +409,15 @@ def test_parity_10M_reads():
     assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
     for k in ("probes", "keyok", "cands", "hits", "unmatched", "iterations", "lost"):
         assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
+    # the production build (no counters: four chains per wavefront) on the same reads
+    del got
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T)) as st:
+        st.load_synth(n, L, n * L // 25, 3, 10000)
+        got = st.run().streams()
+    _same(got, want, "10M-production")
+    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+    for k in ("unmatched", "lost"):
+        assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
 
 
 def test_1M_150bp_k1_reference_counters_on_the_gpu():
