@@ -15,7 +15,8 @@ constexpr uint32_t DEEP_BIN = 16;   // bins with at least this many reads are ta
 constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
 constexpr uint32_t MARK_BLOCK = 256; // chains per block of k_mg_mark = per class-list segment (k_round_mc)
 constexpr uint32_t MC_WAVES_PER_BLOCK = MARK_BLOCK / 4 + 3;  // wavefronts of four chains a segment can need (each class rounded up)
-constexpr int UBLK_SHIFT = 14;      // DevParams::ublk counts untaken reads per 2^14 reads (256 bitmap words)
+constexpr int UBLK_SHIFT = 12;      // DevParams::ublk counts untaken reads per 2^12 reads (64 bitmap words = 512 bytes: what a
+                                    // seed pick reads of the cursor's block; 2^14 cost four times the L1 requests per pick)
 constexpr int LDS_PAD = 10;         // zero limbs either side of ref/revref in LDS
 constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
 

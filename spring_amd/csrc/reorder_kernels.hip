@@ -750,43 +750,44 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   // At most two dependent steps per 1 M reads, whatever the rank and however few reads are left.  P.ublk[b] = reads of
   // block b (reads [b << UBLK_SHIFT, (b + 1) << UBLK_SHIFT)) not yet claimed by a MATCH (kept by whoever sets such a
   // taken bit).  Seeds are always taken from the top and every read above the cursor is taken, so below the cursor's
-  // block ublk[] is the exact number of untaken reads; the cursor's own block is counted from its 256 bitmap words
-  // (four per lane, highest first), which are fetched together with the counts of the 63 blocks below it.
+  // block ublk[] is the exact number of untaken reads; the cursor's own block is counted from its bitmap words
+  // (WPL per lane, highest first), which are fetched together with the counts of the 63 blocks below it.
   if (top < 0) return -1;
   const long long bt = top >> UBLK_SHIFT;
   constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // bitmap words per block
+  constexpr int WPL = WPB_ / 64;               // ... per lane
+  static_assert(WPL >= 1 && WPL * 64 == WPB_, "a block is a whole number of bitmap words per lane");
   auto pick_in_block = [&](long long blk, const uint64_t *uu, int cnt, uint32_t want) -> long long {
     const long long wtop = blk * WPB_ + (WPB_ - 1);
     const int inc2 = wave_incl_scan_i(cnt, lane);
     const uint64_t m = __ballot((uint32_t)inc2 >= want);
     const int wl = __ffsll((unsigned long long)m) - 1;
-    int kth = (int)want - __shfl(inc2 - cnt, wl, 64);  // kth highest untaken read of lane wl's four words
+    int kth = (int)want - __shfl(inc2 - cnt, wl, 64);  // kth highest untaken read of lane wl's words
     long long seed = -1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < WPL; k++) {
       uint64_t v = shfl_u64(uu[k], wl);
       const int c = __popcll(v);
       if (seed < 0) {
         if (kth <= c) {
           for (int t = 1; t < kth; t++) v &= ~(1ull << (63 - __clzll(v)));
-          seed = (wtop - 4 * wl - k) * 64 + (63 - __clzll(v));
+          seed = (wtop - WPL * wl - k) * 64 + (63 - __clzll(v));
         } else kth -= c;
       }
     }
     return seed;
   };
   auto load_block = [&](long long blk, uint64_t *uu) -> int {
-    const long long wl0 = blk * WPB_ + (WPB_ - 1) - 4 * lane;
+    const long long wl0 = blk * WPB_ + (WPB_ - 1) - WPL * lane;
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < WPL; k++) {
       uu[k] = ~P.taken[wl0 - k];  // (the bitmap is padded to whole blocks; bits >= n are set)
       cnt += __popcll(uu[k]);
     }
     return cnt;
   };
-  static_assert(WPB_ == 256, "four bitmap words per lane");
-  uint64_t uu[4];
+  uint64_t uu[WPL];
   {
     const long long b = bt - 1 - lane;
     int u = b >= 0 ? (int)P.ublk[b] : 0;  // (in flight together with the cursor block's words)

@@ -1237,7 +1237,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   ctx->K = K;
   DevParams &P = ctx->P;
   fill_params(ctx, P);
-  // the bitmap is padded to whole blocks of 2^UBLK_SHIFT reads (find_seed reads a block's 256 words; bits >= n are set)
+  // the bitmap is padded to whole blocks of 2^UBLK_SHIFT reads (find_seed reads a block's words; bits >= n are set)
   const uint64_t nublk = std::max<uint64_t>(((uint64_t)n + (1u << UBLK_SHIFT) - 1) >> UBLK_SHIFT, 1);
   const uint64_t nwords = nublk << (UBLK_SHIFT - 6);
   const size_t nn = std::max<uint32_t>(n, 1);

@@ -331,20 +331,22 @@ __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t c
   *is_last = rank + 1 == nneedy;
   uint32_t need = rank + 1;
   if (top < 0) return -1;
-  constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // 256 bitmap words per block, 16 per lane
+  constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // bitmap words per block
+  constexpr int WPG = WPB_ / G;                // ... per lane of the group
+  static_assert(WPG >= 1 && WPG * G == WPB_ && WPG <= G, "a block is 1..16 bitmap words per lane");
   // the need-th highest untaken read of block blk (it holds at least that many)
   auto pick = [&](long long blk, uint32_t want) -> long long {
     const long long wtop = blk * WPB_ + (WPB_ - 1);
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) cnt += __popcll(~P.taken[wtop - 16 * gl - k]);
+    for (int k = 0; k < WPG; k++) cnt += __popcll(~P.taken[wtop - WPG * gl - k]);
     const int inc = gincl_scan_i(cnt, gl);
     const uint32_t m = gballot((uint32_t)inc >= want, (int)threadIdx.x);
     const int wl = __ffs((int)m) - 1;
     const uint32_t want2 = want - (uint32_t)__shfl(inc - cnt, wl, G);
-    // lane wl's sixteen words, one per lane
-    const long long wbase = wtop - 16 * wl;
-    const uint64_t u = ~P.taken[wbase - gl];
+    // lane wl's words, one per lane
+    const long long wbase = wtop - WPG * wl;
+    const uint64_t u = gl < WPG ? ~P.taken[wbase - gl] : 0ull;
     const int c1 = __popcll(u);
     const int inc1 = gincl_scan_i(c1, gl);
     const uint32_t m1 = gballot((uint32_t)inc1 >= want2, (int)threadIdx.x);
@@ -359,7 +361,7 @@ __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t c
     const long long wtop = bt * WPB_ + (WPB_ - 1);
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) cnt += __popcll(~P.taken[wtop - 16 * gl - k]);
+    for (int k = 0; k < WPG; k++) cnt += __popcll(~P.taken[wtop - WPG * gl - k]);
     const uint32_t tot0 = (uint32_t)gsum_i(cnt);
     if (tot0 >= need) return pick(bt, need);
     need -= tot0;
