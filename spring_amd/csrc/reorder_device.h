@@ -164,6 +164,7 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal);
 void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg);
 void launch_mg_resolve(hipStream_t st, const DevParams &P);
 void launch_mg_mark(hipStream_t st, const DevParams &P);
+void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot /* [7] */);
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s);
 void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz);

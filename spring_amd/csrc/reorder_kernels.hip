@@ -1714,6 +1714,23 @@ __global__ void k_init_ord(DevParams P) {
   if (threadIdx.x == 0) P.ord_cnt[blockIdx.x] = make_uint4(0u, 0u, s_n, 0u);
 }
 
+// per chain: {records emitted, singletons}; totals of the per-chain counters (finalize reads 8 bytes per chain
+// instead of the 384-byte chain records)
+__global__ void k_chain_summary(DevParams P, uint2 *__restrict__ sum, unsigned long long *__restrict__ tot /* [7] */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (i < P.K) {
+    const Chain &c = P.chains[i];
+    sum[i] = make_uint2(c.h.n_emit, c.h.n_single);
+    v[0] = c.n_unmatched; v[1] = c.st_probes; v[2] = c.st_keyok; v[3] = c.st_cands; v[4] = c.st_iter; v[5] = c.st_lost; v[6] = c.st_hits;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const uint64_t w = wave_sum_u64(v[k]);
+    if ((threadIdx.x & 63) == 0 && w) atomicAdd(&tot[k], (unsigned long long)w);
+  }
+}
+
 // ------------------------------------------------------------ K7 finalize / emit
 // slot i of the append buffers belongs to chunk i / CHUNK; its record is number first_seq + i % CHUNK of the owning chain
 __global__ void k_scatter_matched(DevParams P, uint64_t cap, const uint64_t *__restrict__ off_m) {
@@ -1929,6 +1946,9 @@ void launch_mg_resolve(hipStream_t st, const DevParams &P) {
 }
 void launch_mg_mark(hipStream_t st, const DevParams &P) {
   hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
+}
+void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot) {
+  if (P.K) hipLaunchKernelGGL(k_chain_summary, GRID1(P.K, 256), dim3(256), 0, st, P, sum, tot);
 }
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s) {

@@ -1658,11 +1658,29 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   const uint32_t K = ctx->K;
   const int T = ctx->o.num_thr;
   HIPCHK(hipEventRecord(ctx->ev[6], st));
-  std::vector<Chain> hc(K);
+  // per chain only {records, singletons} come back (8 bytes instead of the 384-byte chain record), the counters summed
+  // on the device
+  std::vector<uint2> hs(std::max<uint32_t>(K, 1));
+  unsigned long long htot[7] = {0, 0, 0, 0, 0, 0, 0};
   Globals g;
-  HIPCHK(hipMemcpyAsync(hc.data(), P.chains, (size_t)K * sizeof(Chain), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&g, P.glob, sizeof(g), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  {
+    uint2 *d_sum = nullptr;
+    unsigned long long *d_tot = nullptr;
+    DMALLOC(d_sum, (size_t)std::max<uint32_t>(K, 1) * sizeof(uint2));
+    DMALLOC(d_tot, 64);
+    HIPCHK(hipMemsetAsync(d_tot, 0, 56, st));
+    launch_chain_summary(st, P, d_sum, d_tot);
+    HIPCHK(hipGetLastError());
+    if (K) HIPCHK(hipMemcpyAsync(hs.data(), d_sum, (size_t)K * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(htot, d_tot, 56, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&g, P.glob, sizeof(g), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->dfree(d_sum); ctx->dfree(d_tot);
+  }
+#ifdef SR_PHASE_TIMING
+  std::vector<Chain> hc(K);
+  if (K) HIPCHK(hipMemcpy(hc.data(), P.chains, (size_t)K * sizeof(Chain), hipMemcpyDeviceToHost));
+#endif
   // chain i -> tid i % num_thr, chains ascending inside a tid (each per-tid file is a
   // sequence of whole contigs, which is all the encoder needs: encoder.h:215-363)
   std::vector<uint64_t> off_m(K), off_s(K);
@@ -1674,18 +1692,16 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   for (int t = 0; t < T; t++) {
     ctx->tid_off[t] = am;
     ctx->tid_off_s[t] = as;
-    for (uint32_t i = 0; i < K; i++) {
-      if ((P.c0 + i) % (uint32_t)T != (uint32_t)t) continue;  // chain id -> tid id % num_thr
+    // chain id -> tid id % num_thr: the first local chain of tid t, then every T-th
+    for (uint32_t i = (uint32_t)(((uint32_t)t + (uint32_t)T - P.c0 % (uint32_t)T) % (uint32_t)T); i < K; i += (uint32_t)T) {
       off_m[i] = am; off_s[i] = as;
-      am += hc[i].h.n_emit; as += hc[i].h.n_single;
+      am += hs[i].x; as += hs[i].y;
     }
   }
   ctx->tid_off[T] = am;
   ctx->tid_off_s[T] = as;
-  for (uint32_t i = 0; i < K; i++) {
-    s.unmatched += hc[i].n_unmatched; s.probes += hc[i].st_probes; s.keyok += hc[i].st_keyok;
-    s.cands += hc[i].st_cands; s.iterations += hc[i].st_iter; s.lost += hc[i].st_lost; s.hits += hc[i].st_hits;
-  }
+  s.unmatched = htot[0]; s.probes = htot[1]; s.keyok = htot[2]; s.cands = htot[3]; s.iterations = htot[4];
+  s.lost = htot[5]; s.hits = htot[6];
 #ifdef SR_PHASE_TIMING  // experiment builds: per-phase shader clocks of k_round (tools/xbuild.sh, XPIPE=1)
   {
     unsigned long long pt[64] = {0};
