@@ -119,6 +119,12 @@ def test_fastq_frontend_gzip_input(members):
         for j in range(2):
             nd, on = s.fastq_N(j)
             assert nd == want_n[j][0] and np.array_equal(on, want_n[j][1])
+    with spring_amd.ReorderStage() as s:  # zero padding after the last member (tape / block padding): ignored, as gzip(1) does
+        s.load_fastq(gz(f1) + b"\0" * 700, f2)
+        assert s.download_dna() == want_dna
+    with spring_amd.ReorderStage() as s:  # anything else after the last member is an error, not silently dropped
+        with pytest.raises(spring_amd.ReorderError, match="gzip error"):
+            s.load_fastq(gz(f1) + b"\0" * 8 + b"garbage", f2)
     with spring_amd.ReorderStage() as s:
         with pytest.raises(spring_amd.ReorderError, match="gzip error"):
             s.load_fastq(gz(f1)[:-20])  # truncated
