@@ -115,6 +115,9 @@ struct DevParams {
   // writes the four class sizes to ord_cnt[block].  No atomics, rewritten every round; done chains are in no list.
   uint32_t *ord;
   uint4 *ord_cnt;
+#ifdef SR_PHASE_TIMING
+  unsigned long long *dbg;  // [0..63] phase clocks / visits summed over the wavefronts that ran > 1M clocks, [64] how many
+#endif
   Globals *glob;
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;

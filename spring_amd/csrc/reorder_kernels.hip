@@ -810,14 +810,16 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   return -1;
 }
 
-// A candidate read is compared STAGE_LIMBS limbs at a time: its dwords go from global memory straight into the
-// wavefront's LDS staging area (global_load_lds: LDS address = uniform base + 4 * lane, one 256-byte row per dword), all
-// in flight together -- one memory round trip per candidate instead of one per limb, and no registers held for the
-// data while it is in flight (the round kernel runs at 64 VGPRs; limbs preloaded into registers spill).
+// A candidate read is compared STAGE_LIMBS limbs at a time: its limbs go from global memory straight into the
+// wavefront's LDS staging area (global_load_lds, 16 bytes per lane and instruction on gfx950), all in flight together --
+// one memory round trip per candidate instead of one per limb, and no registers held for the data while it is in
+// flight (the round kernel runs at 64 VGPRs; limbs preloaded into registers spill).
 constexpr int STAGE_LIMBS = 5;
 constexpr int STAGE_WORDS = 2 * STAGE_LIMBS * 64;  // uint32_t per wavefront
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;  // the staging rows are addressed as LDS (no generic-pointer checks)
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+constexpr int STAGE_ODD = 512;  // dword offset of the odd limb's two rows, behind the two quad rows
 typedef const __attribute__((address_space(1))) void glb_void_t;
 #ifndef SR_ROUND_WAVES
 #define SR_ROUND_WAVES 8  // minimum waves per SIMD the round kernel is compiled for (64 VGPRs)
@@ -843,28 +845,30 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
   const int first = blo >> 6, last = (bhi - 1) >> 6;
   for (int i0 = 0; i0 < W; i0 += STAGE_LIMBS) {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(rdp + i0);
-    // dword d of the chunk -> staging row d: the instruction offset moves the global address by 4 d bytes and the
-    // LDS address with it, so row d's base is given 252 d bytes further (one address register for all ten loads)
-#define STAGE_ROW(D) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (D) * 63), 4, (D) * 4, 0)
-    static_assert(STAGE_LIMBS == 5, "ten rows below");
-    if (W - i0 >= STAGE_LIMBS) {
-      STAGE_ROW(0); STAGE_ROW(1); STAGE_ROW(2); STAGE_ROW(3); STAGE_ROW(4);
-      STAGE_ROW(5); STAGE_ROW(6); STAGE_ROW(7); STAGE_ROW(8); STAGE_ROW(9);
-    } else {
-      const int nd = 2 * (W - i0);
-      STAGE_ROW(0); STAGE_ROW(1);
-      if (nd > 2) { STAGE_ROW(2); STAGE_ROW(3); }
-      if (nd > 4) { STAGE_ROW(4); STAGE_ROW(5); }
-      if (nd > 6) { STAGE_ROW(6); STAGE_ROW(7); }
-    }
-#undef STAGE_ROW
+    // gfx950 loads 16 bytes per lane straight into LDS (global_load_lds_dwordx4: LDS address = uniform base +
+    // 16 * lane): a chunk's first 4 nq dwords go into nq staging rows of 1024 bytes, the odd limb's two dwords into two
+    // 256-byte rows behind them -- four requests per candidate and lane at W = 5 instead of ten (a balanced deep-bin
+    // scan has 64 lanes on 64 different reads: the L1 looks every one of them up per instruction).  The instruction
+    // offset moves the global address and the LDS address together, so a row's base is given less that offset.
+    const int nd = 2 * min(W - i0, STAGE_LIMBS), nq = nd >> 2;
+#define STAGE_QUAD(Q) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (Q) * 252), 16, (Q) * 16, 0)
+#define STAGE_WORD(D, ROW) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + STAGE_ODD + (ROW) * 64 - (D)), 4, (D) * 4, 0)
+    static_assert(STAGE_LIMBS == 5, "two quad rows and the odd limb below");
+    if (nd == 10) { STAGE_QUAD(0); STAGE_QUAD(1); STAGE_WORD(8, 0); STAGE_WORD(9, 1); }
+    else if (nd == 8) { STAGE_QUAD(0); STAGE_QUAD(1); }
+    else if (nd == 6) { STAGE_QUAD(0); STAGE_WORD(4, 0); STAGE_WORD(5, 1); }
+    else if (nd == 4) { STAGE_QUAD(0); }
+    else { STAGE_WORD(0, 0); STAGE_WORD(1, 1); }
+#undef STAGE_QUAD
+#undef STAGE_WORD
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PT(13);
     const int ihi = min(i0 + STAGE_LIMBS - 1, last);
-#pragma nounroll  // LDS reads are cheap; unrolled, their ten result registers would all be live at once
+#pragma nounroll  // unrolled (all LDS reads of a chunk issued first) the kernels spill: 420 -> 569 ms at the headline size
     for (int i = max(i0, first); i <= ihi; i++) {
       const int u = i - i0;
-      const uint64_t xr = (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32);
+      const uint64_t xr = u < 2 * nq ? *(const lds_u64_t *)(stage + (u >> 1) * 256 + lane * 4 + (u & 1) * 2)
+                                     : (uint64_t)stage[STAGE_ODD + lane] | ((uint64_t)stage[STAGE_ODD + 64 + lane] << 32);
       uint64_t y = lds_window(sx, i * 64 + bitshift) ^ xr;
       if (i == first) y &= ~0ull << (blo & 63);
       if (i == last) y &= ~0ull >> (63 - ((bhi - 1) & 63));
@@ -876,6 +880,7 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
       }
     }
   }
+  PT(14);
   if (kdiff) return -1;
   return hd <= THRESH;
 }
@@ -1367,7 +1372,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
   __shared__ uint8_t s_pres[WPB][128];
   __shared__ uint32_t s_best[WPB];
-  __shared__ uint32_t s_stage[WPB][STAGE_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[WPB][STAGE_WORDS];
   const int wave = uni_i32((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: the chain pointer stays in SGPRs)
   const uint32_t li = blockIdx.x * WPB + wave;
   if (li >= P.K) return;
@@ -1615,6 +1620,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   }
   (void)search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
   PT_FLUSH(c);
+#ifdef SR_PHASE_TIMING
+  {
+    const int tot = wave_sum_i(lane < 32 ? (int)g_pt_lds[lane] : 0);
+    if (tot > 1000000) {
+      atomicAdd(&P.dbg[lane], (unsigned long long)g_pt_lds[lane]);
+      if (lane == 0) atomicAdd(&P.dbg[64], 1ull);
+    }
+  }
+#endif
 }
 
 #include "reorder_round_mc.h"

@@ -1279,6 +1279,10 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   } else {
     P.ord = nullptr; P.ord_cnt = nullptr;
   }
+#ifdef SR_PHASE_TIMING
+  DMALLOC(P.dbg, 65 * sizeof(unsigned long long));
+  HIPCHK(hipMemsetAsync(P.dbg, 0, 65 * sizeof(unsigned long long), ctx->st));
+#endif
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   launch_init_taken(st, P.taken, nwords, n, P.ublk);
   launch_fill_u32(st, P.resv, n, 0xffffffffu);
@@ -1714,6 +1718,26 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
       if (pt[32 + k])
         fprintf(stderr, "[phase] %2d: %16llu (%5.1f %%) %12llu %9.0f\n", k, pt[k], 100.0 * (double)pt[k] / (double)std::max(tot, 1ull),
                 pt[32 + k], (double)pt[k] / (double)pt[32 + k]);
+    unsigned long long dbg[65];
+    HIPCHK(hipMemcpy(dbg, P.dbg, sizeof(dbg), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[phase] %llu wavefronts ran > 1M clocks; their buckets (clocks/visits):", dbg[64]);
+    for (int k = 0; k < 32; k++)
+      if (dbg[32 + k]) fprintf(stderr, " %d:%llu/%llu", k, dbg[k], dbg[32 + k]);
+    fprintf(stderr, "\n");
+    // the three chains that spent the most clocks: what a round's slowest wavefronts are doing
+    std::vector<std::pair<unsigned long long, uint32_t>> top;
+    for (uint32_t i = 0; i < K; i++) {
+      unsigned long long t = 0;
+      for (int k = 0; k < 32; k++) t += hc[i].pt[k];
+      top.push_back({t, i});
+    }
+    std::partial_sort(top.begin(), top.begin() + std::min<size_t>(3, top.size()), top.end(), std::greater<>());
+    for (size_t j = 0; j < std::min<size_t>(3, top.size()); j++) {
+      fprintf(stderr, "[phase] chain %u: %llu clocks:", top[j].second, top[j].first);
+      for (int k = 0; k < 32; k++)
+        if (hc[top[j].second].pt[32 + k]) fprintf(stderr, " %d:%u/%u", k, hc[top[j].second].pt[k], hc[top[j].second].pt[32 + k]);
+      fprintf(stderr, "\n");
+    }
   }
 #endif
   // a rank of a multi-GPU pool only holds the records of the chains it owns
