@@ -811,7 +811,7 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
 }
 
 // A candidate read is compared STAGE_LIMBS limbs at a time: its limbs go from global memory straight into the
-// wavefront's LDS staging area (global_load_lds, 16 bytes per lane and instruction on gfx950), all in flight together --
+// wavefront's LDS staging area (global_load_lds; the deep-bin variants 16 bytes per lane and instruction), all in flight together --
 // one memory round trip per candidate instead of one per limb, and no registers held for the data while it is in
 // flight (the round kernel runs at 64 VGPRs; limbs preloaded into registers spill).
 constexpr int STAGE_LIMBS = 5;
@@ -828,6 +828,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
 // (mask[0][..] / mask[shift][..] of reorder.h:291-301); with check_key also the reference's key re-check of
 // a single-read bin (reorder.h:282-285): -1 = the read's window is not `key` (fingerprint collision), else 0 / 1.
+template <bool QUAD>
 __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t *sx, int bitshift, int lo, int mref, int ds,
                                            int klen2, uint32_t r, bool check_key, lds_u32_t *stage, int lane) {
   const int W = P.W;
@@ -845,20 +846,31 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
   const int first = blo >> 6, last = (bhi - 1) >> 6;
   for (int i0 = 0; i0 < W; i0 += STAGE_LIMBS) {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(rdp + i0);
-    // gfx950 loads 16 bytes per lane straight into LDS (global_load_lds_dwordx4: LDS address = uniform base +
-    // 16 * lane): a chunk's first 4 nq dwords go into nq staging rows of 1024 bytes, the odd limb's two dwords into two
-    // 256-byte rows behind them -- four requests per candidate and lane at W = 5 instead of ten (a balanced deep-bin
-    // scan has 64 lanes on 64 different reads: the L1 looks every one of them up per instruction).  The instruction
-    // offset moves the global address and the LDS address together, so a row's base is given less that offset.
-    const int nd = 2 * min(W - i0, STAGE_LIMBS), nq = nd >> 2;
+    // Plain: dword d of the chunk -> staging row d (256 bytes).  The instruction offset moves the global address and
+    // the LDS address together, so a row's base is given less that offset (one address register for all the loads).
+    // QUAD (the deep-bin variants): gfx950 loads 16 bytes per lane straight into LDS (global_load_lds_dwordx4: LDS
+    // address = uniform base + 16 * lane): the chunk's first 4 nq dwords go into nq rows of 1024 bytes, an odd limb's
+    // two dwords into two 256-byte rows behind them -- four requests per candidate and lane at W = 5 instead of ten.
+    // A balanced deep-bin scan has 64 lanes on 64 different reads and the L1 looks every one of them up per
+    // instruction: +3-6 % on deep pools; at the headline size, where one or two lanes compare, it costs 1 % (same box:
+    // 407 / 410 ms), so the other variants keep the dwords.
+    const int nd = 2 * min(W - i0, STAGE_LIMBS), nq = QUAD ? nd >> 2 : 0;
+#define STAGE_ROW(D) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (D) * 63), 4, (D) * 4, 0)
 #define STAGE_QUAD(Q) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + (Q) * 252), 16, (Q) * 16, 0)
 #define STAGE_WORD(D, ROW) __builtin_amdgcn_global_load_lds((glb_void_t *)g, (lds_void_t *)(stage + STAGE_ODD + (ROW) * 64 - (D)), 4, (D) * 4, 0)
-    static_assert(STAGE_LIMBS == 5, "two quad rows and the odd limb below");
-    if (nd == 10) { STAGE_QUAD(0); STAGE_QUAD(1); STAGE_WORD(8, 0); STAGE_WORD(9, 1); }
+    static_assert(STAGE_LIMBS == 5, "ten dword rows / two quad rows and the odd limb below");
+    if (!QUAD) {
+      STAGE_ROW(0); STAGE_ROW(1);
+      if (nd > 2) { STAGE_ROW(2); STAGE_ROW(3); }
+      if (nd > 4) { STAGE_ROW(4); STAGE_ROW(5); }
+      if (nd > 6) { STAGE_ROW(6); STAGE_ROW(7); }
+      if (nd > 8) { STAGE_ROW(8); STAGE_ROW(9); }
+    } else if (nd == 10) { STAGE_QUAD(0); STAGE_QUAD(1); STAGE_WORD(8, 0); STAGE_WORD(9, 1); }
     else if (nd == 8) { STAGE_QUAD(0); STAGE_QUAD(1); }
     else if (nd == 6) { STAGE_QUAD(0); STAGE_WORD(4, 0); STAGE_WORD(5, 1); }
     else if (nd == 4) { STAGE_QUAD(0); }
     else { STAGE_WORD(0, 0); STAGE_WORD(1, 1); }
+#undef STAGE_ROW
 #undef STAGE_QUAD
 #undef STAGE_WORD
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -867,8 +879,9 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
 #pragma nounroll  // unrolled (all LDS reads of a chunk issued first) the kernels spill: 420 -> 569 ms at the headline size
     for (int i = max(i0, first); i <= ihi; i++) {
       const int u = i - i0;
-      const uint64_t xr = u < 2 * nq ? *(const lds_u64_t *)(stage + (u >> 1) * 256 + lane * 4 + (u & 1) * 2)
-                                     : (uint64_t)stage[STAGE_ODD + lane] | ((uint64_t)stage[STAGE_ODD + 64 + lane] << 32);
+      const uint64_t xr = !QUAD      ? (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32)
+                          : u < 2 * nq ? *(const lds_u64_t *)(stage + (u >> 1) * 256 + lane * 4 + (u & 1) * 2)
+                                       : (uint64_t)stage[STAGE_ODD + lane] | ((uint64_t)stage[STAGE_ODD + 64 + lane] << 32);
       uint64_t y = lds_window(sx, i * 64 + bitshift) ^ xr;
       if (i == first) y &= ~0ull << (blo & 63);
       if (i == last) y &= ~0ull >> (63 - ((bhi - 1) & 63));
@@ -908,7 +921,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
   const int lo = rev ? shift : 0;
   const int mref = rev ? ref_len + shift : ref_len - shift;
   auto within_thresh = [&](uint32_t r, bool check_key) -> int {
-    return cmp_candidate(P, sx, bitshift, lo, mref, ds, klen2, r, check_key, stage, lane);
+    return cmp_candidate<TRIM>(P, sx, bitshift, lo, mref, ds, klen2, r, check_key, stage, lane);
   };
   // *s_best (LDS) = lowest priority code that has hit so far in this batch of probes: the lanes run in lock step, so
   // a lane still walking a bin after another lane with a lower code has hit can never be the winner and leaves
@@ -1049,7 +1062,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
         if (!is_taken(P.taken, r)) {
           lv = true;
           const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
-          ps = cmp_candidate(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+          ps = cmp_candidate<true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
                              prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
         }
       }
