@@ -16,3 +16,8 @@ python tools/pmc_aggregate.py $O/pmc 100000000 $O/pmc_100Mx150.json > $O/pmc_agg
 rm -rf $O/pmc
 for mc in 1 0 1 0; do echo "SPRING_REORDER_MC=$mc"; SPRING_REORDER_MC=$mc python tools/scale_probe.py 100000000,150,65536 2>&1 | tail -1; done > $O/ab_round_kernels.txt
 python bench.py --force-pool --pool-reads 100000000 --pool-chains 65536 --steps 2 --no-single > $O/bench_pool_world1.json 2> $O/bench_pool.err
+# the shared 400 M-read pool at world = 1 (what the N > 1 lines of the driver's scaling run are compared with)
+python bench.py --force-pool --steps 2 --no-single > $O/bench_pool400M_world1.json 2>> $O/bench_pool.err
+# throughput vs coverage (each pool twice: the second run is the warm one) and the PhiX-like pool
+for cov in 25 400 1600 6400 25600; do python tools/scale_probe.py 20000000,150,0,10000,x,$cov 20000000,150,0,10000,x,$cov 2>&1 | grep "^n=" | tail -1; done > $O/coverage_sweep.txt
+python tools/deep_bins_probe.py 10000000,150,5400,0 10000000,150,5400,0 2>&1 | grep "^n=" | tail -1 | sed 's/^/PhiX-like: /' >> $O/coverage_sweep.txt
