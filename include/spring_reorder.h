@@ -38,7 +38,9 @@ typedef struct {
   int32_t time_search;  /* 1: bracket every search-kernel launch with HIP events (bench roofline) */
   int32_t force_literal_update; /* 1: consensus update always through the literal lane-0 path (tests) */
   int32_t rounds_per_sync;      /* rounds enqueued between host termination checks; 0 = auto      */
-  int32_t reserved;
+  int32_t long_budget;          /* deep-coverage pools: 64-lane compare passes a wavefront spends on one search before the
+                                   search is handed to a block of 16 wavefronts (k_long); 0 = default (24), -1 = never.
+                                   Same results for every value. */
   /* ---- tuning / experiments (0 = default).  The output does not depend on any of them; each non-default
    * setting is covered by a parity test (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results). */
   int32_t first_shifts;   /* a search probes shifts in ordered batches of k and 16, then all the rest at once: k = 1..16
@@ -79,6 +81,7 @@ typedef struct {
   double ms_exchange, ms_resolve_mark;
   uint64_t chains;         /* K the chain phase ran with (opts.num_chains, or what the default rule chose) */
   uint64_t deep_pool;      /* 1: the dictionary averages >= 1.3 reads per key (the deep-coverage default applies) */
+  uint64_t long_searches;  /* searches a wavefront handed over to a block of 16 (k_long; deep-coverage pools only) */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);

@@ -27,7 +27,7 @@ EXPORTS = [
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_chains", C.c_uint32), ("num_thr", C.c_int32),
                 ("collect_stats", C.c_int32), ("time_search", C.c_int32), ("force_literal_update", C.c_int32),
-                ("rounds_per_sync", C.c_int32), ("reserved", C.c_int32),
+                ("rounds_per_sync", C.c_int32), ("long_budget", C.c_int32),
                 ("first_shifts", C.c_int32), ("seed_wide", C.c_int32), ("tab_scale", C.c_int32),
                 ("search_wpb", C.c_int32), ("dbg_search_lds", C.c_int32), ("dbg_apply_lds", C.c_int32),
                 ("fused", C.c_int32), ("deep_bins", C.c_int32),
@@ -61,7 +61,7 @@ class Stats(C.Structure):
                                              "ms_search_kernel")]
                 + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64),
                    ("ms_exchange", C.c_double), ("ms_resolve_mark", C.c_double), ("chains", C.c_uint64),
-                   ("deep_pool", C.c_uint64)])
+                   ("deep_pool", C.c_uint64), ("long_searches", C.c_uint64)])
 
     def asdict(self):
         d = {}

@@ -10,7 +10,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspring_reorder_hip.so")
 SOURCES = ["reorder_kernels.hip", "reorder_pipeline.cpp", "reorder_files.cpp", "order_ops.hip", "fastq_kernels.hip",
            "encoder.hip", "fastq_reorder.hip"]
-HEADERS = ["reorder_device.h", "reorder_internal.h", "synth_common.h", "call_reorder.h"]
+HEADERS = ["reorder_device.h", "reorder_internal.h", "reorder_round_mc.h", "synth_common.h", "call_reorder.h"]
 
 
 def _stale():

@@ -61,7 +61,7 @@ struct __attribute__((aligned(64))) Chain {
   ChainHot h;
   uint64_t ref[16];      // consensus, 2 bits/base (reorder.h:371)
   uint64_t revref[16];   // its reverse complement
-  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost, st_hits, n_unmatched, st_pad;
+  uint64_t st_probes, st_keyok, st_cands, st_iter, st_lost, st_hits, n_unmatched, st_long /* searches finished by k_long */;
 #ifdef SR_PHASE_TIMING  // experiment builds (tools/xbuild.sh): shader clocks per phase of k_round, [32 + k] = visits
   uint64_t pt[64];
 #endif
@@ -115,6 +115,11 @@ struct DevParams {
   // writes the four class sizes to ord_cnt[block].  No atomics, rewritten every round; done chains are in no list.
   uint32_t *ord;
   uint4 *ord_cnt;
+  // long searches (deep-bin pools, k_long): [0] = searches k_round handed over this round, [1 + i] = their local chain
+  // indices; k_mg_mark zeroes the count.  long_budget: 64-lane compare passes (balanced scan) / bin entries walked by
+  // one lane (tail) a wavefront of k_round spends on a search before it hands it over; 0 = never.
+  uint32_t *longq;
+  int long_budget, long_blocks;
 #ifdef SR_PHASE_TIMING
   unsigned long long *dbg;  // [0..63] phase clocks / visits summed over the wavefronts that ran > 1M clocks, [64] how many
 #endif
@@ -167,7 +172,7 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal);
 void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg);
 void launch_mg_resolve(hipStream_t st, const DevParams &P);
 void launch_mg_mark(hipStream_t st, const DevParams &P);
-void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot /* [7] */);
+void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot /* [8] */);
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s);
 void launch_rec_size(hipStream_t st, const uint32_t *order, const uint16_t *lens, uint64_t cnt, uint32_t *sz);

@@ -908,7 +908,7 @@ template <bool TRIM, bool DEFER = false>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
                                            bool &keyok, uint32_t &ncand, bool &other, lds_u32_t *s_best, lds_u32_t *stage,
-                                           int lane, PendBin *pend = nullptr) {
+                                           int lane, PendBin *pend = nullptr, int walk_lim = -1) {
   // (l differs between lanes: P.x[l] would be a vector load from the kernel-argument buffer -- select instead)
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   const int klen2 = 2 * P.wl;
@@ -950,6 +950,13 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     int live = 0, top_live = -1;
     for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
       if (j != (int)count - 1 && beaten()) { gave_up = true; break; }
+      // (long searches, see k_long: a lane that has walked walk_lim entries of one bin calls the search off for the whole
+      // wavefront -- code 0 beats every probe of the tail, the only caller that passes a limit)
+      if (walk_lim >= 0 && (int)count - 1 - j >= walk_lim) {
+        __hip_atomic_fetch_min(s_best, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        gave_up = true;
+        break;
+      }
       const uint32_t r = single ? pay : ids[start + j];
       if (is_taken(P.taken, r)) continue;
       if (TRIM && top_live < 0) top_live = j;
@@ -995,7 +1002,8 @@ struct BatchOut {
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                             int sh_base, int nsh, int lane, int ref_len, uint8_t *pres, lds_u32_t *s_best,
-                                            lds_u32_t *stage, int min_code, uint8_t *owner_of /* [64], LDS */, BatchOut &out) {
+                                            lds_u32_t *stage, int min_code, uint8_t *owner_of /* [64], LDS */, BatchOut &out,
+                                            int *budget = nullptr /* wave-uniform: passes of the balanced scan left */) {
   const int l = lane & 1, rev = (lane >> 1) & 1;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
@@ -1033,6 +1041,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
     const int klen2 = 2 * P.wl;
     typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
     while (pm) {
+      if (budget && --(*budget) < 0) break;  // a long search: k_long finishes it (the caller tests the budget)
       const bool own = (pm >> lane) & 1ull;
       const int rem = own ? jn + 1 : 0;
       const int incl = wave_incl_scan_i(rem > 64 ? 64 : rem, lane);  // (64 is all a chunk can take from one bin)
@@ -1130,7 +1139,8 @@ constexpr int TAIL_CAP = 576;  // 2 * (32 + MAX_READ_LEN / 2) windows at most
 template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
-                                           int ref_len, lds_u32_t *s_best, lds_u32_t *stage, int min_code, BatchOut &out) {
+                                           int ref_len, lds_u32_t *s_best, lds_u32_t *stage, int min_code, BatchOut &out,
+                                           int walk_lim = -1 /* >= 0: bin entries a lane may walk per probe (long searches) */) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
@@ -1196,7 +1206,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
         if ((base || k) && *(volatile lds_u32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
-        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane);
+        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane, nullptr, walk_lim);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
         if (TRIM && !hit && ncand >= (uint32_t)MAX_SEARCH) capmin = min(capmin, probe_code(sh, rev, l));
         if (hit) {
@@ -1325,23 +1335,46 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   o.found = 0;
   uint64_t st_p = 0, st_k = 0, st_c = 0;
   int t0 = 0;
+  // Long searches (deep-bin pools, fused rounds): a failing search over full bins compares hundreds of candidates
+  // one 64-lane pass after the other and a round waits for the few dozen wavefronts that do (45 % of a PhiX-like
+  // run).  A wavefront that has spent P.long_budget passes of the balanced scan, or walked that many entries of one
+  // lane's bins in the tail, stops, queues its chain and leaves: k_long, launched behind this kernel, runs the whole
+  // search again with a block of 16 wavefronts.  The search is a pure function of (consensus, taken[]), so who
+  // computes it does not show in the result.
+  constexpr bool LONG = TRIM && !STATS && WORD;
+  const bool lng = LONG && P.long_budget > 0;
+  int budget = lng ? P.long_budget : 0x7fffffff;
+  bool handed_over = false;
   PT(6);
 #pragma nounroll
   for (int ph = 0; ph < 6 && plan[ph] > 0 && t0 < P.maxshift; ph++) {
     probe_batch<STATS, TRIM>(P, sref, srev, t0, plan[ph], lane, ref_len, s_pres, s_best, s_stage, min_code,
-                             reinterpret_cast<uint8_t *>(s_list), o);
+                             reinterpret_cast<uint8_t *>(s_list), o, LONG ? &budget : nullptr);
+    if (LONG && __builtin_amdgcn_readfirstlane(budget) < 0) { handed_over = true; break; }
     capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     t0 += plan[ph];
     if (ph == 0) PT(7); else PT(8);
     if (o.found) break;
   }
-  if (!o.found && t0 < P.maxshift) {
+  if (!handed_over && !o.found && t0 < P.maxshift) {
     wave_sync();  // s_pres
-    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, min_code, o);
+    probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, min_code, o,
+                            (lng && t0 > 0) ? P.long_budget : -1);
+    if (lng && t0 > 0) {
+      wave_sync();
+      handed_over = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32_t *)s_best) == 0;
+    }
     capped = capped || o.capped;
     st_p += o.st_p; st_k += o.st_k; st_c += o.st_c;
     PT(9);
+  }
+  if (LONG && handed_over) {
+    // the iteration bookkeeping above stays; the proposal fields still hold the last proposal (k_long derives the
+    // resume point from them exactly as this search did) and k_long writes the new one
+    store_hot(c, h, lane, 2, 4);
+    if (lane == 0) P.longq[1 + atomicAdd(&P.longq[0], 1u)] = cid - P.c0;
+    return -4;
   }
   {
     const bool found = __builtin_amdgcn_readfirstlane((int)o.found) != 0;
@@ -1644,6 +1677,182 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #endif
 }
 
+// ------------------------------------------------------------ long searches: one block of 16 wavefronts per chain
+// k_round hands a search over (search_step) when it turns out long: on deep-bin pools a chain whose consensus carries
+// five or more errors fails its search only after comparing every live read of every bin it probes, as the reference
+// does (reorder.h:262-316), and one wavefront doing that is what the whole round waits for.  Here the same search --
+// same probes, same priority order, same MAX_SEARCH_REORDER rule, hence the same winner -- is spread over a block:
+//   1. one thread per probe (code = shift << 2 | rev << 1 | dict, the reference's order): bucket fetch, single-read
+//      bins compared at once, verified multi-read bins collected in code order;
+//   2. the collected bins are cut into chunks of 64 entries (bin tail first); a step gives the next 16 chunks in
+//      priority order to the 16 wavefronts, thread 0 then folds the 16 results in that order: the first passing
+//      entry whose bin has fewer than MAX_SEARCH_REORDER live entries ahead of it wins, a bin that reaches the limit
+//      is left for the next one.  The scan stops at the first winner, so nothing behind it is compared.
+// Dead bin tails are not trimmed here (k_round's scans and k_trim_bins do that).
+constexpr int LONG_WAVES = 16;
+struct LongRes { uint32_t live, first, before, rid; };  // live entries of the chunk; first passing entry (64: none), live ones ahead of it, its read
+__global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direct) {
+  __shared__ uint64_t s_refs[2][LDS_LIMBS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[LONG_WAVES][STAGE_WORDS];
+  __shared__ uint32_t s_bstart[64 * LONG_WAVES], s_bcount[64 * LONG_WAVES];
+  __shared__ uint16_t s_bcode[64 * LONG_WAVES];
+  __shared__ uint32_t s_wcnt[LONG_WAVES];
+  __shared__ uint32_t s_best, s_bestrid, s_ctl, s_win_code, s_win_rid, s_capped;
+  __shared__ LongRes s_res[LONG_WAVES];
+  __shared__ uint32_t s_asg_bin[LONG_WAVES], s_asg_q[LONG_WAVES];
+  const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
+  const uint32_t npend = P.longq[0];
+  const int klen2 = 2 * P.wl;
+  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
+  lds_u32_t *stage = (lds_u32_t *)s_stage[wave];
+  const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
+  for (uint32_t qi = blockIdx.x; qi < npend; qi += gridDim.x) {
+    const uint32_t li = P.longq[1 + qi];
+    const uint32_t cid = P.c0 + li;
+    Chain *c = &P.chains[li];
+    if (tid < LDS_LIMBS) {
+      const int i = tid - LDS_PAD;
+      uint64_t r0 = 0, r1 = 0;
+      if (i >= 0 && i < P.W) { r0 = c->ref[i]; r1 = c->revref[i]; }
+      s_refs[0][tid] = r0; s_refs[1][tid] = r1;
+    }
+    ChainHot h;
+    load_hot(c, h);
+    if (tid == 0) { s_best = 0x7fffffffu; s_bestrid = 0; s_win_code = 0x7fffffffu; s_win_rid = 0; s_capped = 0; }
+    __syncthreads();
+    const int ref_len = h.ref_len;
+    int min_code = 0;
+    if (h.retrying) {  // as search_step: a repeated search resumes at the last winner's probe
+      const int pr = (int)h.prop_rev;
+      if (pr & 4) min_code = ((int)h.prop_shift << 2) | ((pr & 1) << 1) | ((pr >> 1) & 1);
+    }
+    // ---- 1. one thread per probe
+    const int code = tid, l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
+    const bool valid = probe_valid(P, l, rev, shift, ref_len) && code >= min_code;
+    bool hit = false, keyok = false, other = false;
+    uint32_t rid = 0, ncand = 0;
+    PendBin pend;
+    pend.on = false; pend.start = pend.count = pend.pay = 0;
+    if (valid) {
+      const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+      const uint64_t *sx = rev ? srev : sref;
+      const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
+      eval_probe<true, true>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, (lds_u32_t *)&s_best, stage, lane, &pend);
+    }
+    __syncthreads();
+    if (hit && s_best == (uint32_t)code) s_bestrid = rid;  // (eval_probe left the lowest hitting code in s_best)
+    const bool mine = pend.on && pend.count > 0;
+    const uint64_t pb = __ballot(mine);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(pb);
+    __syncthreads();
+    const uint32_t best_single = s_best;
+    uint32_t nb = 0;
+    {
+      uint32_t base = 0;
+      for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; nb += v; }
+      if (mine) {
+        const uint32_t at = base + (uint32_t)__popcll(pb & ((1ull << lane) - 1));
+        s_bstart[at] = pend.start; s_bcount[at] = pend.count; s_bcode[at] = (uint16_t)code;
+      }
+    }
+    // ---- 2. the bins, 16 chunks per step
+    uint32_t nx_bin = 0, nx_q = 0, cur = 0xffffffffu, cur_live = 0;  // thread 0: next chunk; bin whose live count is cur_live
+    bool cur_skip = false, have_res = false, done = false;
+    uint32_t n_asg = 0;
+    for (;;) {
+      __syncthreads();  // s_b* / s_res written
+      if (tid == 0) {
+        if (have_res) {
+          for (uint32_t w = 0; w < n_asg && !done; w++) {
+            const uint32_t b = s_asg_bin[w];
+            if (b != cur) { cur = b; cur_live = 0; cur_skip = false; }
+            if (cur_skip) continue;
+            const LongRes r = s_res[w];
+            if (r.first < 64) {
+              if (cur_live + r.before < (uint32_t)MAX_SEARCH) { s_win_code = s_bcode[b]; s_win_rid = r.rid; done = true; }
+              else { s_capped = 1; cur_skip = true; }
+            } else {
+              cur_live += r.live;
+              if (cur_live >= (uint32_t)MAX_SEARCH) { s_capped = 1; cur_skip = true; }
+            }
+          }
+          if (cur_skip && nx_bin == cur) { nx_bin = cur + 1; nx_q = 0; }  // the rest of a bin that reached the limit
+        }
+        n_asg = 0;
+        if (!done) {
+          while (n_asg < (uint32_t)LONG_WAVES && nx_bin < nb) {
+            if ((uint32_t)s_bcode[nx_bin] > best_single) { nx_bin = nb; break; }  // behind a single-read bin that hit
+            if ((uint64_t)nx_q * 64 >= s_bcount[nx_bin]) { nx_bin++; nx_q = 0; continue; }
+            s_asg_bin[n_asg] = nx_bin; s_asg_q[n_asg] = nx_q;
+            n_asg++; nx_q++;
+          }
+        }
+        have_res = true;
+        s_ctl = n_asg;
+      }
+      __syncthreads();
+      const uint32_t na = s_ctl;
+      if (na == 0) break;
+      if ((uint32_t)wave < na) {
+        const uint32_t b = s_asg_bin[wave], q = s_asg_q[wave];
+        const int pcode = (int)s_bcode[b];
+        const int pl = pcode & 1, prev = (pcode >> 1) & 1, psh = pcode >> 2;
+        const uint32_t cnt = s_bcount[b], st0 = s_bstart[b];
+        const long long j = (long long)cnt - 1 - ((long long)q * 64 + lane);
+        bool lv = false, ps = false;
+        uint32_t r = 0;
+        if (j >= 0) {
+          typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+          g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
+          r = pids[st0 + (uint32_t)j];
+          if (!is_taken(P.taken, r)) {
+            lv = true;
+            const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+            ps = cmp_candidate<true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                     prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
+          }
+        }
+        const uint64_t Lm = __ballot(lv), Pm = __ballot(ps);
+        const int fp = Pm ? __ffsll((unsigned long long)Pm) - 1 : 64;
+        const uint32_t wr = (uint32_t)__shfl((int)r, fp & 63, 64);
+        if (lane == 0) {
+          LongRes o;
+          o.live = (uint32_t)__popcll(Lm); o.first = (uint32_t)fp;
+          o.before = fp < 64 ? (uint32_t)__popcll(Lm & ((1ull << fp) - 1)) : 0u; o.rid = wr;
+          s_res[wave] = o;
+        }
+      }
+    }
+    // ---- the proposal (as the end of search_step)
+    if (wave == 0) {
+      const uint32_t wm = s_win_code, ws = best_single;
+      const bool found = wm != 0x7fffffffu || ws != 0x7fffffffu;
+      const uint32_t wcode = wm < ws ? wm : ws;
+      const uint32_t wrid = wm < ws ? s_win_rid : s_bestrid;
+      const bool cap_u = s_capped != 0;
+      if (found) {
+        h.prop_rid = uni_u32(wrid);
+        h.prop_shift = uni_u32(wcode >> 2);
+        h.prop_rev = uni_u32(((wcode >> 1) & 1) | ((wcode & 1) << 1) | (cap_u ? 0u : 4u));
+        h.prop_kind = PROP_MATCH;
+      } else {
+        h.prop_kind = PROP_NONE;
+      }
+      store_hot(c, h, lane, 2, 4);
+      if (lane == 0) {
+        if (found) {
+          P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid;
+          if (direct) atomicMin(&P.resv[wrid], cid);
+        } else {
+          P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
+        }
+        c->st_long++;  // (the chain is this block's alone)
+      }
+    }
+    __syncthreads();  // the LDS state belongs to the next chain of this block
+  }
+}
+
 #include "reorder_round_mc.h"
 
 // ---------------------------------------------- single-pool multi-GPU: kernels after the exchange
@@ -1702,6 +1911,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   }
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
+  if (cid == 0 && P.longq) P.longq[0] = 0;  // this round's long searches are done (k_long ran before this kernel)
   if (P.ord) {  // class lists of this block's chains (k_round_mc): class 0 first, no atomics
     static_assert(MARK_BLOCK == 256, "k_mg_mark runs 256 chains per block");
     __shared__ uint32_t s_wc[4][4];  // [wave][class]
@@ -1743,16 +1953,16 @@ __global__ void k_init_ord(DevParams P) {
 
 // per chain: {records emitted, singletons}; totals of the per-chain counters (finalize reads 8 bytes per chain
 // instead of the 384-byte chain records)
-__global__ void k_chain_summary(DevParams P, uint2 *__restrict__ sum, unsigned long long *__restrict__ tot /* [7] */) {
+__global__ void k_chain_summary(DevParams P, uint2 *__restrict__ sum, unsigned long long *__restrict__ tot /* [8] */) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (i < P.K) {
     const Chain &c = P.chains[i];
     sum[i] = make_uint2(c.h.n_emit, c.h.n_single);
-    v[0] = c.n_unmatched; v[1] = c.st_probes; v[2] = c.st_keyok; v[3] = c.st_cands; v[4] = c.st_iter; v[5] = c.st_lost; v[6] = c.st_hits;
+    v[0] = c.n_unmatched; v[1] = c.st_probes; v[2] = c.st_keyok; v[3] = c.st_cands; v[4] = c.st_iter; v[5] = c.st_lost; v[6] = c.st_hits; v[7] = c.st_long;
   }
 #pragma unroll
-  for (int k = 0; k < 7; k++) {
+  for (int k = 0; k < 8; k++) {
     const uint64_t w = wave_sum_u64(v[k]);
     if ((threadIdx.x & 63) == 0 && w) atomicAdd(&tot[k], (unsigned long long)w);
   }
@@ -1966,6 +2176,9 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL
+  // the searches that k_round handed over (deep-bin pools): a fixed grid, each block takes queue entries in turn
+  if (P.deep_bins && !stats && P.long_budget > 0 && P.longq)
+    hipLaunchKernelGGL(k_long, dim3(std::min<uint32_t>(P.K, (uint32_t)P.long_blocks)), dim3(64 * LONG_WAVES), 0, st, P, mg ? 0 : 1);
 #endif
 }
 void launch_mg_resolve(hipStream_t st, const DevParams &P) {

@@ -1215,6 +1215,12 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
   P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_is_deep(ctx);
+  // long searches of such pools go from k_round to k_long after this many compare passes (same results for every value)
+  P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : 24);
+  P.long_blocks = 512;
+  if (const char *e = getenv("SPRING_REORDER_LONG")) P.long_budget = std::max(0, atoi(e));  // A/B runs of the tools
+  if (const char *e = getenv("SPRING_REORDER_LONG_BLOCKS")) P.long_blocks = std::max(1, atoi(e));
+  P.longq = nullptr;
 }
 // Default chain count.  ~1000 reads per chain: the compressed size grows with the chain count on ordinary coverage
 // (+7 % from n/1024 to 65 536 chains at 16 M reads).  On deep-coverage pools (the dictionary
@@ -1276,6 +1282,10 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     const size_t nmark = ((size_t)Ktot + MARK_BLOCK - 1) / MARK_BLOCK;  // blocks of k_mg_mark = class-list segments
     DMALLOC(P.ord, nmark * MARK_BLOCK * 4);
     DMALLOC(P.ord_cnt, nmark * sizeof(uint4));
+    if (P.deep_bins && P.long_budget > 0) {  // queue of the searches k_round hands to k_long
+      DMALLOC(P.longq, ((size_t)K + 1) * 4);
+      HIPCHK(hipMemsetAsync(P.longq, 0, 4, st));
+    }
   } else {
     P.ord = nullptr; P.ord_cnt = nullptr;
   }
@@ -1665,18 +1675,18 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   // per chain only {records, singletons} come back (8 bytes instead of the 384-byte chain record), the counters summed
   // on the device
   std::vector<uint2> hs(std::max<uint32_t>(K, 1));
-  unsigned long long htot[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long htot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   Globals g;
   {
     uint2 *d_sum = nullptr;
     unsigned long long *d_tot = nullptr;
     DMALLOC(d_sum, (size_t)std::max<uint32_t>(K, 1) * sizeof(uint2));
     DMALLOC(d_tot, 64);
-    HIPCHK(hipMemsetAsync(d_tot, 0, 56, st));
+    HIPCHK(hipMemsetAsync(d_tot, 0, 64, st));
     launch_chain_summary(st, P, d_sum, d_tot);
     HIPCHK(hipGetLastError());
     if (K) HIPCHK(hipMemcpyAsync(hs.data(), d_sum, (size_t)K * sizeof(uint2), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(htot, d_tot, 56, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(htot, d_tot, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&g, P.glob, sizeof(g), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     ctx->dfree(d_sum); ctx->dfree(d_tot);
@@ -1705,7 +1715,7 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   ctx->tid_off[T] = am;
   ctx->tid_off_s[T] = as;
   s.unmatched = htot[0]; s.probes = htot[1]; s.keyok = htot[2]; s.cands = htot[3]; s.iterations = htot[4];
-  s.lost = htot[5]; s.hits = htot[6];
+  s.lost = htot[5]; s.hits = htot[6]; s.long_searches = htot[7];
 #ifdef SR_PHASE_TIMING  // experiment builds: per-phase shader clocks of k_round (tools/xbuild.sh, XPIPE=1)
   {
     unsigned long long pt[64] = {0};

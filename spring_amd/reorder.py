@@ -38,6 +38,7 @@ class ReorderOpts:
     dbg_apply_lds: int = 0
     fused: int = 0            # -1: the two-kernel round; 2: fused round with one chain per wavefront everywhere
     deep_bins: int = 0        # 1 / -1: force the bin-trimming kernel variant on / off (0 = from the dictionary)
+    long_budget: int = 0      # deep pools: compare passes before a search goes to k_long (0 = default, -1 = never)
     devices: tuple = ()       # call_reorder on several GPUs: one pool over these device ordinals (may repeat: host transport)
     mg_host_transport: bool = False
 
@@ -50,6 +51,7 @@ class ReorderOpts:
         o.first_shifts, o.seed_wide, o.tab_scale = self.first_shifts, self.seed_wide, self.tab_scale
         o.search_wpb, o.dbg_search_lds, o.dbg_apply_lds = self.search_wpb, self.dbg_search_lds, self.dbg_apply_lds
         o.fused, o.deep_bins = self.fused, self.deep_bins
+        o.long_budget = self.long_budget
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d

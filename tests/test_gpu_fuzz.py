@@ -70,6 +70,8 @@ def test_fuzz_gpu_equals_oracle(block):
         # variant forced on, the balanced scan and the resumed searches; and the one-chain-per-wavefront round
         rng = np.random.default_rng(seed + 77)
         kw = dict(deep_bins=int(rng.choice([0, 1, -1])), fused=int(rng.choice([0, 0, 2])))
+        if kw["deep_bins"] == 1:  # searches handed to k_long after 1 / 2 / the default number of compare passes, or never
+            kw["long_budget"] = int(rng.choice([1, 1, 2, 0, -1]))
         got2 = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, **kw))
         for k in KEYS:
             assert np.array_equal(got2[k], want[k]), ("seed", seed, "no-stats", kw, "n", n, "L", L, "K", K, "T", T, k)

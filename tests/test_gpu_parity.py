@@ -360,6 +360,49 @@ def test_resumed_search_with_bins_beyond_max_search(K):
     _same(_gpu("heavy", K, 1, deep_bins=1), po.reorder_rounds(read, ln, L, K, 1), ("heavy", K))
 
 
+@pytest.mark.parametrize("budget", [1, 3, 0])
+@pytest.mark.parametrize("n,L,G,K", [(60_000, 100, 300, 256), (40_000, 150, 2_000, 500), (30_000, 150, 400, 37)])
+def test_long_searches_through_k_long(n, L, G, K, budget):
+    """Deep-bin pools: a search that has used up `long_budget` compare passes in k_round is finished by k_long (one
+    block of 16 wavefronts per chain, same probes / priority order / MAX_SEARCH rule).  budget 1 sends nearly every
+    search over a multi-read bin there, 3 a mixture, 0 is the default (24); the streams equal the rounds oracle and
+    the run with k_long switched off."""
+    sa = _sa()
+    outs = {}
+    for b in (budget, -1):
+        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, deep_bins=1, long_budget=b)) as st:
+            st.load_synth(n, L, G, 23, 10000)
+            outs[b] = st.run().streams()
+            dna = st.download_dna()
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, 2)
+    _same(outs[budget], want, ("k_long", budget))
+    _same(outs[-1], want, "k_long off")
+    assert outs[-1]["stats"]["long_searches"] == 0
+    if budget > 0:  # (the default budget only fires on searches longer than these pools have)
+        assert outs[budget]["stats"]["long_searches"] > (n // 20 if budget == 1 else 0), outs[budget]["stats"]["long_searches"]
+
+
+@pytest.mark.parametrize("K", [16, 300])
+def test_long_searches_with_bins_beyond_max_search(K):
+    """k_long on the set whose bins hold more than MAX_SEARCH_REORDER reads (the live-entry limit is kept per bin across
+    the 64-entry chunks the wavefronts of a block take), also over two virtual ranks (proposal words instead of resv[])."""
+    from spring_amd.pool import VirtualPool
+    dna, n, L = named_set("heavy")
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, 1)
+    got = _gpu("heavy", K, 1, deep_bins=1, long_budget=1)
+    _same(got, want, ("heavy k_long", K))
+    assert got["stats"]["long_searches"] > 0
+    vp = VirtualPool(2, K, 1, deep_bins=1, long_budget=1)
+    try:
+        got2 = vp.run(lambda s: s.load_dna(dna, n, L))
+    finally:
+        vp.close()
+    for k in KEYS:
+        assert np.array_equal(got2[k], want[k]), ("heavy k_long pool", K, k)
+
+
 def test_paired_pool_through_pe_encode():
     """BASELINE config 4 at test size (tools/pe_config4.py runs it at 1 M and 50 M pairs): a paired synthetic pool
     (file-1 reads then their mates, reorder.h:233-242) -> reorder == rounds oracle -> encoder -> pe_encode == the

@@ -9,5 +9,5 @@ for a in sys.argv[1:]:
         s.load_synth(n, L, G, 21, 10000)
         s.run()
         st = s.stats()
-    print("n=%d L=%d G=%d K=%d wall=%.3fs dict=%.1f chains=%.1f ms rounds=%d unmatched=%d single=%d numkeys=%s" % (
-        n, L, G, K, time.perf_counter() - t0, st["ms_dict"], st["ms_chains"], st["rounds"], st["unmatched"], st["n_single"], st["numkeys"]), flush=True)
+    print("n=%d L=%d G=%d K=%d wall=%.3fs dict=%.1f chains=%.1f ms rounds=%d unmatched=%d single=%d long=%d numkeys=%s" % (
+        n, L, G, K, time.perf_counter() - t0, st["ms_dict"], st["ms_chains"], st["rounds"], st["unmatched"], st["n_single"], st["long_searches"], st["numkeys"]), flush=True)

@@ -14,7 +14,7 @@ f = glob.glob(O + "/prof/**/*kernel_trace.csv", recursive=True)[0]
 rows = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:32]
-    if "k_round" in k or "k_seeds" in k or "k_mg_mark" in k or "k_trim" in k:
+    if "k_round" in k or "k_long" in k or "k_seeds" in k or "k_mg_mark" in k or "k_trim" in k:
         rows[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 with open(O + "/timeline.txt", "w") as o:
     for k, v in rows.items():
