@@ -39,7 +39,7 @@ typedef struct {
   int32_t force_literal_update; /* 1: consensus update always through the literal lane-0 path (tests) */
   int32_t rounds_per_sync;      /* rounds enqueued between host termination checks; 0 = auto      */
   int32_t long_budget;          /* deep-coverage pools: 64-lane compare passes a wavefront spends on one search before the
-                                   search is handed to a block of 16 wavefronts (k_long); 0 = default (24), -1 = never.
+                                   search is handed to a block of 16 wavefronts (k_long); 0 = default (8), -1 = never.
                                    Same results for every value. */
   /* ---- tuning / experiments (0 = default).  The output does not depend on any of them; each non-default
    * setting is covered by a parity test (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results). */

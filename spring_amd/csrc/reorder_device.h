@@ -12,6 +12,7 @@ constexpr int MAX_READ_LEN = 511;   // params.h:22
 constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
 constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
 constexpr uint32_t DEEP_BIN = 16;   // bins with at least this many reads are tail-trimmed between rounds
+constexpr uint32_t BIG_BIN = 256;   // reads in bins of at least this size are counted (DictBuild::ndeep[1]): long searches, k_long
 constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
 constexpr uint32_t MARK_BLOCK = 256; // chains per block of k_mg_mark = per class-list segment (k_round_mc)
 constexpr uint32_t MC_WAVES_PER_BLOCK = MARK_BLOCK / 4 + 3;  // wavefronts of four chains a segment can need (each class rounded up)
@@ -118,8 +119,9 @@ struct DevParams {
   // long searches (deep-bin pools, k_long): [0] = searches k_round handed over this round, [1 + i] = their local chain
   // indices; k_mg_mark zeroes the count.  long_budget: 64-lane compare passes (balanced scan) / bin entries walked by
   // one lane (tail) a wavefront of k_round spends on a search before it hands it over; 0 = never.
+  // long_min: bin entries that must still be ahead of the search at that point (else the wavefront carries on).
   uint32_t *longq;
-  int long_budget, long_blocks;
+  int long_budget, long_min, long_blocks;
 #ifdef SR_PHASE_TIMING
   unsigned long long *dbg;  // [0..63] phase clocks / visits summed over the wavefronts that ran > 1M clocks, [64] how many
 #endif
@@ -150,7 +152,7 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
 struct DictBuild {
   const uint32_t *ustart, *ucount, *ids;
   ulonglong2 *urec;
-  uint32_t *deep, *ndeep;
+  uint32_t *deep, *ndeep;   // ndeep[0] bins listed in deep[], ndeep[1] reads in bins of >= BIG_BIN entries
 };
 void launch_tab_insert(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
                        DictBuild d1, uint4 *fpt, int bshift);

@@ -161,6 +161,9 @@ __device__ __forceinline__ uint64_t read_window(const uint64_t *__restrict__ r, 
 // Phase clocks of the round kernel (experiment builds only, -DSR_PHASE_TIMING): PT(k) adds the shader clocks since
 // the last mark to bucket k of the wavefront's LDS table; k_round adds the table to Chain::pt when it ends.
 #ifdef SR_PHASE_TIMING
+#ifndef SR_PT_LONG
+#define SR_PT_LONG 1000000  // clocks: wavefronts that ran longer are summed separately (DevParams::dbg)
+#endif
 __shared__ uint32_t g_pt_lds[66];  // k_round: one wavefront per block.  [k] clocks, [32 + k] visits, [64] last mark
 #define PT(k)                                                                                         \
   do {                                                                                                \
@@ -262,6 +265,7 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ mhash, const uint64_t 
   const uint32_t tag = (fp30_of(h) << 2) | (l << 1) | (single ? 1u : 0u);
   const uint32_t pay = single ? d.ids[st] : u;
   if (cn >= DEEP_BIN) d.deep[atomicAdd(d.ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
+  if (cn >= BIG_BIN) atomicAdd(d.ndeep + 1, cn);
   d.urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
   if (!OVERFLOW) {
     fpt[b0 * 8 + rank] = tag;
@@ -828,7 +832,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
 // (mask[0][..] / mask[shift][..] of reorder.h:291-301); with check_key also the reference's key re-check of
 // a single-read bin (reorder.h:282-285): -1 = the read's window is not `key` (fingerprint collision), else 0 / 1.
-template <bool QUAD>
+template <bool QUAD, bool UNROLL = false>
 __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t *sx, int bitshift, int lo, int mref, int ds,
                                            int klen2, uint32_t r, bool check_key, lds_u32_t *stage, int lane) {
   const int W = P.W;
@@ -876,8 +880,11 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PT(13);
     const int ihi = min(i0 + STAGE_LIMBS - 1, last);
-#pragma nounroll  // unrolled (all LDS reads of a chunk issued first) the kernels spill: 420 -> 569 ms at the headline size
-    for (int i = max(i0, first); i <= ihi; i++) {
+    // unrolled (all LDS reads of a chunk issued first) the round kernels spill: 420 -> 569 ms at the headline size;
+    // k_long has the registers (UNROLL: every limb of the chunk, the ones outside [first, last] masked to nothing)
+#pragma unroll(UNROLL ? STAGE_LIMBS : 1)
+    for (int i = UNROLL ? i0 : max(i0, first); i <= (UNROLL ? min(i0 + STAGE_LIMBS, W) - 1 : ihi); i++) {
+      if (UNROLL && (i < first || i > last)) continue;
       const int u = i - i0;
       const uint64_t xr = !QUAD      ? (uint64_t)stage[(2 * u) * 64 + lane] | ((uint64_t)stage[(2 * u + 1) * 64 + lane] << 32)
                           : u < 2 * nq ? *(const lds_u64_t *)(stage + (u >> 1) * 256 + lane * 4 + (u & 1) * 2)
@@ -908,7 +915,7 @@ template <bool TRIM, bool DEFER = false>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
                                            bool &keyok, uint32_t &ncand, bool &other, lds_u32_t *s_best, lds_u32_t *stage,
-                                           int lane, PendBin *pend = nullptr, int walk_lim = -1) {
+                                           int lane, PendBin *pend = nullptr, int *walk_left = nullptr) {
   // (l differs between lanes: P.x[l] would be a vector load from the kernel-argument buffer -- select instead)
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   const int klen2 = 2 * P.wl;
@@ -950,12 +957,16 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     int live = 0, top_live = -1;
     for (int j = (int)count - 1; j >= 0 && live < MAX_SEARCH; j--) {  // bin tail first, <=1000 live
       if (j != (int)count - 1 && beaten()) { gave_up = true; break; }
-      // (long searches, see k_long: a lane that has walked walk_lim entries of one bin calls the search off for the whole
-      // wavefront -- code 0 beats every probe of the tail, the only caller that passes a limit)
-      if (walk_lim >= 0 && (int)count - 1 - j >= walk_lim) {
-        __hip_atomic_fetch_min(s_best, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        gave_up = true;
-        break;
+      // (long searches, see k_long: a lane that has walked its share of bin entries calls the search off for the whole
+      // wavefront -- code 0 beats every probe of the tail, the only caller that passes a budget)
+      if (walk_left && --(*walk_left) < 0) {
+        // ... if this bin alone still holds a long walk (P.long_min / 64 entries); else the lane finishes the bin
+        if (j >= P.long_min >> 6) {
+          __hip_atomic_fetch_min(s_best, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          gave_up = true;
+          break;
+        }
+        *walk_left = j;
       }
       const uint32_t r = single ? pay : ids[start + j];
       if (is_taken(P.taken, r)) continue;
@@ -1041,7 +1052,13 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
     const int klen2 = 2 * P.wl;
     typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
     while (pm) {
-      if (budget && --(*budget) < 0) break;  // a long search: k_long finishes it (the caller tests the budget)
+      if (budget && --(*budget) < 0) {  // a long search: k_long finishes it (the caller tests the budget) ...
+        // ... unless little is left of this batch's bins: a hand-over adds k_long's own latency (30 us and more) to the
+        // round, which only pays for a search that would outlast the round's other chains by a multiple of that
+        const int left = wave_sum_i(((pm >> lane) & 1ull) ? min(jn + 1, 1 << 20) : 0);
+        if (left >= P.long_min) break;
+        *budget = 16;
+      }
       const bool own = (pm >> lane) & 1ull;
       const int rem = own ? jn + 1 : 0;
       const int incl = wave_incl_scan_i(rem > 64 ? 64 : rem, lane);  // (64 is all a chunk can take from one bin)
@@ -1140,7 +1157,7 @@ template <bool STATS, bool TRIM>
 __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *sref, const uint64_t *srev,
                                            uint16_t *list, uint16_t *stat, int t0, const uint8_t *pres, int lane,
                                            int ref_len, lds_u32_t *s_best, lds_u32_t *stage, int min_code, BatchOut &out,
-                                           int walk_lim = -1 /* >= 0: bin entries a lane may walk per probe (long searches) */) {
+                                           int *walk_left = nullptr /* per lane: bin entries it may still walk (long searches) */) {
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   // did the ordered batches' fetch for shift sp (slot x: 1 = forward dict 1, 2 = reverse dict 0) leave the other
@@ -1206,7 +1223,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
         if ((base || k) && *(volatile lds_u32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
-        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane, nullptr, walk_lim);
+        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane, nullptr, walk_left);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
         if (TRIM && !hit && ncand >= (uint32_t)MAX_SEARCH) capmin = min(capmin, probe_code(sh, rev, l));
         if (hit) {
@@ -1258,7 +1275,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
 // WORD: publish the proposal as a word of P.prop (multi-GPU pools: resolved after the all-gather; fused rounds:
 // read by k_mg_mark).  DIRECT: reserve the read at once (atomicMin on resv[]), everything is on this GPU.
 // `h` is the chain's header as it stands (all lanes hold the same copy); ref / revref are already in s_refs.
-template <bool STATS, bool WORD, bool DIRECT, bool TRIM>
+template <bool STATS, bool WORD, bool DIRECT, bool TRIM, bool LONG = false>
 __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, int lane,
                                             uint64_t *s_refs /* [2][LDS_LIMBS] */, uint16_t *s_list, uint16_t *s_stat,
                                             uint8_t *s_pres /* [128] */, lds_u32_t *s_best, lds_u32_t *s_stage /* [STAGE_WORDS] */) {
@@ -1341,7 +1358,9 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   // lane's bins in the tail, stops, queues its chain and leaves: k_long, launched behind this kernel, runs the whole
   // search again with a block of 16 wavefronts.  The search is a pure function of (consensus, taken[]), so who
   // computes it does not show in the result.
-  constexpr bool LONG = TRIM && !STATS && WORD;
+  // (LONG: its own instantiation of the round kernel -- the budget bookkeeping costs the deep-bin variant 20 bytes of
+  // scratch per lane, 2-4 % on the pools that never hand over)
+  static_assert(!LONG || (TRIM && !STATS && WORD), "long searches: production deep-bin variant of the fused round");
   const bool lng = LONG && P.long_budget > 0;
   int budget = lng ? P.long_budget : 0x7fffffff;
   bool handed_over = false;
@@ -1359,8 +1378,9 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   }
   if (!handed_over && !o.found && t0 < P.maxshift) {
     wave_sync();  // s_pres
+    int walk_left = budget;  // (what the ordered batches left of it)
     probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, min_code, o,
-                            (lng && t0 > 0) ? P.long_budget : -1);
+                            (lng && t0 > 0) ? &walk_left : nullptr);
     if (lng && t0 > 0) {
       wave_sync();
       handed_over = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32_t *)s_best) == 0;
@@ -1624,7 +1644,7 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
 // MG (one pool over several GPUs): a rank runs its own chains only and publishes one word per chain; the lowest-
 // chain-id resolution (k_mg_resolve) runs after the all-gather on every rank, then k_mg_mark.  One GPU: the
 // proposals go straight to resv[] (atomicMin) and the words are only k_mg_mark's input.
-template <int NP, bool STATS, bool MG, bool TRIM>
+template <int NP, bool STATS, bool MG, bool TRIM, bool LONG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_round(DevParams P) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
   __shared__ uint16_t s_list[TAIL_CAP];
@@ -1664,12 +1684,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     PT_FLUSH(c);
     return;
   }
-  (void)search_step<STATS, true, !MG, TRIM>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
+  (void)search_step<STATS, true, !MG, TRIM, LONG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
   PT_FLUSH(c);
 #ifdef SR_PHASE_TIMING
   {
     const int tot = wave_sum_i(lane < 32 ? (int)g_pt_lds[lane] : 0);
-    if (tot > 1000000) {
+    if (tot > SR_PT_LONG) {
       atomicAdd(&P.dbg[lane], (unsigned long long)g_pt_lds[lane]);
       if (lane == 0) atomicAdd(&P.dbg[64], 1ull);
     }
@@ -1805,12 +1825,14 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
           g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
           r = pids[st0 + (uint32_t)j];
-          if (!is_taken(P.taken, r)) {
-            lv = true;
-            const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
-            ps = cmp_candidate<true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
-                                     prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
-          }
+          // (the limbs are fetched while the taken word is on its way: one dependent step less per chunk; the memory
+          // system is idle in the rounds this kernel matters in)
+          const uint64_t tw = P.taken[r >> 6];
+          const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+          const bool pass = cmp_candidate<true, true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                                      prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
+          lv = !((tw >> (r & 63)) & 1ull);
+          ps = lv && pass;
         }
         const uint64_t Lm = __ballot(lv), Pm = __ballot(ps);
         const int fp = Pm ? __ffsll((unsigned long long)Pm) - 1 : 64;
@@ -2173,12 +2195,17 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
            else hipLaunchKernelGGL((k_round<N, false, false, T>), g, b, dyn, st, P); }       \
   } while (0)
 #define RCALL(N) do { if (P.deep_bins) RCALL2(N, true); else RCALL2(N, false); } while (0)
-  if (P.Lpad <= 192) RCALL(3); else RCALL(8);
+  if (P.deep_bins && !stats && P.long_budget > 0 && P.longq) {
+    // pools of very deep bins: the variant that hands long searches over, then k_long for them (a fixed grid, each
+    // block takes queue entries in turn)
+#define LCALL(N) do { if (mg) hipLaunchKernelGGL((k_round<N, false, true, true, true>), g, b, dyn, st, P); \
+                      else hipLaunchKernelGGL((k_round<N, false, false, true, true>), g, b, dyn, st, P); } while (0)
+    if (P.Lpad <= 192) LCALL(3); else LCALL(8);
+#undef LCALL
+    hipLaunchKernelGGL(k_long, dim3(std::min<uint32_t>(P.K, (uint32_t)P.long_blocks)), dim3(64 * LONG_WAVES), 0, st, P, mg ? 0 : 1);
+  } else if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL
-  // the searches that k_round handed over (deep-bin pools): a fixed grid, each block takes queue entries in turn
-  if (P.deep_bins && !stats && P.long_budget > 0 && P.longq)
-    hipLaunchKernelGGL(k_long, dim3(std::min<uint32_t>(P.K, (uint32_t)P.long_blocks)), dim3(64 * LONG_WAVES), 0, st, P, mg ? 0 : 1);
 #endif
 }
 void launch_mg_resolve(hipStream_t st, const DevParams &P) {

@@ -117,6 +117,7 @@ struct DictDev {
   uint32_t *ids = nullptr;
   uint32_t *deep = nullptr, *d_ndeep = nullptr;  // bins with >= DEEP_BIN reads (k_trim_bins)
   uint32_t ndeep = 0;
+  uint32_t big_reads = 0;   // reads in bins of >= BIG_BIN entries (d_ndeep[1]): the pools whose long searches go to k_long
 };
 
 struct spring_reorder_ctx {
@@ -1010,13 +1011,13 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     }
     d.numreads = m;
     d.numkeys = 0;
-    d.ndeep = 0;
+    d.ndeep = 0; d.big_reads = 0;
     if (m == 0) {
       DMALLOC(d.urec, 16);
       DMALLOC(d.ids, 16);
       DMALLOC(d.deep, 16);
       DMALLOC(d.d_ndeep, 16);
-      HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 4, st));
+      HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 8, st));
       if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
       continue;
     }
@@ -1066,7 +1067,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     // deep-bin list: at most one entry per DEEP_BIN reads of the dictionary
     DMALLOC(d.deep, ((size_t)m / DEEP_BIN + 1) * 4);
     DMALLOC(d.d_ndeep, 16);
-    HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 4, st));
+    HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 8, st));
     HIPCHK(hipStreamSynchronize(st));
     ctx->dfree(d_tmp);
     if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
@@ -1115,9 +1116,11 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     }
     launch_tab_insert(st, h_in, v_in, nm, db[0], db[1], ctx->fpt, ctx->bshift);
     HIPCHK(hipGetLastError());
+    uint32_t nd[2][2] = {{0, 0}, {0, 0}};
     for (int l = 0; l < 2; l++)
-      HIPCHK(hipMemcpyAsync(&ctx->dict[l].ndeep, ctx->dict[l].d_ndeep, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(nd[l], ctx->dict[l].d_ndeep, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int l = 0; l < 2; l++) { ctx->dict[l].ndeep = nd[l][0]; ctx->dict[l].big_reads = nd[l][1]; }
     DBG_T("insert");
     ctx->dfree(mv0); ctx->dfree(mv1); ctx->dfree(mh); ctx->dfree(mv); ctx->dfree(d_tmp);
   }
@@ -1216,9 +1219,20 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
   P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_is_deep(ctx);
   // long searches of such pools go from k_round to k_long after this many compare passes (same results for every value)
-  P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : 24);
+  // -- in pools where bins of hundreds of reads are the rule (a quarter of the dictionary's reads in bins of >= BIG_BIN
+  // entries: PhiX-like, tens of thousands x), where a failing search compares thousands of candidates.  Below that a
+  // hand-over does not pay (k_long's own latency is added to the round: 25 600x +-0, 6 400x -4 %), so those pools run
+  // the variant of k_round without it; opts.long_budget > 0 forces it on (tests), -1 off.
+  const uint64_t big = (uint64_t)ctx->dict[0].big_reads + ctx->dict[1].big_reads, nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads;
+  const bool very_deep = P.deep_bins && big * 4 >= nd && nd > 0;
+  P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : (very_deep ? 8 : 0));
   P.long_blocks = 512;
-  if (const char *e = getenv("SPRING_REORDER_LONG")) P.long_budget = std::max(0, atoi(e));  // A/B runs of the tools
+  if (const char *e = getenv("SPRING_REORDER_LONG")) P.long_budget = atoi(e) < 0 ? P.long_budget : atoi(e);  // A/B runs of the tools (-1: the default)
+  // ... and only when at least this many bin entries are still ahead of it (32 compare passes of one wavefront, two
+  // steps of k_long); budgets below 8 hand over unconditionally (tests).  PhiX-like pool, chains stage, same box: off
+  // 300 ms; budget 8 with 2 048 / 4 096 / 8 192 entries 219 / 225 / 228; 24 unconditionally 218; 8 unconditionally 238
+  P.long_min = P.long_budget < 8 ? 0 : 2048;
+  if (const char *e = getenv("SPRING_REORDER_LONG_MIN")) P.long_min = std::max(0, atoi(e));
   if (const char *e = getenv("SPRING_REORDER_LONG_BLOCKS")) P.long_blocks = std::max(1, atoi(e));
   P.longq = nullptr;
 }

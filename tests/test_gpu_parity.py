@@ -365,7 +365,8 @@ def test_resumed_search_with_bins_beyond_max_search(K):
 def test_long_searches_through_k_long(n, L, G, K, budget):
     """Deep-bin pools: a search that has used up `long_budget` compare passes in k_round is finished by k_long (one
     block of 16 wavefronts per chain, same probes / priority order / MAX_SEARCH rule).  budget 1 sends nearly every
-    search over a multi-read bin there, 3 a mixture, 0 is the default (24); the streams equal the rounds oracle and
+    search over a multi-read bin there, 3 a mixture, 0 is the default (8 passes, and only searches with thousands of
+    bin entries still ahead of them); the streams equal the rounds oracle and
     the run with k_long switched off."""
     sa = _sa()
     outs = {}

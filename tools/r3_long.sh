@@ -13,7 +13,8 @@ if [ "${1:-tests}" = "tests" ]; then
   tail -3 $O/fuzz.txt
 fi
 for b in ${BUDGETS:-0 24 8 64}; do
-  echo "SPRING_REORDER_LONG=$b"
+  export SPRING_REORDER_LONG_MIN=${b#*/}; b=${b%/*}; [ "$SPRING_REORDER_LONG_MIN" = "$b" ] && unset SPRING_REORDER_LONG_MIN
+  echo "SPRING_REORDER_LONG=$b SPRING_REORDER_LONG_MIN=${SPRING_REORDER_LONG_MIN:-default}"
   SPRING_REORDER_LONG=$b timeout 300 python tools/deep_bins_probe.py 10000000,150,5400,0 10000000,150,5400,0 2>&1 | grep "^n=" | tail -1 | sed 's/^/PhiX-like: /'
   for cov in ${COVS:-1600 6400 25600}; do SPRING_REORDER_LONG=$b timeout 300 python tools/scale_probe.py 20000000,150,0,10000,x,$cov 20000000,150,0,10000,x,$cov 2>&1 | grep "^n=" | tail -1; done
 done > $O/ab_long.txt 2>&1
