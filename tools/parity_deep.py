@@ -34,6 +34,6 @@ for a in sys.argv[1:]:
     for k in ("probes", "keyok", "cands", "hits", "unmatched"):
         assert outs[1][1][k] == want["stats"][k], (k, outs[1][1][k], want["stats"][k])
     print("n=%d L=%d genome=%d (%.0fx) K=%d: production and counting builds identical to the rounds oracle (%.0f s of oracle); "
-          "rounds %d, lost proposals %d, %.1f candidate comparisons per read, production chains stage %.1f ms"
+          "rounds %d, lost proposals %d, %.1f candidate comparisons per read, %d searches finished by k_long, production chains stage %.1f ms"
           % (n, L, G, n * L / G, K, time.time() - t0, outs[0][1]["rounds"], outs[0][1]["lost"],
-             want["stats"]["cands"] / n, outs[0][1]["ms_chains"]), flush=True)
+             want["stats"]["cands"] / n, outs[0][1]["long_searches"], outs[0][1]["ms_chains"]), flush=True)
