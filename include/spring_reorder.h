@@ -32,7 +32,7 @@ typedef struct {
   int32_t device;       /* HIP device ordinal; -1 = current device                                */
   uint32_t num_chains;  /* K concurrent greedy chains (= reference threads, reorder.h:351);
                            1 reproduces `-t 1` byte for byte; 0 = auto: N/1024, or N/128 when the
-                           dictionary averages >= 1.3 reads per key (deep coverage), at most 65536 */
+                           dictionary averages >= 1.3 reads per key (deep coverage); at most 65536, deep coverage 131072 */
   int32_t num_thr;      /* number of per-tid output sets to emit (cp.num_thr, reorder.h:748)      */
   int32_t collect_stats;/* 1: count reference-equivalent probes / key hits / Hamming evaluations  */
   int32_t time_search;  /* 1: bracket every search-kernel launch with HIP events (bench roofline) */
@@ -137,7 +137,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx);
  * lock-step rounds (search_match reorder.h:246-318, updaterefcount :110-220). */
 int spring_reorder_run_chains(spring_reorder_ctx *ctx);
 /* The chain count run_chains() uses when opts.num_chains = 0 (valid after build_dict): n / 1024, or n / 128 when the
- * dictionary averages >= 1.3 reads per key (*deep = 1), at most 65536.  A multi-GPU caller that wants the pool to equal
+ * dictionary averages >= 1.3 reads per key (*deep = 1), at most 65536 (131072 on deep pools other than the very deepest).  A multi-GPU caller that wants the pool to equal
  * the single-GPU default passes this value (rounded up to a multiple of the world size) to mg_begin / mg_run. */
 int spring_reorder_auto_chains(spring_reorder_ctx *ctx, uint32_t *chains, int32_t *deep);
 

@@ -1177,6 +1177,12 @@ static bool dict_is_deep(const spring_reorder_ctx *ctx) {
   const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
   return nd * 10 >= nk * 13;
 }
+// ... and a quarter of its reads sit in bins of >= BIG_BIN entries: bins of hundreds of reads are the rule (PhiX-like
+// pools, tens of thousands x): long searches go to k_long, and more than 65 536 chains make it slower, not faster
+static bool dict_is_very_deep(const spring_reorder_ctx *ctx) {
+  const uint64_t big = (uint64_t)ctx->dict[0].big_reads + ctx->dict[1].big_reads, nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads;
+  return dict_is_deep(ctx) && nd > 0 && big * 4 >= nd;
+}
 static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   const spring_reorder_opts &o = ctx->o;
   P.reads = ctx->d_reads; P.lens = ctx->d_lens; P.n = ctx->n;
@@ -1223,8 +1229,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // entries: PhiX-like, tens of thousands x), where a failing search compares thousands of candidates.  Below that a
   // hand-over does not pay (k_long's own latency is added to the round: 25 600x +-0, 6 400x -4 %), so those pools run
   // the variant of k_round without it; opts.long_budget > 0 forces it on (tests), -1 off.
-  const uint64_t big = (uint64_t)ctx->dict[0].big_reads + ctx->dict[1].big_reads, nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads;
-  const bool very_deep = P.deep_bins && big * 4 >= nd && nd > 0;
+  const bool very_deep = P.deep_bins && dict_is_very_deep(ctx);
   P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : (very_deep ? 8 : 0));
   P.long_blocks = 512;
   if (const char *e = getenv("SPRING_REORDER_LONG")) P.long_budget = atoi(e) < 0 ? P.long_budget : atoi(e);  // A/B runs of the tools (-1: the default)
@@ -1242,10 +1247,15 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
 // n/1024 give 1.3 % / 2.0 % / 1.2 % SMALLER streams at 400x / 1 600x / 6 400x (real BSC, 20 M reads; flat on a
 // PhiX-like pool; n/128 and n/256 within 0.4 % of each other at 4 M reads) and run 13 % / 9 % faster, 2.6x on the
 // PhiX-like pool -- so those get ~128 reads per chain.
-static uint32_t auto_chains(uint32_t n, bool deep) {
+// Contended deep pools (every proposal fought over by many chains) gain from still more chains: at 20 M reads, 131 072
+// instead of 65 536 chains run 1 600x / 6 400x / 25 600x 5 / 13 / 20 % faster at -1.4 / -0.6 / +0.3 % of the compressed
+// size (profiles/r03_chain_count_deep.txt), so their cap is 131 072; pools of very deep bins stay at 65 536 (the
+// PhiX-like pool takes 220 ms with 65 536 chains, 350 with 131 072).
+static uint32_t auto_chains(uint32_t n, bool deep, bool very_deep) {
   uint64_t k = deep ? n >> 7 : n >> 10;
+  const uint64_t cap = (deep && !very_deep) ? 131072 : 65536;
   if (k < 1) k = 1;
-  if (k > 65536) k = 65536;
+  if (k > cap) k = cap;
   return (uint32_t)k;
 }
 
@@ -1352,7 +1362,7 @@ int spring_reorder_auto_chains(spring_reorder_ctx *ctx, uint32_t *chains, int32_
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage < ST_DICT) return fail(SPRING_REORDER_E_STATE, "auto_chains: build_dict first");
   const bool d = dict_is_deep(ctx);
-  if (chains) *chains = auto_chains(ctx->n, d);
+  if (chains) *chains = auto_chains(ctx->n, d, dict_is_very_deep(ctx));
   if (deep) *deep = d ? 1 : 0;
   return 0;
 }
@@ -1363,7 +1373,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
   const uint32_t n = ctx->n;
-  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n, dict_is_deep(ctx));
+  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n, dict_is_deep(ctx), dict_is_very_deep(ctx));
   const bool stats = ctx->o.collect_stats != 0;
   const bool timed = ctx->o.time_search != 0;
   const bool literal = ctx->o.force_literal_update != 0;
