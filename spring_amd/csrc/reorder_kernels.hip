@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void emit_single(const DevParams &P, ChainHot &h, uin
 // allocator excepted, which only lane 0 uses); lane 0 stores it.  DEFER: the shared state (taken[], needy[],
 // cursor, alive) is updated by k_mg_mark instead (multi-GPU pools, fused rounds).  lds_refs: see pack_consensus.
 // Returns false when the chain has nothing more to do this round (it is, or just became, done).
-template <int NP, bool LITERAL, bool DEFER>
+template <int NP, bool LITERAL, bool DEFER, bool OWNER_FIRST = false>
 __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, int lane,
                                            WaveLds *ws, WaveLdsLiteral *wl, uint64_t *lds_refs) {
   const int kind = h.prop_kind;
@@ -1537,6 +1537,16 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
   int n = P.L, R_new = h.ref_len;
   const int R_old = h.ref_len;
   bool nw = false;
+  // OWNER_FIRST (the deep-bin variants of the fused round: contended pools lose one to two proposals per read): the
+  // answer is waited for before the update is computed -- a loser then costs its header, this word and a store instead
+  // of the count columns read and the speculative ones written (~20 requests); a winner pays one dependent step
+  static_assert(!OWNER_FIRST || DEFER, "OWNER_FIRST: fused rounds only (the cursor is k_mg_mark's)");
+  if (OWNER_FIRST && kind != PROP_NONE && uni_u32(owner_v) != cid) {
+    if (h.mode == MODE_SEARCH) h.retrying = 1;
+    store_hot(c, h, lane);
+    if (lane == 0) atomicAdd((unsigned long long *)&c->st_lost, 1ull);
+    return true;
+  }
   if (do_upd) {
     if (!P.uniform_len) n = uni_i32((int)P.lens[urid]);
     // bytes first; the rare update that would push a count past 255 is redone in the wide format
@@ -1679,7 +1689,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     return;
   }
   PTW(0);
-  if (!apply_step<NP, false, true>(P, c, cid, li, h, lane, &lds, nullptr, &s_refs[0][0])) {
+#ifdef SR_NO_OWNER_FIRST  // experiment builds (tools/xbuild.sh): the A side of the A/B
+  constexpr bool OWNER_FIRST = false;
+#else
+  constexpr bool OWNER_FIRST = TRIM && !STATS;
+#endif
+  if (!apply_step<NP, false, true, OWNER_FIRST>(P, c, cid, li, h, lane, &lds, nullptr, &s_refs[0][0])) {
     if (lane == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     PT_FLUSH(c);
     return;
