@@ -1224,6 +1224,14 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
   P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_is_deep(ctx);
+  // ... and the next read of a chain sits at shift 0 or 1 nearly always, while every verified bin a batch holds past the
+  // winner is scanned for nothing: a narrow first batch (2 + 6 + 8 + 16 shifts instead of 4 + 8 + 16: 1 600x -3 %, 6 400x
+  // -4 %, 25 600x -7 %, PhiX-like -5 %; 1 + 3 + 4 + 8 + 16 the same within 1 %, 1 + 1 + 2 + 4 + 8 + 16 slower at 400x)
+  if (P.deep_bins && o.first_shifts == 0 && o.fused >= 0 && !o.collect_stats && !o.force_literal_update &&
+      !getenv("SPRING_REORDER_PLAN0")) {
+    memset(P.plan[0], 0, sizeof(P.plan[0]));
+    P.plan[0][0] = 2; P.plan[0][1] = 6; P.plan[0][2] = 8; P.plan[0][3] = 16;
+  }
   // long searches of such pools go from k_round to k_long after this many compare passes (same results for every value)
   // -- in pools where bins of hundreds of reads are the rule (a quarter of the dictionary's reads in bins of >= BIG_BIN
   // entries: PhiX-like, tens of thousands x), where a failing search compares thousands of candidates.  Below that a
