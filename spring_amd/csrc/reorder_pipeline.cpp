@@ -1231,6 +1231,12 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
       !getenv("SPRING_REORDER_PLAN0")) {
     memset(P.plan[0], 0, sizeof(P.plan[0]));
     P.plan[0][0] = 2; P.plan[0][1] = 6; P.plan[0][2] = 8; P.plan[0][3] = 16;
+    // (a fresh seed of such a pool finds its first match like any other chain: 4 + 12 + 16 instead of the wide 16 + 16:
+    // PhiX-like -3 %, the 20 M-read pools within 1 %)
+    if (!getenv("SPRING_REORDER_PLAN1")) {
+      memset(P.plan[1], 0, sizeof(P.plan[1]));
+      P.plan[1][0] = 4; P.plan[1][1] = 12; P.plan[1][2] = 16;
+    }
   }
   // long searches of such pools go from k_round to k_long after this many compare passes (same results for every value)
   // -- in pools where bins of hundreds of reads are the rule (a quarter of the dictionary's reads in bins of >= BIG_BIN
