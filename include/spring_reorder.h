@@ -43,8 +43,9 @@ typedef struct {
                                    Same results for every value. */
   /* ---- tuning / experiments (0 = default).  The output does not depend on any of them; each non-default
    * setting is covered by a parity test (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results). */
-  int32_t first_shifts;   /* a search probes shifts in ordered batches of k and 16, then all the rest at once: k = 1..16
-                             (default 8); -1: batches of 4, 4, 8, 8 (fewer wasted requests, more round trips: slower) */
+  int32_t first_shifts;   /* a search probes shifts in ordered batches of k and 16, then all the rest at once: k = 1..16;
+                             0 = default (4 + 8 + 16 with four chains per wavefront, 8 + 16 with one, 2 + 6 + 8 + 16 on
+                             deep-coverage pools); -1: batches of 4, 4, 8, 8 (fewer wasted requests, more round trips: slower) */
   int32_t seed_wide;      /* -1: off; else a chain whose seed is still unmatched probes in batches of 16, 16 */
   int32_t tab_scale;      /* dictionary table size multiplier 1 / 2 / 4 (default 2: load <= 0.2)           */
   int32_t search_wpb;     /* chains (wavefronts) per block of the search kernel: 1 / 2 / 4                 */
