@@ -106,3 +106,24 @@ def test_bench_line_builders_keep_the_contract():
     assert abs(r["achieved"] - 164.25e9 / 0.428 / 1e9) < 0.01
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 0.01
     assert 0 < r["frac"] < 1 and r["traffic"] > r["algorithmic_bytes_per_launch"]
+
+
+def test_ctypes_mirrors_match_the_c_header(tmp_path):
+    """spring_amd/_lib.py mirrors spring_reorder_opts / spring_reorder_stats by hand: sizes and the offsets of the
+    fields added last must equal what a C compiler makes of include/spring_reorder.h."""
+    import ctypes as C
+    import subprocess
+    from spring_amd import _lib
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "spring_reorder.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(spring_reorder_opts), '
+                   'offsetof(spring_reorder_opts, long_budget), offsetof(spring_reorder_opts, mg_host_transport), '
+                   'sizeof(spring_reorder_stats), offsetof(spring_reorder_stats, long_searches), '
+                   'offsetof(spring_reorder_stats, deep_pool)); return 0; }\n')
+    exe = tmp_path / "abi"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(_lib.Opts), _lib.Opts.long_budget.offset, _lib.Opts.mg_host_transport.offset,
+            C.sizeof(_lib.Stats), _lib.Stats.long_searches.offset, _lib.Stats.deep_pool.offset]
+    assert got == want, (got, want)
