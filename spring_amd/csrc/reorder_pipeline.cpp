@@ -1399,6 +1399,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   if (r0) return r0;
   DevParams &P = ctx->P;
   int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : (K >= 256 ? 16 : 256);
+  if (const char *e = getenv("SPRING_REORDER_RPS")) R = std::max(1, atoi(e));  // A/B runs of the tools (same results)
   std::vector<hipEvent_t> tev;
   if (timed) {
     tev.resize(2 * (size_t)R);
