@@ -1177,6 +1177,15 @@ static bool dict_is_deep(const spring_reorder_ctx *ctx) {
   const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
   return nd * 10 >= nk * 13;
 }
+// the kernel variant with the deep-bin machinery (dead tails trimmed while scanning, balanced scan, resumed searches,
+// owner-first apply, narrow first probe batch) pays from ~1.07 reads per key on, well before the chain-count rule
+// above (whose threshold is a matter of compressed size): 20 M reads with 19 531 chains, four-chain kernel against
+// this one: 25x (1.02 reads per key) 107 / 118 ms, 40x (1.04) 109 / 115, 60x (1.05) 116 / 116, 100x (1.09) 130 / 121,
+// 200x (1.18) 159 / 130 (tools/deep_threshold_probe.py)
+static bool dict_wants_deep_kernel(const spring_reorder_ctx *ctx) {
+  const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
+  return nd * 100 >= nk * 107;
+}
 // ... and a quarter of its reads sit in bins of >= BIG_BIN entries: bins of hundreds of reads are the rule (PhiX-like
 // pools, tens of thousands x): long searches go to k_long, and more than 65 536 chains make it slower, not faster
 static bool dict_is_very_deep(const spring_reorder_ctx *ctx) {
@@ -1223,7 +1232,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.fpt = ctx->fpt; P.bshift = ctx->bshift;
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
-  P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_is_deep(ctx);
+  P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_wants_deep_kernel(ctx);
   // ... and the next read of a chain sits at shift 0 or 1 nearly always, while every verified bin a batch holds past the
   // winner is scanned for nothing: a narrow first batch (2 + 6 + 8 + 16 shifts instead of 4 + 8 + 16: 1 600x -3 %, 6 400x
   // -4 %, 25 600x -7 %, PhiX-like -5 %; 1 + 3 + 4 + 8 + 16 the same within 1 %, 1 + 1 + 2 + 4 + 8 + 16 slower at 400x)
