@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--force-pool", action="store_true",
                     help="run the shared-pool path even at N=1 (a 1-rank RCCL communicator): exercises the in-library "
                          "ncclAllGather on a single-GPU box")
+    ap.add_argument("--sweep-sample", type=int, default=20_000_000,
+                    help="reads per pool of the coverage_sweep leg (deep-coverage / contended pools, library defaults; 0 = skip)")
     ap.add_argument("--files-sample", type=int, default=100_000_000,
                     help="reads in the file-contract leg (stage_incl_files): the whole workload by default; 0 = skip")
     return ap.parse_args()
@@ -462,6 +464,38 @@ def main():
                                                    "the %d per-tid file sets + singleton files (%.2f GB)" % (recb / 1e9, a.num_thr, out_bytes / 1e9)}
             except Exception as e:
                 out["stage_incl_files"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_roofline and a.sweep_sample > 0:
+        # Beside the headline, never part of `value`: the stage on pools of other depths with the library's defaults
+        # (chain count, kernel variant, probe plan, k_long all chosen from the dictionary) -- every BASELINE config is
+        # uniform 25x, real read sets are not.  Second, warm run of each pool.
+        try:
+            del buf
+            torch.cuda.empty_cache()
+            sweep = []
+            ns = a.sweep_sample
+            pools = [(ns, c, max(ns * L // c, 4 * L), "%dx" % c) for c in (100, 400, 1600, 6400, 25600)]
+            pools.append((ns // 2, 0, 5400, "PhiX-like (%d reads over 5.4 kb)" % (ns // 2)))
+            for pn, _, pG, name in pools:
+                pb = L_.spring_synth_dna_bytes(pn, L)
+                tb = torch.empty(pb, dtype=torch.uint8, device="cuda")
+                assert L_.spring_synth_dna_device(C.c_void_p(tb.data_ptr()), pn, L, pG, 11, a.err_ppm) == 0
+                torch.cuda.synchronize()
+                for it in range(2):
+                    t0 = time.perf_counter()
+                    s = spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=0, num_thr=a.num_thr))
+                    s.load_dna_device(tb.data_ptr(), pb, pn, L, True)
+                    s.run()
+                    t1 = time.perf_counter() - t0
+                    ps = s.stats()
+                    s.close()
+                sweep.append({"pool": name, "reads": pn, "Mreads_per_s": round(pn / t1 / 1e6, 1), "chains": ps["chains"],
+                              "rounds": ps["rounds"], "lost_proposals": ps["lost"], "searches_by_k_long": ps["long_searches"],
+                              "chains_stage_ms": round(ps["ms_chains"], 1)})
+                del tb
+            out["coverage_sweep"] = {"read_len": L, "err_ppm": a.err_ppm, "pools": sweep,
+                                     "what": "the same stage, library defaults, inputs resident in HBM, whole-stage wall clock"}
+        except Exception as e:  # noqa: BLE001
+            out["coverage_sweep"] = {"error": repr(e)}
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         # CPU baseline on the GPU box's host cores: the C port of the reference algorithm
         # (oracle/reorder_oracle.c).  Multi-thread leg = free-running OpenMP chains like the
