@@ -51,8 +51,10 @@ typedef struct {
   int32_t search_wpb;     /* chains (wavefronts) per block of the search kernel: 1 / 2 / 4                 */
   int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per search block  */
   int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
-  int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (apply + search) + mark; 2: the fused round
-                             always with one chain per wavefront (k_round) instead of four (k_round_mc) where that applies */
+  int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (apply + search) + mark.  0: the mapping
+                             is chosen from the run (four chains per wavefront, k_round_mc, on shallow dictionaries with at
+                             least 49 152 chains; else one chain per wavefront, k_round); 2: always one chain per wavefront;
+                             3: four chains per wavefront wherever that kernel applies, whatever the chain count (tests) */
   int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
   /* ---- spring_reorder_run / spring_reorder_encode_run on several GPUs of one node (one read pool):
    * num_devices >= 2 runs the stage on devices[0 .. num_devices) -- one host thread and one context per entry inside

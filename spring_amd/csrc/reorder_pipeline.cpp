@@ -1178,13 +1178,13 @@ static bool dict_is_deep(const spring_reorder_ctx *ctx) {
   return nd * 10 >= nk * 13;
 }
 // the kernel variant with the deep-bin machinery (dead tails trimmed while scanning, balanced scan, resumed searches,
-// owner-first apply, narrow first probe batch) pays from ~1.07 reads per key on, well before the chain-count rule
-// above (whose threshold is a matter of compressed size): 20 M reads with 19 531 chains, four-chain kernel against
-// this one: 25x (1.02 reads per key) 107 / 118 ms, 40x (1.04) 109 / 115, 60x (1.05) 116 / 116, 100x (1.09) 130 / 121,
-// 200x (1.18) 159 / 130 (tools/deep_threshold_probe.py)
+// owner-first apply) pays from ~1.15 reads per key on, before the chain-count rule above (whose threshold is a matter
+// of compressed size).  tools/variant_probe2.py, chains stage in ms, four chains per wavefront / one chain / one chain
+// with the deep-bin machinery: 100 M reads at 100x (1.09 reads per key) 418 / 423 / 439, at 200x (1.18) 493 / 472 / 471;
+// 20 M reads at 100x 130 / 109 / 113, at 200x 159 / 124 / 125; at 400x and up (>= 1.3) the deep variant wins by 15-40 %
 static bool dict_wants_deep_kernel(const spring_reorder_ctx *ctx) {
   const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
-  return nd * 100 >= nk * 107;
+  return nd * 100 >= nk * 115;
 }
 // ... and a quarter of its reads sit in bins of >= BIG_BIN entries: bins of hundreds of reads are the rule (PhiX-like
 // pools, tens of thousands x): long searches go to k_long, and more than 65 536 chains make it slower, not faster
@@ -1236,7 +1236,12 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // ... and the next read of a chain sits at shift 0 or 1 nearly always, while every verified bin a batch holds past the
   // winner is scanned for nothing: a narrow first batch (2 + 6 + 8 + 16 shifts instead of 4 + 8 + 16: 1 600x -3 %, 6 400x
   // -4 %, 25 600x -7 %, PhiX-like -5 %; 1 + 3 + 4 + 8 + 16 the same within 1 %, 1 + 1 + 2 + 4 + 8 + 16 slower at 400x)
-  if (P.deep_bins && o.first_shifts == 0 && o.fused >= 0 && !o.collect_stats && !o.force_literal_update &&
+  if (P.deep_bins && !dict_is_deep(ctx) && o.first_shifts == 0 && !getenv("SPRING_REORDER_PLAN0")) {
+    // (between the two thresholds bins hold two or three reads: 8 + 16 as for one chain per wavefront elsewhere)
+    memset(P.plan[0], 0, sizeof(P.plan[0]));
+    P.plan[0][0] = 8; P.plan[0][1] = 16;
+  }
+  if (P.deep_bins && dict_is_deep(ctx) && o.first_shifts == 0 && o.fused >= 0 && !o.collect_stats && !o.force_literal_update &&
       !getenv("SPRING_REORDER_PLAN0")) {
     memset(P.plan[0], 0, sizeof(P.plan[0]));
     P.plan[0][0] = 2; P.plan[0][1] = 6; P.plan[0][2] = 8; P.plan[0][3] = 16;
@@ -1313,7 +1318,17 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   P.K = K; P.c0 = c0; P.Ktot = Ktot;
   P.fused = fused ? 1 : 0;
   P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
+  // Four chains per wavefront pay when a launch holds several wavefronts per slot (5 120 slots of four chains): with
+  // fewer chains the GPU is not full and every wavefront waits for the slowest of its four.  25x, chains stage, four
+  // chains / one chain per wavefront: 4 882 chains (5 M reads) 74 / 47 ms, 19 531 (20 M) 106 / 100, 39 062 (40 M)
+  // 184 / 179, 65 536 (70 M) 282 / 293, 65 536 (100 M) 405 / 418 (tools/variant_probe2.py; at 60-100x the one-chain
+  // kernel's lead below 40 000 chains is 5-16 %)
+  if (K < 49152 && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
   if (const char *e = getenv("SPRING_REORDER_MC")) P.mc = atoi(e) != 0;  // A/B runs of the tools (same results)
+  if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !getenv("SPRING_REORDER_PLAN0")) {
+    memset(P.plan[0], 0, sizeof(P.plan[0]));   // (fill_params assumed the four-chain kernel: 4 + 8 + 16)
+    P.plan[0][0] = 8; P.plan[0][1] = 16;
+  }
   P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
   ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
   if (fused) {  // the rounds whose shared state k_mg_mark keeps: proposal words + double-buffered counters

@@ -36,7 +36,7 @@ class ReorderOpts:
     search_wpb: int = 0
     dbg_search_lds: int = 0
     dbg_apply_lds: int = 0
-    fused: int = 0            # -1: the two-kernel round; 2: fused round with one chain per wavefront everywhere
+    fused: int = 0            # -1: the two-kernel round; 2: one chain per wavefront everywhere; 3: four per wavefront whatever the chain count
     deep_bins: int = 0        # 1 / -1: force the bin-trimming kernel variant on / off (0 = from the dictionary)
     long_budget: int = 0      # deep pools: compare passes before a search goes to k_long (0 = default, -1 = never)
     devices: tuple = ()       # call_reorder on several GPUs: one pool over these device ordinals (may repeat: host transport)

@@ -66,10 +66,11 @@ def test_fuzz_gpu_equals_oracle(block):
             ser = po.reorder_serial(read, ln, L)
             for k in KEYS:
                 assert np.array_equal(got[k], ser[k]), ("seed", seed, "serial", k)
-        # the production build (no counters): four chains per wavefront on shallow dictionaries; with the deep-bin
-        # variant forced on, the balanced scan and the resumed searches; and the one-chain-per-wavefront round
+        # the production build (no counters): four chains per wavefront on shallow dictionaries (fused = 3: the library
+        # itself takes that kernel from 49 152 chains on); with the deep-bin variant forced on, the balanced scan and the
+        # resumed searches; and the one-chain-per-wavefront round (fused = 0: the automatic choice at these sizes, or 2)
         rng = np.random.default_rng(seed + 77)
-        kw = dict(deep_bins=int(rng.choice([0, 1, -1])), fused=int(rng.choice([0, 0, 2])))
+        kw = dict(deep_bins=int(rng.choice([0, 1, -1])), fused=int(rng.choice([3, 3, 0, 2])))
         if kw["deep_bins"] == 1:  # searches handed to k_long after 1 / 2 / the default number of compare passes, or never
             kw["long_budget"] = int(rng.choice([1, 1, 2, 0, -1]))
         got2 = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, **kw))
@@ -89,7 +90,7 @@ def test_fuzz_single_pool_virtual_ranks(block):
         K = max(G, (K // G) * G)
         read, ln = po.load_dna(dna, n, L)
         want = po.reorder_rounds(read, ln, L, K, T)
-        vp = VirtualPool(G, K, T)
+        vp = VirtualPool(G, K, T, fused=3 if seed % 2 else 0)  # four chains per wavefront / the automatic choice (one)
         try:
             got = vp.run(lambda s: s.load_dna(dna, n, L))
         finally:

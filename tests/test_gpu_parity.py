@@ -22,6 +22,11 @@ def _sa():
 def _gpu(name, K, T=1, **kw):
     sa = _sa()
     dna, n, L = named_set(name)
+    # the library picks four chains per wavefront (k_round_mc) only from 49 152 chains on; the test sets are small, so
+    # a run that does not say otherwise asks for that kernel (fused = 3) -- the automatic choice (one chain per
+    # wavefront here) is what the fuzz's fused = 0 legs and the tests that pass `fused` themselves run
+    if "fused" not in kw and not kw.get("collect_stats") and not kw.get("force_literal_update"):
+        kw["fused"] = 3
     return sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=K, num_thr=T, **kw))
 
 
@@ -258,7 +263,7 @@ def test_single_pool_is_independent_of_gpu_count(name, K, G):
     T = 3
     want = po.reorder_rounds(read, ln, L, K, T)
     single = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=K, num_thr=T))
-    vp = VirtualPool(G, K, T)
+    vp = VirtualPool(G, K, T, fused=3)  # (four chains per wavefront on every rank; `single` runs the automatic choice)
     try:
         got = vp.run(lambda s: s.load_dna(dna, n, L))
     finally:
@@ -455,13 +460,16 @@ def test_parity_10M_reads():
         assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
     # the production build (no counters: four chains per wavefront) on the same reads
     del got
-    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T)) as st:
-        st.load_synth(n, L, n * L // 25, 3, 10000)
-        got = st.run().streams()
-    _same(got, want, "10M-production")
-    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
-    for k in ("unmatched", "lost"):
-        assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
+    # (four chains per wavefront -- what a pool of 50 M reads and more runs by default -- and the automatic choice at
+    # this chain count, one chain per wavefront)
+    for fused in (3, 0):
+        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, fused=fused)) as st:
+            st.load_synth(n, L, n * L // 25, 3, 10000)
+            got = st.run().streams()
+        _same(got, want, ("10M-production", fused))
+        assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+        for k in ("unmatched", "lost"):
+            assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
 
 
 def test_1M_150bp_k1_reference_counters_on_the_gpu():
