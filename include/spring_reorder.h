@@ -38,9 +38,11 @@ typedef struct {
   int32_t time_search;  /* 1: bracket every search-kernel launch with HIP events (bench roofline) */
   int32_t force_literal_update; /* 1: consensus update always through the literal lane-0 path (tests) */
   int32_t rounds_per_sync;      /* rounds enqueued between host termination checks; 0 = auto      */
-  int32_t long_budget;          /* deep-coverage pools: 64-lane compare passes a wavefront spends on one search before the
-                                   search is handed to a block of 16 wavefronts (k_long); 0 = default (8), -1 = never.
-                                   Same results for every value. */
+  int32_t long_budget;          /* deep-bin kernel variant: 64-lane compare passes a wavefront spends on one search before the
+                                   search is handed to a block of 16 wavefronts (k_long).  0 = default: 8, and only on pools of
+                                   very deep bins (a quarter of the dictionary's reads in bins of >= 256 entries) and only for
+                                   searches with >= 2048 bin entries still ahead; > 0: on whenever that variant runs (values
+                                   below 8 hand over unconditionally: tests); -1 = never.  Same results for every value. */
   /* ---- tuning / experiments (0 = default).  The output does not depend on any of them; each non-default
    * setting is covered by a parity test (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results). */
   int32_t first_shifts;   /* a search probes shifts in ordered batches of k and 16, then all the rest at once: k = 1..16;
