@@ -35,14 +35,17 @@ assert np.array_equal(got["tid_off"], want["tid_off"])
 for k in ("probes", "keyok", "cands", "hits", "unmatched"):
     assert gst[k] == want["stats"][k], (k, gst[k], want["stats"][k])
 print("reorder: %d reads, K=%d: streams and work counters identical" % (n, K), flush=True)
-with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8)) as st:  # the production build: no counters
-    st.load_dna(dna, n, L)
-    st.run()
-    got2 = st.streams()
-for k in KEYS:
-    assert np.array_equal(got2[k], want[k]), ("production", k)
-assert np.array_equal(got2["tid_off"], want["tid_off"]) and got2["stats"]["lost"] == want["stats"]["lost"]
-print("reorder, production round kernel (four chains per wavefront): streams identical", flush=True)
+# the production build (no counters): the kernel the library picks at this chain count (four chains per wavefront from
+# 49 152 chains on, one below) and the other one
+for fused, what in ((0, "the library's choice"), (3, "four chains per wavefront"), (2, "one chain per wavefront")):
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8, fused=fused)) as st:
+        st.load_dna(dna, n, L)
+        st.run()
+        got2 = st.streams()
+    for k in KEYS:
+        assert np.array_equal(got2[k], want[k]), ("production", fused, k)
+    assert np.array_equal(got2["tid_off"], want["tid_off"]) and got2["stats"]["lost"] == want["stats"]["lost"]
+    print("reorder, production round kernel (%s): streams identical" % what, flush=True)
 t0 = time.time()
 we = po.encode(read, ln, L, want, num_thr=8)
 print("encoder oracle: %.1f s" % (time.time() - t0), flush=True)
