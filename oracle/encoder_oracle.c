@@ -442,6 +442,42 @@ uint64_t orc_pack_seq(const char *seq, uint64_t len, uint8_t *packed, char *tail
   return len / 4;
 }
 
+
+/* ---- one contig through buildcontig + writecontig, exposed for tests/test_oracle_vs_ref_units.py (pinned against the
+ * REAL encoder.cpp:32-109).  reads: NUL-separated strings; out receives the seven streams back to back, sizes[7] =
+ * seq, pos, noise, noisepos, order, RC, readlength. */
+long orc_enc_contig(const char *reads, const int64_t *pos, const char *rc, const uint32_t *order, uint32_t count,
+                    uint64_t *abs_pos, uint8_t *out, long cap, uint64_t *sizes) {
+  cread_t *c = (cread_t *)calloc(count ? count : 1, sizeof(cread_t));
+  const char *p = reads;
+  for (uint32_t i = 0; i < count; i++) {
+    size_t n = strlen(p);
+    c[i].read = (char *)p;
+    c[i].len = (uint16_t)n;
+    c[i].pos = pos[i];
+    c[i].rc = rc[i];
+    c[i].order = order[i];
+    p += n + 1;
+  }
+  streams_t o;
+  memset(&o, 0, sizeof(o));
+  size_t ref_size = 0;
+  char *ref = buildcontig(c, count, &ref_size);
+  writecontig(ref, ref_size, c, count, &o, abs_pos);
+  free(ref);
+  buf_t *bs[7] = {&o.seq, &o.pos, &o.noise, &o.noisepos, &o.order, &o.rc, &o.rlen};
+  long w = 0;
+  for (int i = 0; i < 7; i++) {
+    if (w + (long)bs[i]->n > cap) { w = -1; break; }
+    memcpy(out + w, bs[i]->p, bs[i]->n);
+    sizes[i] = bs[i]->n;
+    w += (long)bs[i]->n;
+  }
+  for (int i = 0; i < 7; i++) free(bs[i]->p);
+  free(c);
+  return w;
+}
+
 /* ---- bpb = 3 primitives exposed for tests/test_oracle_vs_ref.py (pinned against the real bitset_util) */
 void orc_enc_bits3(const char *s, int n, uint64_t *b, int W) { string_to_bits3(s, n, b, W); }
 int orc_enc_hamming3(const uint64_t *a, const uint64_t *b, int W, int len) { return hamming3(a, b, W, len); }

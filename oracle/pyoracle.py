@@ -53,6 +53,17 @@ def lib():
                                              C.c_void_p, C.c_void_p]
         L.orc_reorder_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
                                       C.POINTER(OrcOut), C.POINTER(OrcStats)]
+        L.orc_string_to_bits.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_string_to_bits.restype = None
+        L.orc_bits_to_string.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        L.orc_bits_to_string.restype = None
+        L.orc_reverse_complement.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.orc_reverse_complement.restype = None
+        L.orc_pack_read.restype = C.c_size_t
+        L.orc_pack_read.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.orc_updaterefcount.restype = None
+        L.orc_updaterefcount.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_write_dna_stream.restype = C.c_size_t
         L.orc_write_dna_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_uint64, C.c_void_p]
@@ -92,6 +103,84 @@ def ref_lib():
         R.ref_mask_hamming.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _REF = R
     return _REF
+
+
+_UNITS = None
+
+
+class OrcShadow(C.Structure):
+    """orc_shadow (reorder_oracle.h): C function pointers, filled straight from oracle/_ref/libref_units.so."""
+    _fields_ = [("user", C.c_void_p), ("claim_first", C.c_void_p), ("remove", C.c_void_p), ("search", C.c_void_p),
+                ("update", C.c_void_p), ("pick_seed", C.c_void_p)]
+
+
+def ref_units():
+    """oracle/_ref/libref_units.so: the REAL updaterefcount / search_match / readDnaFile / setglobalarrays
+    (reorder.h:33-318), util.cpp helpers and encoder.cpp units compiled by line range (oracle/Makefile), or None."""
+    global _UNITS
+    if _UNITS is None:
+        path = os.path.join(_HERE, "_ref", "libref_units.so")
+        if not os.path.exists(path):
+            return None
+        U = C.CDLL(path)
+        U.ref_u_updaterefcount.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
+        U.ref_u_chartobitset.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        U.ref_u_bitsettostring.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        U.ref_u_readDnaFile.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        U.ref_u_reverse_complement.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        U.ref_u_reverse_complement.restype = None
+        U.ref_u_write_dna.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_int]
+        U.ref_u_read_dna.restype = C.c_long
+        U.ref_u_read_dna.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_char_p, C.c_long]
+        U.ref_u_read_fastq.restype = C.c_long
+        U.ref_u_read_fastq.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_char_p, C.c_long, C.POINTER(C.c_long)]
+        U.ref_shadow_create.restype = C.c_void_p
+        U.ref_shadow_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_int]
+        U.ref_shadow_destroy.argtypes = [C.c_void_p]
+        U.ref_shadow_destroy.restype = None
+        U.ref_shadow_remove.argtypes = [C.c_void_p, C.c_uint32]
+        U.ref_shadow_set_remaining.argtypes = [C.c_void_p, C.c_void_p]
+        U.ref_shadow_set_remaining.restype = None
+        U.ref_shadow_get_remaining.argtypes = [C.c_void_p, C.c_void_p]
+        U.ref_shadow_get_remaining.restype = None
+        U.ref_shadow_search_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+        U.ref_shadow_search_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        U.ref_u_contig.restype = C.c_long
+        U.ref_u_contig.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_char_p,
+                                   C.POINTER(C.c_uint64), C.c_void_p, C.c_long, C.c_void_p]
+        U.ref_u_correct_order.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p]
+        U.ref_u_enc_bits3_roundtrip.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]
+        U.ref_u_readsingletons.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _UNITS = U
+    return _UNITS
+
+
+def reorder_serial_shadow(read, ln, L, basedir, num_thr=2):
+    """orc_reorder_serial with every search_match / updaterefcount / bin removal / seed pick cross-checked against the
+    REAL reference functions advancing a mirrored state.  -> (streams dict, stats, mm[10])."""
+    U = ref_units()
+    Lb = lib()
+    n = len(ln)
+    read = np.ascontiguousarray(read, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.uint16)
+    sh_obj = U.ref_shadow_create(read.ctypes.data, ln.ctypes.data, n, L, basedir.encode(), num_thr)
+    assert sh_obj
+    sh = OrcShadow()
+    sh.user = sh_obj
+    for name in ("claim_first", "remove", "search", "update", "pick_seed"):
+        setattr(sh, name, C.cast(getattr(U, "ref_shadow_" + name), C.c_void_p).value)
+    o, arrs = _alloc_out(max(n, 1), 1)
+    st = OrcStats()
+    mm = np.zeros(10, np.uint64)
+    Lb.orc_reorder_serial_shadow.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(OrcOut),
+                                             C.POINTER(OrcStats), C.POINTER(OrcShadow), C.c_void_p]
+    rc = Lb.orc_reorder_serial_shadow(read.ctypes.data, ln.ctypes.data, n, L, C.byref(o), C.byref(st), C.byref(sh),
+                                      mm.ctypes.data)
+    U.ref_shadow_destroy(sh_obj)
+    assert rc == 0
+    return _finish(o, arrs, st), st.asdict(), mm
 
 
 def ref_order_bin():

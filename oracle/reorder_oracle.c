@@ -468,8 +468,39 @@ static int search_match(ctx_t *x, const uint64_t *ref, uint32_t *k, int rev, int
   return flag;
 }
 
+static int reorder_serial_impl(const uint64_t *read, const uint16_t *len, uint32_t n, int L, orc_out *out,
+                               orc_stats *st, const orc_shadow *sh, uint64_t *mm);
+
 int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, int L, orc_out *out,
                        orc_stats *st) {
+  return reorder_serial_impl(read, len, n, L, out, st, NULL, NULL);
+}
+
+/* The same run with every step mirrored on a shadow state that only reference code advances
+ * (oracle/ref_units_driver.cpp): mm[0] search_match results that differ, mm[1] working ref/revref or ref_len that
+ * differ at a search, mm[2] ref/revref/ref_len after updaterefcount, mm[3] count[][] after updaterefcount,
+ * mm[4] seed picks, mm[5] bin removals / first claim the reference could not do, mm[6..9] calls made
+ * (search, update, remove, seed). */
+int orc_reorder_serial_shadow(const uint64_t *read, const uint16_t *len, uint32_t n, int L, orc_out *out,
+                              orc_stats *st, const orc_shadow *sh, uint64_t *mm) {
+  memset(mm, 0, sizeof(uint64_t) * 10);
+  return reorder_serial_impl(read, len, n, L, out, st, sh, mm);
+}
+
+#define SH_SEARCH(refp, rev)                                                                     \
+  if (sh) {                                                                                      \
+    int b_ = sh->search(sh->user, refp, rev, shift, c->ref_len, flag, k);                        \
+    mm[0] += b_ & 1; mm[1] += (b_ >> 1) & 1; mm[6]++;                                            \
+  }
+#define SH_UPDATE(rid, reset, rev, sft)                                                          \
+  if (sh) {                                                                                      \
+    int b_ = sh->update(sh->user, (uint32_t)(rid), reset, rev, sft, &c->cnt[0][0],               \
+                        ORC_MAX_READ_LEN + 1, c->ref, c->revref, c->ref_len);                    \
+    mm[2] += b_ & 1; mm[3] += (b_ >> 1) & 1; mm[7]++;                                            \
+  }
+
+static int reorder_serial_impl(const uint64_t *read, const uint16_t *len, uint32_t n, int L, orc_out *out,
+                               orc_stats *st, const orc_shadow *sh, uint64_t *mm) {
   ctx_t x;
   memset(&x, 0, sizeof(x));
   memset(st, 0, sizeof(*st));
@@ -507,9 +538,11 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
   else {
     x.remainingreads[current] = 0;
     unmatched++;
+    if (sh) mm[5] += sh->claim_first(sh->user, (uint32_t)current) != 0;
   }
   if (!done) {
     updaterefcount(read + (size_t)current * W, c, 1, 0, 0, len[current], L, W, st);
+    SH_UPDATE(current, 1, 0, 0)
     cur_read_pos = 0; ref_pos = 0; first_rid = current; prev_unmatched = 1; prev = current;
   }
   while (!done) {
@@ -528,6 +561,7 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
         findpos(d, dictidx, (uint64_t)startposidx);
         bin_remove(d, dictidx, (uint64_t)startposidx, current);
       }
+      if (sh) { mm[5] += sh->remove(sh->user, (uint32_t)current) != 0; mm[8]++; }
     } else
       left_search_start = 0;
     flag = 0;
@@ -537,10 +571,12 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
       memcpy(revref, c->revref, sizeof(uint64_t) * W);
       for (int shift = 0; shift < x.maxshift; shift++) { /* :479-558 */
         flag = search_match(&x, ref, &k, 0, shift, c->ref_len);
+        SH_SEARCH(ref, 0)
         if (flag == 1) {
           current = k;
           int ref_len_old = c->ref_len;
           updaterefcount(read + (size_t)current * W, c, 0, 0, shift, len[current], L, W, st);
+          SH_UPDATE(current, 0, 0, shift)
           if (!left_search) {
             cur_read_pos = ref_pos + shift;
             ref_pos = cur_read_pos;
@@ -554,10 +590,12 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
           break;
         }
         flag = search_match(&x, revref, &k, 1, shift, c->ref_len);
+        SH_SEARCH(revref, 1)
         if (flag == 1) {
           current = k;
           int ref_len_old = c->ref_len;
           updaterefcount(read + (size_t)current * W, c, 0, 1, shift, len[current], L, W, st);
+          SH_UPDATE(current, 0, 1, shift)
           if (!left_search) {
             cur_read_pos = ref_pos + ref_len_old + shift - len[current];
             ref_pos = ref_pos + ref_len_old + shift - c->ref_len;
@@ -580,6 +618,7 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
         left_search = 1;
         left_search_start = 1;
         updaterefcount(read + (size_t)first_rid * W, c, 1, 1, 0, len[first_rid], L, W, st);
+        SH_UPDATE(first_rid, 1, 1, 0)
         ref_pos = 0;
         cur_read_pos = 0;
       } else {
@@ -594,11 +633,13 @@ int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, in
             break;
           }
         }
+        if (sh) { mm[4] += sh->pick_seed(sh->user) != (flag ? current : -1); mm[9]++; }
         if (flag == 0) {
           if (prev_unmatched) ob_push_s(&ob, (uint32_t)prev);
           done = 1;
         } else {
           updaterefcount(read + (size_t)current * W, c, 1, 0, 0, len[current], L, W, st);
+          SH_UPDATE(current, 1, 0, 0)
           ref_pos = 0;
           cur_read_pos = 0;
           if (prev_unmatched) ob_push_s(&ob, (uint32_t)prev);
@@ -992,6 +1033,72 @@ void orc_updaterefcount(const uint64_t *cur, int32_t *cnt, uint64_t *ref, uint64
   *ref_len = c->ref_len;
   free(c);
 }
+
+
+/* ---- unit contexts for tests/test_oracle_vs_ref.py: the oracle's two search primitives on caller-driven state,
+ * compared there with the REAL search_match<> (oracle/_ref/libref_units.so).
+ *   serial flavour: mutable bins (bin_remove) + remainingreads[], one search_match() call;
+ *   rounds flavour: immutable bins + taken[], one whole rounds_search() (the shift loop). */
+typedef struct { ctx_t x; orc_stats st; } orc_unit_t;
+
+void *orc_unit_create(const uint64_t *read, const uint16_t *len, uint32_t n, int L) {
+  orc_unit_t *u = (orc_unit_t *)calloc(1, sizeof(orc_unit_t));
+  ctx_t *x = &u->x;
+  x->read = read; x->len = len; x->n = n; x->L = L; x->W = orc_limbs(L); x->maxshift = L / 2; x->st = &u->st;
+  int s[2], e[2];
+  orc_dict_windows(L, s, e);
+  for (int l = 0; l < 2; l++) { x->dict[l].start = s[l]; x->dict[l].end = e[l]; }
+  if (n > 0) for (int l = 0; l < 2; l++) dict_build(&x->dict[l], read, len, n, x->W);
+  x->remainingreads = (uint8_t *)malloc(n ? n : 1);
+  memset(x->remainingreads, 1, n);
+  return u;
+}
+void orc_unit_free(void *p) {
+  orc_unit_t *u = (orc_unit_t *)p;
+  if (u->x.n > 0) for (int l = 0; l < 2; l++) dict_free(&u->x.dict[l]);
+  free(u->x.remainingreads);
+  free(u);
+}
+/* reorder.h:458-472 for one read */
+void orc_unit_remove(void *p, uint32_t current) {
+  ctx_t *x = &((orc_unit_t *)p)->x;
+  int64_t dictidx[2];
+  for (int l = 0; l < 2; l++) {
+    dict_t *d = &x->dict[l];
+    if ((int)x->len[current] <= d->end) continue;
+    uint64_t ull = read_key(x->read + (size_t)current * x->W, x->W, d);
+    int64_t startposidx = dict_lookup(d, ull);
+    findpos(d, dictidx, (uint64_t)startposidx);
+    bin_remove(d, dictidx, (uint64_t)startposidx, current);
+  }
+}
+void orc_unit_set_remaining(void *p, const uint8_t *r) { ctx_t *x = &((orc_unit_t *)p)->x; memcpy(x->remainingreads, r, x->n); }
+void orc_unit_get_remaining(void *p, uint8_t *r) { ctx_t *x = &((orc_unit_t *)p)->x; memcpy(r, x->remainingreads, x->n); }
+int orc_unit_search(void *p, const uint64_t *refbits, int rev, int shift, int ref_len, uint32_t *k) {
+  return search_match(&((orc_unit_t *)p)->x, refbits, k, rev, shift, ref_len);
+}
+/* rounds_search on (ref, revref, ref_len, taken[]) -- taken = !remainingreads of the same context, bins untouched */
+int orc_unit_rounds_search(void *p, const uint64_t *ref, const uint64_t *revref, int ref_len, const uint8_t *taken,
+                           uint32_t *k, int *shift, int *rev) {
+  orc_unit_t *u = (orc_unit_t *)p;
+  rctx_t r;
+  memset(&r, 0, sizeof(r));
+  r.read = u->x.read; r.len = u->x.len; r.n = u->x.n; r.L = u->x.L; r.W = u->x.W; r.maxshift = u->x.maxshift;
+  r.dict[0] = u->x.dict[0]; r.dict[1] = u->x.dict[1];
+  r.taken = (uint8_t *)taken;
+  r.st = &u->st;
+  cons_t *c = (cons_t *)calloc(1, sizeof(cons_t));
+  memcpy(c->ref, ref, sizeof(uint64_t) * r.W);
+  memcpy(c->revref, revref, sizeof(uint64_t) * r.W);
+  c->ref_len = ref_len;
+  int f = rounds_search(&r, c, k, shift, rev, NULL, 0, NULL);
+  free(c);
+  return f;
+}
+/* chartobitset / bitsettostring twins (reorder.h:76-92, bitset_util.h:238-244) */
+void orc_string_to_bits(const char *s, int len, int L, uint64_t *b) { string_to_bits(s, len, b, orc_limbs(L)); }
+void orc_bits_to_string(const uint64_t *b, int len, int L, char *s) { bits_to_string(b, orc_limbs(L), s, len); }
+void orc_reverse_complement(const char *s, char *s1, int len) { reverse_complement(s, s1, len); }
 
 /* ------------------------------------------------ OpenMP port (CPU baseline only)
  *

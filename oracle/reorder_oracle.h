@@ -75,6 +75,20 @@ typedef struct {
 int orc_reorder_serial(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
                        orc_out *out, orc_stats *st);
 
+/* orc_reorder_serial with every step cross-checked by callbacks that run the REAL reference functions on a mirrored
+ * state (oracle/ref_units_driver.cpp::ref_shadow_*); mm[10] = mismatch / call counters, see reorder_oracle.c */
+typedef struct {
+  void *user;
+  int (*claim_first)(void *user, uint32_t current);
+  int (*remove)(void *user, uint32_t current);
+  int (*search)(void *user, const uint64_t *ref_shifted, int rev, int shift, int ref_len, int flag, uint32_t k);
+  int (*update)(void *user, uint32_t rid, int reset, int rev, int shift, const int32_t *cnt, int stride,
+                const uint64_t *ref, const uint64_t *revref, int ref_len);
+  int64_t (*pick_seed)(void *user);
+} orc_shadow;
+int orc_reorder_serial_shadow(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
+                              orc_out *out, orc_stats *st, const orc_shadow *sh, uint64_t *mm);
+
 int orc_reorder_rounds(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
                        uint32_t num_chains, int num_thr, orc_out *out, orc_stats *st);
 /* the same schedule with A candidates per match proposal resolved in A passes (A = 1: orc_reorder_rounds) */
