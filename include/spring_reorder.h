@@ -67,6 +67,10 @@ typedef struct {
   int32_t num_devices;
   int32_t devices[8];
   int32_t mg_host_transport;
+  int32_t table_mode;     /* dictionary table addressing (same results): 0 / 1 = by the key's hash; 2 = by the key's minimizer
+                             where that applies (32-base windows, reads of 100..192 bases): consecutive windows of a
+                             consensus share cache lines -- 60 % fewer memory requests per round, the same run time
+                             (DESIGN.md section 6), a dictionary stage twice as long: an experiment, not the default */
 } spring_reorder_opts;
 
 typedef struct {
@@ -87,6 +91,8 @@ typedef struct {
   uint64_t chains;         /* K the chain phase ran with (opts.num_chains, or what the default rule chose) */
   uint64_t deep_pool;      /* 1: the dictionary averages >= 1.3 reads per key (the deep-coverage default applies) */
   uint64_t long_searches;  /* searches a wavefront handed over to a block of 16 (k_long; deep-coverage pools only) */
+  uint64_t table_minz;     /* 1: the dictionary table is addressed by minimizers (opts.table_mode) */
+  uint64_t table_marked_lines; /* ... and this many of its lines were over-subscribed: their keys live at the redirect address */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);

@@ -31,7 +31,8 @@ class Opts(C.Structure):
                 ("first_shifts", C.c_int32), ("seed_wide", C.c_int32), ("tab_scale", C.c_int32),
                 ("search_wpb", C.c_int32), ("dbg_search_lds", C.c_int32), ("dbg_apply_lds", C.c_int32),
                 ("fused", C.c_int32), ("deep_bins", C.c_int32),
-                ("num_devices", C.c_int32), ("devices", C.c_int32 * 8), ("mg_host_transport", C.c_int32)]
+                ("num_devices", C.c_int32), ("devices", C.c_int32 * 8), ("mg_host_transport", C.c_int32),
+                ("table_mode", C.c_int32)]
 
 
 class FastqInfo(C.Structure):
@@ -61,7 +62,8 @@ class Stats(C.Structure):
                                              "ms_search_kernel")]
                 + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64),
                    ("ms_exchange", C.c_double), ("ms_resolve_mark", C.c_double), ("chains", C.c_uint64),
-                   ("deep_pool", C.c_uint64), ("long_searches", C.c_uint64)])
+                   ("deep_pool", C.c_uint64), ("long_searches", C.c_uint64),
+                   ("table_minz", C.c_uint64), ("table_marked_lines", C.c_uint64)])
 
     def asdict(self):
         d = {}

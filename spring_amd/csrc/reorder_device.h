@@ -79,6 +79,28 @@ struct Globals {
   uint32_t pad;
 };
 
+// The dictionary table (both dictionaries in one): 2^(64-bshift) buckets of 32 bytes, [tag x4 | payload x4]; a probe loads
+// the 16 tag bytes (buck[2 b]) and the payload word of a slot (word 8 b + 4 + s) on a fingerprint match only -- by then
+// the line is in L1 / L2.
+// Home bucket of a key with hash h = mix64(key):
+//   minz = 0: h >> bshift;
+//   minz = 1 (32-base windows, reads of 100..192 bases): four consecutive buckets = one 128-byte neighbourhood, chosen by
+//     the key's minimizer (the smallest canonical 16-mer of the window, minz_of_key), the bucket inside it by two bits of
+//     h.  Consecutive windows of a consensus share their minimizer for ~9 shifts on average, so the ~151 tag fetches of
+//     a failing search touch a few dozen cache lines instead of 151.  A neighbourhood that more than MINZ_HEAVY keys ask for
+//     (repeats, low-complexity sequence) keeps none of them: its four buckets carry TAG_MARK in slot 0 and its keys live
+//     at tab_redirect(h), where a lookup that sees the mark continues.
+struct TabView {
+  const uint4 *buck;
+  int bshift;
+  int minz;
+  int lshift;   // minz: neighbourhood = mixed minimizer >> lshift (32 - log2(buckets / 4), 2..31)
+};
+constexpr uint32_t TAG_MARK = 0xfffffffcu;  // fingerprint 0x3fffffff is never handed out (fp30_of)
+constexpr int MINZ_HEAVY = 12;              // keys a line may be the home of
+constexpr int MINZ_K = 16;                  // minimizer length in bases
+constexpr int MINZ_WL = 32;                 // ... of windows of this length only (MINZ_WL - MINZ_K + 1 = 17 k-mers per window)
+
 struct DevParams {
   // reads
   const uint64_t *reads;  // n * S limbs (S = limb stride, power of two >= W, <= 16)
@@ -95,8 +117,7 @@ struct DevParams {
   // dictionaries (reorder.h:751-759)
   int dstart[2], dend[2];
   uint32_t numkeys[2];
-  const uint4 *fpt;           // ONE table for both dictionaries: buckets [tag x4 | payload x4], 32 B each
-  int bshift;                 // bucket = hash >> bshift (the table has 2^(64-bshift) buckets, at least 2)
+  TabView tab;                // ONE table for both dictionaries (tab_find)
   const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key (multi-read bins)
   const uint32_t *ids[2];
   // shared mutable state
@@ -155,13 +176,21 @@ struct DictBuild {
   uint32_t *deep, *ndeep;   // ndeep[0] bins listed in deep[], ndeep[1] reads in bins of >= BIG_BIN entries
 };
 void launch_tab_insert(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
-                       DictBuild d1, uint4 *fpt, int bshift);
+                       DictBuild d1, uint32_t *fpt, int bshift);
+// minimizer-addressed table: bucket + {tag, payload} word of every merged entry (also writes the bin records), then,
+// after a sort by bucket, the two insert passes
+void launch_minz_prepare(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
+                         DictBuild d1, int lshift, uint32_t *bucket, uint64_t *tagpay);
+void launch_tab_insert_minz(hipStream_t st, const uint32_t *bucket_sorted, const uint64_t *tagpay_sorted, uint64_t nmerged,
+                            uint32_t *fpt, int bshift, uint32_t *marked);
+hipError_t sort_pairs_u32_u64(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *kout,
+                              const uint64_t *vin, uint64_t *vout, size_t n, unsigned end_bit);
 hipError_t merge_by_hash(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *k0, const uint64_t *k1,
                          const uint64_t *v0, const uint64_t *v1, uint64_t *kout, uint64_t *vout, size_t n0, size_t n1);
 void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag);
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
                       ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken);
-void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift, int which,
+void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count);
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);

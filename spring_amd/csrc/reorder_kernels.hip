@@ -79,11 +79,11 @@ __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uin
 }
 
 // exact key -> bin map in two levels (replaces boomphf lookup + findpos + key re-check,
-// reorder.h:271-285), ONE table for both dictionaries:
-//   fpt : 32-byte buckets [tag0..3 | pay0..3]; tag = (30-bit hash fingerprint << 2) | dict << 1 | single,
-//         tag 0 = empty slot.  One bucket = one 32-byte HBM fetch, the granularity random reads
-//         actually cost on MI355X (tools/random_gather_bench.hip: 64 B/lane random reads run at
-//         20 G/s, <= 32 B/lane at 48 G/s).  98 % of probes are absent keys and end here.
+// reorder.h:271-285), ONE table for both dictionaries (TabView, reorder_device.h):
+//   32-byte buckets [tag0..3 | pay0..3]; tag = (30-bit hash fingerprint << 2) | dict << 1 | single, tag 0 = empty slot.
+//         98 % of the probes are absent keys and end at the 16 tag bytes.  The payload word is fetched on a fingerprint
+//         match only (a second 16-byte load of every bucket doubles the L1 traffic of a gather, tools/wave_hop_bench.hip);
+//         it sits in the cache line the tags came from.
 //   The two dictionary windows are adjacent and equally long (reorder.h:751-759: start1 = end0 + 1), so the
 //   window dictionary 1 looks up at shift s is the window dictionary 0 looks up at shift s + wl (forward;
 //   reverse: dict 0 at s == dict 1 at s + wl).  A key of both dictionaries sits in the same bucket (same
@@ -93,11 +93,11 @@ __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uin
 //         against the read's own window (as the reference does with the first read of a bin,
 //         reorder.h:282-285), so the hot path is bucket -> read: no offsets/ids hops.
 //   single = 0: pay indexes urec[dict], a 16-byte record {key, start | count << 32}.
-// bucket = top bits of the hash (the table is built in hash order, so unique keys arrive at
-// k_tab_insert in bucket order and their writes stream), fingerprint = low 30 bits
+// Home bucket: top bits of the hash, or (minz) the line of the key's minimizer + two hash bits (TabView).
+// fingerprint = low 30 bits of the hash; 0 (empty) and 0x3fffffff (TAG_MARK) are never handed out
 __device__ __forceinline__ uint32_t fp30_of(uint64_t h) {
   const uint32_t f = (uint32_t)h & 0x3fffffffu;
-  return f ? f : 1u;
+  return f == 0u ? 1u : f == 0x3fffffffu ? 0x3ffffffeu : f;
 }
 __device__ __forceinline__ uint64_t bucket_of(uint64_t h, int bshift) { return h >> bshift; }
 __device__ __forceinline__ uint64_t bucket_mask(int bshift) { return (1ull << (64 - bshift)) - 1; }
@@ -106,31 +106,65 @@ __device__ __forceinline__ uint64_t unmix64(uint64_t x) {
   x ^= x >> 33; x *= 0x9cb4b2f8129337dbull; x ^= x >> 33; x *= 0x4f74430c22a54005ull; x ^= x >> 33;
   return x;
 }
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+// ---- minimizers (TabView::minz).  Order value of a 16-mer (32 bits, SPRING code A0 G1 C2 T3, first base in the low
+// bits): strand-symmetric -- the smaller of the k-mer and its reverse complement -- so that a consensus window and the
+// window of the reverse consensus over the same bases have the same minimizer and ONE array of window minimizers
+// serves the forward and the reverse probes of a search; xor before the multiplication so that poly-A (0) is not
+// everybody's minimum.  Cheap on purpose: it only has to put the k-mers of a window in some fixed pseudo-random order.
+__device__ __forceinline__ uint32_t kmer_order(uint32_t x) {
+  uint32_t r = __builtin_bitreverse32(x);                           // bases reversed, the two bits of a base swapped ...
+  r = ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));       // ... swapped back; complement = 3 - code
+  return ((x < r ? x : r) ^ 0x5bd1e995u) * 0x9e3779b1u;
+}
+// the value a window's line is derived from: min over its 17 k-mers, mixed (a minimum is small: its top bits are not uniform)
+__device__ __forceinline__ uint32_t minz_of_key(uint64_t key) {
+  uint32_t m = 0xffffffffu;
+#pragma unroll
+  for (int q = 0; q <= MINZ_WL - MINZ_K; q++) m = min(m, kmer_order((uint32_t)(key >> (2 * q))));
+  return fmix32(m);
+}
+// home bucket of a key; mz = minz_of_key(key) (only read when T.minz)
+__device__ __forceinline__ uint64_t tab_home(const TabView &T, uint64_t h, uint32_t mz) {
+  return T.minz ? (((uint64_t)(mz >> T.lshift) << 2) | ((h >> 30) & 3ull)) : bucket_of(h, T.bshift);
+}
+// where the keys of an over-subscribed line live instead (a function of the fingerprint and the two bucket bits only:
+// that is what the insert kernel still knows of the hash)
+__device__ __forceinline__ uint64_t tab_redirect_x(uint32_t x32, int bshift) { return mix64(0x6a09e667f3bcc908ull ^ x32) >> bshift; }
+__device__ __forceinline__ uint64_t tab_redirect(const TabView &T, uint64_t h) {
+  return tab_redirect_x(fp30_of(h) | ((uint32_t)((h >> 30) & 3ull) << 30), T.bshift);
+}
 // kind of the (skip+1)-th slot of dictionary l whose fingerprint matches: 0 = none (key absent), 1 = multi,
 // 2 = single.  `other` is set when the other dictionary may hold the key too: a slot of it with the same
 // fingerprint in a bucket this call looked at, or a full bucket (its slots may continue in the next one);
 // other == false proves the key absent from the other dictionary.
-__device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshift, uint64_t h, int l, int skip,
+__device__ __forceinline__ int tab_find(const TabView &T, uint64_t h, uint32_t mz, int l, int skip,
                                         uint32_t &pay, bool &other) {
   const uint32_t mine = (fp30_of(h) << 2) | ((uint32_t)l << 1), theirs = mine ^ 2u;
-  const uint64_t bmask = bucket_mask(bshift);
-  uint64_t b = bucket_of(h, bshift);
+  const uint64_t bmask = bucket_mask(T.bshift);
+  uint64_t b = tab_home(T, h, mz);
+  bool first = T.minz != 0;
   for (;;) {
-    // tags only (16 of the bucket's 32 bytes): 98 % of the probes end here.  The payload word is fetched on a
-    // fingerprint match alone -- a second 16-byte load of every bucket doubles the L1 traffic of a 64-lane
-    // gather and the line is often evicted again before it is read (tools/wave_hop_bench.hip)
+    // tags only: 98 % of the probes end here
 #if defined(SR_TAGS_NT)
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x4_t tv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(&fpt[b * 2]));
+    const u32x4_t tv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(&T.buck[b * 2]));
     const uint4 t = make_uint4(tv.x, tv.y, tv.z, tv.w);
 #elif defined(SR_TAGS_SC)
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     u32x4_t tv;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(tv) : "v"(&fpt[b * 2]) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(tv) : "v"(&T.buck[b * 2]) : "memory");
     const uint4 t = make_uint4(tv.x, tv.y, tv.z, tv.w);
 #else
-    const uint4 t = fpt[b * 2];
+    const uint4 t = T.buck[b * 2];
 #endif
+    if (first) {  // an over-subscribed line: its keys live on the chain that starts at tab_redirect
+      first = false;
+      if (t.x == TAG_MARK) { b = tab_redirect(T, h); continue; }
+    }
     other = other || (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || t.w != 0;
     // slots fill in order and never empty again, so the matches of `mine` all lie before the first free slot and a
     // free last slot ends the key's run; one bit per matching slot instead of a branch per slot
@@ -140,9 +174,9 @@ __device__ __forceinline__ int tab_find(const uint4 *__restrict__ fpt, int bshif
     if (c > skip) {
       for (; skip > 0; skip--) m &= m - 1;
       const int I = __ffs((int)m) - 1;
-      const uint32_t T = I == 0 ? t.x : I == 1 ? t.y : I == 2 ? t.z : t.w;
-      pay = reinterpret_cast<const uint32_t *>(fpt)[b * 8 + 4 + I];
-      return 1 + (int)(T & 1u);
+      const uint32_t Tg = I == 0 ? t.x : I == 1 ? t.y : I == 2 ? t.z : t.w;
+      pay = reinterpret_cast<const uint32_t *>(T.buck)[b * 8 + 4 + I];
+      return 1 + (int)(Tg & 1u);
     }
     if (t.w == 0) return 0;
     skip -= c;
@@ -285,6 +319,76 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ mhash, const uint64_t 
     b = (b + 1) & bmask;
   }
 }
+
+// ---- the minimizer-addressed table (TabView::minz) is built from the same merged list in three steps:
+// k_minz_prepare (streaming, merged = hash order): the bin record of every unique key, its home bucket and its
+// {tag, payload} word; a radix sort of (bucket, word) by bucket; k_tab_insert_minz, two passes over the sorted list
+// (pass 0: streaming -- the keys of a line that more than MINZ_HEAVY keys call home are left out and the line is marked;
+// the first four keys of a bucket take its slots; pass 1: the keys of marked lines, from tab_redirect on, and the keys
+// past the fourth of a bucket, from the next bucket on, claim the first free slot with CAS).
+__global__ void k_minz_prepare(const uint64_t *__restrict__ mhash, const uint64_t *__restrict__ mval, uint64_t nm,
+                               DictBuild d0, DictBuild d1, int lshift, uint32_t *__restrict__ bucket,
+                               uint64_t *__restrict__ tagpay) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nm) return;
+  const uint64_t h = mhash[i], key = unmix64(h);
+  const uint64_t mv = mval[i];
+  const uint32_t l = (uint32_t)(mv >> 63), u = (uint32_t)mv;
+  const DictBuild &d = l ? d1 : d0;
+  const uint32_t st = d.ustart[u], cn = d.ucount[u];
+  const bool single = cn == 1;
+  const uint32_t tag = (fp30_of(h) << 2) | (l << 1) | (single ? 1u : 0u);
+  const uint32_t pay = single ? d.ids[st] : u;
+  if (cn >= DEEP_BIN) d.deep[atomicAdd(d.ndeep, 1u)] = u;
+  if (cn >= BIG_BIN) atomicAdd(d.ndeep + 1, cn);
+  d.urec[u] = make_ulonglong2(key, (uint64_t)st | ((uint64_t)cn << 32));
+  bucket[i] = ((minz_of_key(key) >> lshift) << 2) | (uint32_t)((h >> 30) & 3ull);
+  tagpay[i] = (uint64_t)tag | ((uint64_t)pay << 32);
+}
+template <bool SECOND>
+__global__ void k_tab_insert_minz(const uint32_t *__restrict__ bk, const uint64_t *__restrict__ tp, uint64_t nm,
+                                  uint32_t *fpt, int bshift, uint32_t *marked /* [1]: neighbourhoods marked */) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nm) return;
+  const uint32_t b0 = bk[i], line = b0 >> 2;
+  // is this line the home of more than MINZ_HEAVY keys?  (its entries are adjacent in the sorted list)
+  int back = 0;
+  while (back <= MINZ_HEAVY && i > (uint64_t)back && (bk[i - 1 - back] >> 2) == line) back++;
+  bool heavy = back > MINZ_HEAVY;
+  if (!heavy) {
+    const uint64_t at = i - back + MINZ_HEAVY;  // the (MINZ_HEAVY + 1)-th entry of the line, if it has one
+    heavy = at < nm && (bk[at] >> 2) == line;
+  }
+  int rank = 0;
+  if (!heavy) while (rank < 4 && rank < back && bk[i - 1 - rank] == b0) rank++;
+  const uint64_t w = tp[i];
+  const uint32_t tag = (uint32_t)w, pay = (uint32_t)(w >> 32);
+  if (!SECOND) {
+    if (heavy) {
+      if (back == 0) {
+        for (int s = 0; s < 4; s++) fpt[((uint64_t)line * 4 + s) * 8] = TAG_MARK;
+        atomicAdd(marked, 1u);
+      }
+    } else if (rank < 4) {
+      fpt[(uint64_t)b0 * 8 + rank] = tag;
+      fpt[(uint64_t)b0 * 8 + 4 + rank] = pay;
+    }
+    return;
+  }
+  if (!heavy && rank < 4) return;
+  const uint64_t bmask = bucket_mask(bshift);
+  uint64_t b = heavy ? tab_redirect_x((tag >> 2) | ((b0 & 3u) << 30), bshift) : (((uint64_t)b0 + 1) & bmask);
+  for (;;) {
+    uint32_t *bk = fpt + b * 8;
+    for (int sl = 0; sl < 4; sl++) {
+      if (atomicCAS(bk + sl, 0u, tag) == 0u) {
+        bk[4 + sl] = pay;
+        return;
+      }
+    }
+    b = (b + 1) & bmask;
+  }
+}
 __global__ void k_iota_tag(uint64_t *v, uint64_t n, uint64_t tag) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = i | tag;
@@ -320,18 +424,19 @@ __global__ __launch_bounds__(256) void k_trim_bins(const uint32_t *__restrict__ 
 
 // test hook: start/count of the bin of each key; single-read bins report count = 1 | 0x80000000
 // and the read id in start[]
-__global__ void k_dict_lookup(const uint4 *__restrict__ fpt, const ulonglong2 *__restrict__ urec, int bshift, int which,
+__global__ void k_dict_lookup(TabView tab, const ulonglong2 *__restrict__ urec, int which,
                               const uint64_t *__restrict__ reads, int S, int dstart, int klen2,
                               const uint64_t *__restrict__ keys, uint32_t nkeys, uint32_t *__restrict__ start,
                               uint32_t *__restrict__ count) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nkeys) return;
   const uint64_t key = keys[i], h = mix64(key);
+  const uint32_t mz = tab.minz ? minz_of_key(key) : 0u;
   uint32_t s = 0, c = 0xffffffffu;
   for (int skip = 0;; skip++) {
     uint32_t pay;
     bool other = false;
-    const int kind = tab_find(fpt, bshift, h, which, skip, pay, other);
+    const int kind = tab_find(tab, h, mz, which, skip, pay, other);
     if (kind == 0) break;
     if (kind == 1) {
       const ulonglong2 r = urec[pay];
@@ -832,9 +937,13 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Hamming of candidate r against the shifted consensus over bases [lo, min(mref, len_r))
 // (mask[0][..] / mask[shift][..] of reorder.h:291-301); with check_key also the reference's key re-check of
 // a single-read bin (reorder.h:282-285): -1 = the read's window is not `key` (fingerprint collision), else 0 / 1.
+// spec_taken (may be null): the candidate's limbs are fetched BEFORE it is known whether the read is still free -- its word
+// of the taken bitmap is loaded beside them and comes back in *spec_taken (one memory round trip per candidate instead of
+// two; a taken candidate costs a wasted 64-byte read).  -2: the read is taken (nothing was compared).
 template <bool QUAD, bool UNROLL = false>
 __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t *sx, int bitshift, int lo, int mref, int ds,
-                                           int klen2, uint32_t r, bool check_key, lds_u32_t *stage, int lane) {
+                                           int klen2, uint32_t r, bool check_key, lds_u32_t *stage, int lane,
+                                           const uint64_t *__restrict__ spec_taken = nullptr) {
   const int W = P.W;
   const int clen = P.uniform_len ? P.L : (int)P.lens[r];
   const int m = clen < mref ? clen : mref;
@@ -877,8 +986,15 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
 #undef STAGE_ROW
 #undef STAGE_QUAD
 #undef STAGE_WORD
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PT(13);
+    if (spec_taken && i0 == 0) {
+      const uint64_t tw = spec_taken[r >> 6];  // (issued behind the staging loads, waited for with them)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PT(13);
+      if ((tw >> (r & 63)) & 1ull) return -2;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PT(13);
+    }
     const int ihi = min(i0 + STAGE_LIMBS - 1, last);
     // unrolled (all LDS reads of a chunk issued first) the round kernels spill: 420 -> 569 ms at the headline size;
     // k_long has the registers (UNROLL: every limb of the chunk, the ones outside [first, last] masked to nothing)
@@ -911,11 +1027,14 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
 // DEFER (probe_batch's balanced scan): a multi-read bin whose key is verified is not walked here -- its extent comes back
 // in `pend` (start, count, record index) and the caller deals its entries out over the lanes.
 struct PendBin { bool on; uint32_t start, count, pay; };
-template <bool TRIM, bool DEFER = false>
+// SPEC (k_round_mc): candidate reads are fetched speculatively beside their taken bit (cmp_candidate).
+// pre != 0: the caller has seen the key's first slot in the tags of its HOME bucket already (tab_find's result for skip = 0):
+// pre = kind (1 / 2) | slot << 2 -- the walk is skipped for it, the payload word comes from the line the tags came from.
+template <bool TRIM, bool DEFER = false, bool SPEC = false>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
-                                           int ref_len, uint64_t key, uint64_t hsh, bool &hit, uint32_t &rid,
+                                           int ref_len, uint64_t key, uint64_t hsh, uint32_t mz, bool &hit, uint32_t &rid,
                                            bool &keyok, uint32_t &ncand, bool &other, lds_u32_t *s_best, lds_u32_t *stage,
-                                           int lane, PendBin *pend = nullptr, int *walk_left = nullptr) {
+                                           int lane, PendBin *pend = nullptr, int *walk_left = nullptr, int pre = 0) {
   // (l differs between lanes: P.x[l] would be a vector load from the kernel-argument buffer -- select instead)
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   const int klen2 = 2 * P.wl;
@@ -928,7 +1047,7 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
   const int lo = rev ? shift : 0;
   const int mref = rev ? ref_len + shift : ref_len - shift;
   auto within_thresh = [&](uint32_t r, bool check_key) -> int {
-    return cmp_candidate<TRIM>(P, sx, bitshift, lo, mref, ds, klen2, r, check_key, stage, lane);
+    return cmp_candidate<TRIM>(P, sx, bitshift, lo, mref, ds, klen2, r, check_key, stage, lane, SPEC ? P.taken : nullptr);
   };
   // *s_best (LDS) = lowest priority code that has hit so far in this batch of probes: the lanes run in lock step, so
   // a lane still walking a bin after another lane with a lower code has hit can never be the winner and leaves
@@ -938,7 +1057,11 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
   for (int skip = 0;; skip++) {
     if (skip && beaten()) break;
     uint32_t pay;
-    const int kind = tab_find(P.fpt, P.bshift, hsh, l, skip, pay, other);
+    int kind;
+    if (skip == 0 && pre) {
+      kind = pre & 3;
+      pay = reinterpret_cast<const uint32_t *>(P.tab.buck)[tab_home(P.tab, hsh, mz) * 8 + 4 + (pre >> 2)];
+    } else kind = tab_find(P.tab, hsh, mz, l, skip, pay, other);
     if (skip == 0) PTW(12);
     if (kind == 0) break;  // key absent
     // a single-read bin (kind 2: pay is the read id) runs through the same scan as a bin of one entry; its key is
@@ -969,9 +1092,10 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
         *walk_left = j;
       }
       const uint32_t r = single ? pay : ids[start + j];
-      if (is_taken(P.taken, r)) continue;
+      if (!SPEC && is_taken(P.taken, r)) continue;
       if (TRIM && top_live < 0) top_live = j;
       const int wt = within_thresh(r, single);
+      if (SPEC && wt == -2) continue;  // taken
       if (wt < 0) break;  // fingerprint collision (single-read bin)
       verified = true;
       live++; keyok = true; ncand++;
@@ -1036,7 +1160,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
   if (valid) {
     const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
     const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
-    eval_probe<TRIM, BAL>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, s_best, stage, lane, &pend);
+    eval_probe<TRIM, BAL>(P, sx, l, rev, shift, ref_len, key, mix64(key), 0u /* (hash-addressed tables only: the pipeline refuses table_mode = 2 for the one-chain kernels) */, hit, rid, keyok, ncand, other, s_best, stage, lane, &pend);
   }
   bool bal_capped = false;
   if (BAL) {
@@ -1214,6 +1338,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
       const uint64_t *sx = rev ? srev : sref;
       const uint64_t key = lds_window(sx, 2 * off) & kmask;
       const uint64_t hsh = mix64(key);
+      const uint32_t mzv = 0u;  // (hash-addressed tables only)
       // the probe with the lower priority code first: forward dictionary 1 (its shift is wl lower), reverse dictionary 0
 #pragma nounroll
       for (int k = 0; k < 2; k++) {
@@ -1223,7 +1348,7 @@ __device__ __forceinline__ void probe_tail(const DevParams &P, const uint64_t *s
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
         if ((base || k) && *(volatile lds_u32_t *)s_best < (uint32_t)probe_code(sh, rev, l)) continue;  // cannot win any more
-        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, hit, rid, keyok, ncand, other, s_best, stage, lane, nullptr, walk_left);
+        eval_probe<TRIM>(P, sx, l, rev, sh, ref_len, key, hsh, mzv, hit, rid, keyok, ncand, other, s_best, stage, lane, nullptr, walk_left);
         if (STATS) stat[2 * j + l] = (uint16_t)(((int)keyok << 15) | (int)ncand);
         if (TRIM && !hit && ncand >= (uint32_t)MAX_SEARCH) capmin = min(capmin, probe_code(sh, rev, l));
         if (hit) {
@@ -1772,7 +1897,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
       const uint64_t *sx = rev ? srev : sref;
       const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
-      eval_probe<true, true>(P, sx, l, rev, shift, ref_len, key, mix64(key), hit, rid, keyok, ncand, other, (lds_u32_t *)&s_best, stage, lane, &pend);
+      eval_probe<true, true>(P, sx, l, rev, shift, ref_len, key, mix64(key), 0u /* (hash-addressed tables only: the pipeline refuses table_mode = 2 for the one-chain kernels) */, hit, rid, keyok, ncand, other, (lds_u32_t *)&s_best, stage, lane, &pend);
     }
     __syncthreads();
     if (hit && s_best == (uint32_t)code) s_bestrid = rid;  // (eval_probe left the lowest hitting code in s_best)
@@ -2103,12 +2228,21 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
   hipLaunchKernelGGL(k_keys, GRID1(n, 256), dim3(256), 0, st, reads, lens, slot, n, S, dstart, dend, keys, vals);
 }
 void launch_tab_insert(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
-                       DictBuild d1, uint4 *fpt, int bshift) {
+                       DictBuild d1, uint32_t *fpt, int bshift) {
   if (!nmerged) return;
-  hipLaunchKernelGGL(k_tab_insert<false>, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1,
-                     reinterpret_cast<uint32_t *>(fpt), bshift);
-  hipLaunchKernelGGL(k_tab_insert<true>, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1,
-                     reinterpret_cast<uint32_t *>(fpt), bshift);
+  hipLaunchKernelGGL(k_tab_insert<false>, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1, fpt, bshift);
+  hipLaunchKernelGGL(k_tab_insert<true>, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1, fpt, bshift);
+}
+void launch_minz_prepare(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
+                         DictBuild d1, int lshift, uint32_t *bucket, uint64_t *tagpay) {
+  if (!nmerged) return;
+  hipLaunchKernelGGL(k_minz_prepare, GRID1(nmerged, 256), dim3(256), 0, st, mhash, mval, nmerged, d0, d1, lshift, bucket, tagpay);
+}
+void launch_tab_insert_minz(hipStream_t st, const uint32_t *bucket_sorted, const uint64_t *tagpay_sorted, uint64_t nmerged,
+                            uint32_t *fpt, int bshift, uint32_t *marked) {
+  if (!nmerged) return;
+  hipLaunchKernelGGL(k_tab_insert_minz<false>, GRID1(nmerged, 256), dim3(256), 0, st, bucket_sorted, tagpay_sorted, nmerged, fpt, bshift, marked);
+  hipLaunchKernelGGL(k_tab_insert_minz<true>, GRID1(nmerged, 256), dim3(256), 0, st, bucket_sorted, tagpay_sorted, nmerged, fpt, bshift, marked);
 }
 void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag) {
   if (!n) return;
@@ -2119,11 +2253,11 @@ void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndee
   if (!ndeep_host) return;
   hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 4), dim3(256), 0, st, deep, ndeep, urec, const_cast<uint32_t *>(ids), taken);
 }
-void launch_dict_lookup(hipStream_t st, const uint4 *fpt, const ulonglong2 *urec, int bshift, int which,
+void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count) {
   if (!nkeys) return;
-  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, fpt, urec, bshift, which, reads, S, dstart,
+  hipLaunchKernelGGL(k_dict_lookup, GRID1(nkeys, 256), dim3(256), 0, st, tab, urec, which, reads, S, dstart,
                      2 * (dend - dstart + 1), keys, nkeys, start, count);
 }
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
@@ -2254,6 +2388,10 @@ void launch_synth(hipStream_t st, uint8_t *dst, uint32_t n, uint32_t L, uint64_t
 // ------------------------------------------------- rocPRIM plumbing (sort / RLE / scan)
 hipError_t sort_pairs(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
                       const uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, end_bit, st);
+}
+hipError_t sort_pairs_u32_u64(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint32_t *kin, uint32_t *kout,
+                              const uint64_t *vin, uint64_t *vout, size_t n, unsigned end_bit) {
   return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0u, end_bit, st);
 }
 hipError_t rle(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *in, size_t n, uint64_t *uniq,

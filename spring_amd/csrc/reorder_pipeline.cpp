@@ -138,8 +138,10 @@ struct spring_reorder_ctx {
   uint64_t *d_reads = nullptr;
   uint16_t *d_lens = nullptr;
   DictDev dict[2];
-  uint4 *fpt = nullptr;   // one bucket table for both dictionaries (reorder_kernels.hip, tab_find)
-  int bshift = 63;        // bucket = hash >> bshift
+  uint4 *fpt = nullptr;   // one bucket table for both dictionaries (reorder_kernels.hip, tab_find): nb buckets of 32 bytes
+  int bshift = 63;        // plain home bucket = hash >> bshift (nb = 2^(64 - bshift) buckets)
+  int minz = 0, lshift = 31;  // minimizer-addressed table (TabView)
+  uint32_t marked_lines = 0;  // ... lines of it whose keys were sent to the redirect address
   DevParams P;
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
@@ -974,6 +976,13 @@ static double now_ms() {
     if (dbg) { (void)hipStreamSynchronize(st); double t_ = now_ms(); fprintf(stderr, "[dict] %-14s %8.2f ms\n", label, t_ - t_last); t_last = t_; } \
   } while (0)
 
+static TabView tab_view(const spring_reorder_ctx *ctx) {
+  TabView t;
+  t.buck = ctx->fpt;
+  t.bshift = ctx->bshift; t.minz = ctx->minz; t.lshift = ctx->lshift;
+  return t;
+}
+
 int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
   const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;  // stage timings on stderr, no effect on results
   double t_last = now_ms();
@@ -1081,11 +1090,18 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
   // opts.tab_scale = 1 / 2 / 4 overrides (1 = the smallest table, load <= 0.4).
   const uint64_t nk0 = ctx->dict[0].numkeys, nk1 = ctx->dict[1].numkeys, nm = nk0 + nk1;
   const int tab_scale = ctx->o.tab_scale > 0 ? ctx->o.tab_scale : 2;
-  const uint64_t nb = pow2ceil(std::max<uint64_t>(2, (nm * 10 + 15) / 16)) * (uint64_t)pow2ceil(tab_scale);
+  const uint64_t nb = std::max<uint64_t>(8, pow2ceil(std::max<uint64_t>(2, (nm * 10 + 15) / 16)) * (uint64_t)pow2ceil(tab_scale));
   ctx->bshift = 64;
   for (uint64_t v = nb; v > 1; v >>= 1) ctx->bshift--;
+  // Minimizer addressing (TabView, reorder_device.h; opts.table_mode = 2, same results): windows of 32 bases, reads up to
+  // 192 (what k_round_mc keeps a window-minimizer array in LDS for); anything else keeps the hash addressing.
+  ctx->minz = (ctx->dict[0].end - ctx->dict[0].start + 1 == MINZ_WL && ctx->L <= 192 && ctx->o.table_mode == 2) ? 1 : 0;
+  ctx->lshift = 32 - (64 - ctx->bshift - 2);  // lines = nb / 4
+  if (ctx->lshift < 1) return fail(SPRING_REORDER_E_ARG, "build_dict: table too large for minimizer addressing");
+  ctx->stats.table_minz = ctx->minz; ctx->stats.table_marked_lines = 0;
   DMALLOC(ctx->fpt, nb * 32);
   HIPCHK(hipMemsetAsync(ctx->fpt, 0, nb * 32, st));
+  uint32_t *const tab_words = reinterpret_cast<uint32_t *>(ctx->fpt);
   DBG_T("alloc+memset tab");
   if (nm) {
     uint64_t *mv0 = nullptr, *mv1 = nullptr, *mh = nullptr, *mv = nullptr;
@@ -1114,15 +1130,38 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
       db[l].ustart = ustart[l]; db[l].ucount = ucount[l]; db[l].ids = d.ids; db[l].urec = d.urec;
       db[l].deep = d.deep; db[l].ndeep = d.d_ndeep;
     }
-    launch_tab_insert(st, h_in, v_in, nm, db[0], db[1], ctx->fpt, ctx->bshift);
+    uint32_t *bk_in = nullptr, *bk_out = nullptr, *d_marked = nullptr;
+    uint64_t *tp_in = nullptr, *tp_out = nullptr;
+    ctx->marked_lines = 0;
+    void *d_tmp2 = nullptr;
+    if (!ctx->minz) {
+      launch_tab_insert(st, h_in, v_in, nm, db[0], db[1], tab_words, ctx->bshift);
+    } else {
+      DMALLOC(bk_in, nm * 4); DMALLOC(bk_out, nm * 4);
+      DMALLOC(tp_in, nm * 8); DMALLOC(tp_out, nm * 8);
+      launch_minz_prepare(st, h_in, v_in, nm, db[0], db[1], ctx->lshift, bk_in, tp_in);
+      DBG_T("minz prepare");
+      const unsigned end_bit = (unsigned)(64 - ctx->bshift);  // bucket index bits
+      size_t tb = 0;
+      HIPCHK(sort_pairs_u32_u64(st, nullptr, tb, bk_in, bk_out, tp_in, tp_out, nm, end_bit));
+      DMALLOC(d_tmp2, tb);
+      HIPCHK(sort_pairs_u32_u64(st, d_tmp2, tb, bk_in, bk_out, tp_in, tp_out, nm, end_bit));
+      DBG_T("minz sort");
+      DMALLOC(d_marked, 16);
+      HIPCHK(hipMemsetAsync(d_marked, 0, 4, st));
+      launch_tab_insert_minz(st, bk_out, tp_out, nm, tab_words, ctx->bshift, d_marked);
+      HIPCHK(hipMemcpyAsync(&ctx->marked_lines, d_marked, 4, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipGetLastError());
     uint32_t nd[2][2] = {{0, 0}, {0, 0}};
     for (int l = 0; l < 2; l++)
       HIPCHK(hipMemcpyAsync(nd[l], ctx->dict[l].d_ndeep, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int l = 0; l < 2; l++) { ctx->dict[l].ndeep = nd[l][0]; ctx->dict[l].big_reads = nd[l][1]; }
+    ctx->stats.table_marked_lines = ctx->marked_lines;
     DBG_T("insert");
     ctx->dfree(mv0); ctx->dfree(mv1); ctx->dfree(mh); ctx->dfree(mv); ctx->dfree(d_tmp);
+    ctx->dfree(bk_in); ctx->dfree(bk_out); ctx->dfree(tp_in); ctx->dfree(tp_out); ctx->dfree(d_tmp2); ctx->dfree(d_marked);
   }
   for (int l = 0; l < 2; l++) { ctx->dfree(uhash[l]); ctx->dfree(ustart[l]); ctx->dfree(ucount[l]); }
   DBG_T("free temps");
@@ -1145,7 +1184,7 @@ int spring_reorder_dict_lookup(spring_reorder_ctx *ctx, int32_t which, const uin
   std::vector<uint32_t> hs(nkeys), hc(nkeys), hids(d.numreads);
   if (nkeys) {
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)nkeys * 8, hipMemcpyHostToDevice, ctx->st));
-    launch_dict_lookup(ctx->st, ctx->fpt, d.urec, ctx->bshift, which, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
+    launch_dict_lookup(ctx->st, tab_view(ctx), d.urec, which, ctx->d_reads, ctx->S, d.start, d.end, dk, nkeys, ds, dc);
     HIPCHK(hipMemcpyAsync(hs.data(), ds, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(hc.data(), dc, (size_t)nkeys * 4, hipMemcpyDeviceToHost, ctx->st));
   }
@@ -1229,7 +1268,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
     P.urec[l] = ctx->dict[l].urec; P.ids[l] = ctx->dict[l].ids;
   }
-  P.fpt = ctx->fpt; P.bshift = ctx->bshift;
+  P.tab = tab_view(ctx);
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
   P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_wants_deep_kernel(ctx);
@@ -1324,7 +1363,11 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // 184 / 179, 65 536 (70 M) 282 / 293, 65 536 (100 M) 405 / 418 (tools/variant_probe2.py; at 60-100x the one-chain
   // kernel's lead below 40 000 chains is 5-16 %)
   if (K < 49152 && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
+  if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
   if (const char *e = getenv("SPRING_REORDER_MC")) P.mc = atoi(e) != 0;  // A/B runs of the tools (same results)
+  if (ctx->minz && !(fused && P.mc && !ctx->o.collect_stats && !P.deep_bins))
+    return fail(SPRING_REORDER_E_ARG, "table_mode = 2 (minimizer-addressed table) is an experiment of the four-chain round kernel: "
+                "shallow dictionary, at least 49152 chains or fused = 3, no work counters");
   if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !getenv("SPRING_REORDER_PLAN0")) {
     memset(P.plan[0], 0, sizeof(P.plan[0]));   // (fill_params assumed the four-chain kernel: 4 + 8 + 16)
     P.plan[0][0] = 8; P.plan[0][1] = 16;
@@ -1779,13 +1822,14 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   ctx->tid_off_s[T] = as;
   s.unmatched = htot[0]; s.probes = htot[1]; s.keyok = htot[2]; s.cands = htot[3]; s.iterations = htot[4];
   s.lost = htot[5]; s.hits = htot[6]; s.long_searches = htot[7];
+  s.table_minz = ctx->minz; s.table_marked_lines = ctx->marked_lines;
 #ifdef SR_PHASE_TIMING  // experiment builds: per-phase shader clocks of k_round (tools/xbuild.sh, XPIPE=1)
   {
     unsigned long long pt[64] = {0};
     for (uint32_t i = 0; i < K; i++)
       for (int k = 0; k < 64; k++) pt[k] += hc[i].pt[k];
     unsigned long long tot = 0;
-    for (int k = 0; k < 12; k++) tot += pt[k];
+    for (int k = 0; k < 32; k++) tot += pt[k];
     fprintf(stderr, "[phase] bucket: total clocks (share of buckets 0-11), visits, clocks per visit\n");
     for (int k = 0; k < 32; k++)
       if (pt[32 + k])

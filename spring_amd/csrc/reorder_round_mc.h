@@ -6,8 +6,8 @@
 // Why: with one chain per wavefront almost every instruction of a step is wave-uniform bookkeeping or runs with a
 // few active lanes (a candidate compare: one lane; a first probe batch: 32), and the round kernel sits at 64 VGPRs
 // x 8 waves per SIMD with its vector ALU ~65 % busy and its memory steps queueing behind each other (DESIGN.md
-// section 6).  Here every instruction serves four chains, the kernel runs 4 waves per SIMD with a 128-VGPR budget
-// (16 chains per SIMD in flight instead of 8) and a lane keeps several independent table fetches in flight.
+// section 6).  Here every instruction serves four chains, the kernel runs 5 waves per SIMD with a 96-VGPR budget
+// (20 chains per SIMD in flight instead of 8) and a lane keeps several independent table fetches in flight.
 // The code is plain SIMT over a 16-lane group: values that are uniform per chain are ordinary per-lane variables,
 // branches on them are group-uniform, cross-lane traffic is width-16 shuffles / ballots shifted to the row.
 //
@@ -21,13 +21,21 @@ namespace mc {
 constexpr int G = 16;        // lanes per chain
 constexpr int CPW = 64 / G;  // chains per wavefront
 
-struct GLds {                       // per chain
-  uint64_t refs[2][LDS_LIMBS];      // ref / revref, LDS_PAD zero limbs either side (lds_window)
-  uint64_t rd[18];                  // the read being merged, one zero limb either side
-  uint64_t nref[16];                // the speculative update's consensus, 4 bases per byte (= the limb format)
+// per chain; sized by the instantiation (NQ = 3: reads up to 192 bases, 6 limbs, shifts up to 96 -> 4 pad limbs) so that
+// the block stays inside 6 LDS granules of 1280 bytes = 20 blocks per CU at 5 waves per SIMD with the minimizer array
+template <int NQ>
+struct GLds {
+  static constexpr int WMAX = NQ <= 3 ? 6 : 16;      // limbs of a read
+  static constexpr int PAD = NQ <= 3 ? 4 : LDS_PAD;  // zero limbs either side of ref / revref (lds_window)
+  static constexpr int LIMBS = WMAX + 2 * PAD;
+  static constexpr int MZ = NQ <= 3 ? 164 : 4;       // window minimizers (TabView::minz: reads up to 192 bases only)
+  uint64_t refs[2][LIMBS];          // ref / revref
+  uint64_t rd[WMAX + 2];            // the read being merged, one zero limb either side
+  uint64_t nref[WMAX];              // the speculative update's consensus, 4 bases per byte (= the limb format)
   uint8_t pres[128];                // probe_tail: "the other dictionary may hold this window", by probe code
   uint32_t best;                    // lowest priority code that has hit in the running batch (eval_probe)
   uint32_t pad[3];
+  uint32_t mz[MZ];                  // mz[w] = minz value of the consensus window at offset w (minz_mc)
 };
 
 __device__ __forceinline__ int gmin_i(int v) {
@@ -73,7 +81,7 @@ typedef uint32_t u32x4a_t __attribute__((ext_vector_type(4), aligned(4)));
 // 16-byte store per quad; the new consensus goes to S.nref four bases per byte -- the limb format itself.
 // Anything else (wide counts, the aliasing case of the reference) takes the generic per-position path.
 template <int NQ>
-__device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds &S, uint32_t rid, int n, bool reset,
+__device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<NQ> &S, uint32_t rid, int n, bool reset,
                                          bool rev, int shift, int R, int cb, bool cur_wide, bool out_wide,
                                          bool &overflow, int gl) {
   const int M = P.L, W = P.W;
@@ -99,7 +107,7 @@ __device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds &
     old[k] = (u32x4a_t)(0u);
     if (fast && p0 < cpy_hi) old[k] = *reinterpret_cast<const u32x4a_t *>(cur8 + p0 + src_off);
   }
-  S.rd[1 + gl] = myl;
+  if (gl < GLds<NQ>::WMAX) S.rd[1 + gl] = myl;
   wave_sync();
   const uint64_t *rd = S.rd;
 
@@ -170,18 +178,20 @@ __device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds &
       }
 #undef MC_LOAD_CNT
     }
-    if (q < 128) reinterpret_cast<uint8_t *>(S.nref)[q] = (uint8_t)codes;
+    if (q < 8 * GLds<NQ>::WMAX) reinterpret_cast<uint8_t *>(S.nref)[q] = (uint8_t)codes;
   }
   overflow = gballot(ovf, (int)threadIdx.x) != 0;
   return Rn;
 }
 
 // commit of a speculative update: S.nref -> ref (LDS + global), revref = its reverse complement (LDS + global)
-__device__ __forceinline__ void commit_consensus(const DevParams &P, GLds &S, Chain *c, int R, int gl) {
+template <int NQ>
+__device__ __forceinline__ void commit_consensus(const DevParams &P, GLds<NQ> &S, Chain *c, int R, int gl) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD;
   wave_sync();
   const bool in = gl < P.W;
   const uint64_t limb = in ? S.nref[gl] : 0ull;
-  S.refs[0][LDS_PAD + gl] = limb;
+  if (gl < GLds<NQ>::WMAX) S.refs[0][LDS_PAD + gl] = limb;
   if (in) c->ref[gl] = limb;
   wave_sync();
   uint64_t rl = 0;
@@ -193,7 +203,7 @@ __device__ __forceinline__ void commit_consensus(const DevParams &P, GLds &S, Ch
     const int nv = R - 32 * gl;
     rl = ~x & (nv >= 32 ? ~0ull : ((1ull << (2 * nv)) - 1));
   }
-  S.refs[1][LDS_PAD + gl] = rl;
+  if (gl < GLds<NQ>::WMAX) S.refs[1][LDS_PAD + gl] = rl;
   if (in) c->revref[gl] = rl;
   wave_sync();
 }
@@ -234,7 +244,7 @@ __device__ __forceinline__ void emit_single_mc(const DevParams &P, ChainHot &h, 
 
 // phase B of one chain (apply_step with the shared state deferred to k_mg_mark).  false: the chain is done.
 template <int NQ>
-__device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, GLds &S, int gl) {
+__device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, GLds<NQ> &S, int gl) {
   const int kind = h.prop_kind;
   if (kind == PROP_FRESH) return true;  // first round: nothing proposed yet
   if (h.finishing) {  // seed-needing chain found the pool empty
@@ -270,7 +280,7 @@ __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t 
     return true;
   }
   if (do_upd) {
-    commit_consensus(P, S, c, R_new, gl);
+    commit_consensus<NQ>(P, S, c, R_new, gl);
     h.ref_len = R_new;
     h.cnt_buf ^= 1;
     h.cnt_wide = nw;
@@ -382,28 +392,84 @@ __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t c
 
 constexpr int INF_CODE = 0x7fffffff;
 
-// quick verdict on a fetched tag quad: can dictionary l hold the key (a slot with its fingerprint, or a full
-// bucket whose run may continue in the next one)?  `other`: same question for the other dictionary.
-__device__ __forceinline__ bool tags_may_hold(const uint4 &t, uint64_t hsh, int l, bool &other) {
+#ifdef SR_EXP_FAKE
+// index (in 16-byte units) of the quad a probe of the window at consensus offset `o` fetches in the locality experiment
+__device__ __forceinline__ uint64_t exp_fake_quad(const DevParams &P, const uint64_t *sref, int o, uint64_t key) {
+  const uint32_t grp = SR_EXP_FAKE == 2 ? (uint32_t)(o >> 3) : (uint32_t)o;
+  uint32_t hh = ((uint32_t)sref[0] * 2654435761u) ^ (grp * 0x9E3779B1u);
+  hh ^= hh >> 15; hh *= 0x2c1b3c6du; hh ^= hh >> 12; hh *= 0x297a2d39u; hh ^= hh >> 15;
+  const uint64_t nl = (1ull << (64 - P.tab.bshift)) >> 1;  // 64-byte lines of the table
+  return (uint64_t)(hh & (uint32_t)(nl - 1)) * 4 + ((mix64(key) >> 30) & 3);
+}
+#endif
+
+// One step of a probe's bucket chain on the tags alone: t = the tags of a bucket of the chain of the key with hash hsh.
+// 1: a slot with the fingerprint of dictionary l (a closer look is needed: eval_probe); 2: none, and the bucket is
+// full -- the chain goes on in the next bucket; 0: none, and the chain ends here: the key is absent from dictionary l.
+// `other`: a slot with the fingerprint of the OTHER dictionary was seen (what the tail wants to know about this window).
+// slot (only when 1): index of the first such slot | its `single` bit << 2.
+__device__ __forceinline__ int tags_step(const uint4 &t, uint64_t hsh, int l, bool &other, int &slot) {
   const uint32_t mine = (fp30_of(hsh) << 2) | ((uint32_t)l << 1), theirs = mine ^ 2u;
   const bool full = t.w != 0;
-  other = (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || (t.w & ~1u) == theirs || full;
-  return (t.x & ~1u) == mine || (t.y & ~1u) == mine || (t.z & ~1u) == mine || (t.w & ~1u) == mine || full;
+  other = other || (t.x & ~1u) == theirs || (t.y & ~1u) == theirs || (t.z & ~1u) == theirs || (t.w & ~1u) == theirs;
+  const uint32_t m = (uint32_t)((t.x & ~1u) == mine) | ((uint32_t)((t.y & ~1u) == mine) << 1) |
+                     ((uint32_t)((t.z & ~1u) == mine) << 2) | ((uint32_t)((t.w & ~1u) == mine) << 3);
+  if (m) {
+    other = other || full;  // (the other dictionary's slot may sit in a later bucket of the chain)
+    const int I = __ffs((int)m) - 1;
+    const uint32_t Tg = I == 0 ? t.x : I == 1 ? t.y : I == 2 ? t.z : t.w;
+    slot = I | (int)((Tg & 1u) << 2);
+    return 1;
+  }
+  return full ? 2 : 0;
+}
+constexpr int QUICK_HOPS = 2;  // buckets past the home bucket (or the redirect bucket of a marked neighbourhood) looked at on the tags alone
+
+// Window minimizers of a chain's consensus (TabView::minz): S.mz[w] = minz_of_key(the 32-mer at offset w of ref),
+// w in [0, R - 32].  The reverse consensus needs no array of its own: kmer_order is strand-symmetric, so the window
+// at offset o of revref has the k-mers of the ref window at offset R - 32 - o.  Lane g of row j holds the order
+// value of the k-mer at q = 16 j + g; a window has 17 = 16 + 1 k-mers, so its minimum is the suffix minimum of one row
+// from lane g on and the prefix minimum of the next row up to lane g: two 4-step scans per row, no LDS round trip.
+template <int NQ>
+__device__ __forceinline__ void minz_mc(GLds<NQ> &S, int R, int gl) {
+  static_assert(MINZ_WL - MINZ_K + 1 == G + 1, "a window's k-mers = one row of lanes + 1");
+  const uint64_t *sref = S.refs[0] + GLds<NQ>::PAD;
+  uint32_t sfx_prev = 0xffffffffu;
+  for (int j = 0; j == 0 || G * (j - 1) + MINZ_WL <= R; j++) {
+    const int q = G * j + gl;
+    uint32_t a = 0xffffffffu;
+    if (q + MINZ_K <= R) a = kmer_order((uint32_t)lds_window(sref, 2 * q));
+    // inclusive prefix / suffix minimum over the 16-lane row: DPP row shifts (a lane shifted in from outside the row
+    // keeps the identity 0xffffffff: bound_ctrl off, old = identity), one VALU instruction per step, no LDS
+    uint32_t pfx = a, sfx = a;
+#define MC_DPP_MIN(V, CTRL) V = min(V, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)V, CTRL, 0xf, 0xf, false))
+    MC_DPP_MIN(pfx, 0x111); MC_DPP_MIN(pfx, 0x112); MC_DPP_MIN(pfx, 0x114); MC_DPP_MIN(pfx, 0x118);  // row_shr:1,2,4,8
+    MC_DPP_MIN(sfx, 0x101); MC_DPP_MIN(sfx, 0x102); MC_DPP_MIN(sfx, 0x104); MC_DPP_MIN(sfx, 0x108);  // row_shl:1,2,4,8
+#undef MC_DPP_MIN
+    const int w = G * (j - 1) + gl;
+    if (j > 0 && w + MINZ_WL <= R && w < GLds<NQ>::MZ) S.mz[w] = fmix32(min(sfx_prev, pfx));
+    sfx_prev = sfx;
+  }
 }
 
 // probes with priority codes [c_lo, c_hi) (code = shift << 2 | rev << 1 | dict; at most 4 * G of them): lane gl takes
 // codes c_lo + gl + 16 i, fetches the tag quads of all of them first, and only walks into eval_probe where the
 // quad does not already prove the key absent (2 % of the probes).  Winner = lowest code that hit.
-__device__ __forceinline__ void batch_mc(const DevParams &P, GLds &S, lds_u32_t *stage, int c_lo, int c_hi, int ref_len,
+template <int NQ>
+__device__ __forceinline__ void batch_mc(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, int c_lo, int c_hi, int ref_len,
                                          int lane, int gl, int &wcode, uint32_t &wrid) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD;
   const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
+  const bool minz = P.tab.minz != 0;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   lds_u32_t *s_best = (lds_u32_t *)&S.best;
   if (gl == 0) *s_best = (uint32_t)INF_CODE;
   wave_sync();
+  const uint32_t bmask = (uint32_t)bucket_mask(P.tab.bshift);  // (k_round_mc runs on tables of at most 2^32 buckets)
   uint4 tg[4];
   uint64_t key[4];
+  uint32_t bk[4];
   bool val[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -411,22 +477,74 @@ __device__ __forceinline__ void batch_mc(const DevParams &P, GLds &S, lds_u32_t 
     const int l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
     val[i] = code < c_hi && probe_valid(P, l, rev, shift, ref_len);
     key[i] = 0;
+    bk[i] = 0;
     tg[i] = make_uint4(0, 0, 0, 0);
     if (val[i]) {
       const int ds = l ? P.dstart[1] : P.dstart[0];
       key[i] = lds_window(rev ? srev : sref, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
-      tg[i] = P.fpt[bucket_of(mix64(key[i]), P.bshift) * 2];
+      const int o = rev ? ds - shift : ds + shift;  // the window's offset in its strand
+#ifdef SR_EXP_FAKE  // experiment (tools/xbuild.sh -DSR_EXP_FAKE=1|2): every probe absent; 2 = runs of 8 windows share a 64-byte line
+      tg[i] = P.tab.buck[exp_fake_quad(P, sref, rev ? ref_len - P.wl - o : o, key[i])];
+#else
+      bk[i] = (uint32_t)tab_home(P.tab, mix64(key[i]), minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u);
+      tg[i] = P.tab.buck[2 * (uint64_t)bk[i]];
+#endif
     }
   }
-  // which of this lane's probes need a closer look; `pres` for the tail
-  uint32_t pend = 0;
+  PT(25);   // (experiment builds: batch set-up and address arithmetic | tag fetch | judge + hops | passes)
+  PTW(26);
+  // Which of this lane's probes need a closer look (pend), judged on the tags alone: a probe whose bucket is full without a
+  // slot of its key (5 % of the probes of a minimizer-addressed table, 0.2 % otherwise) or whose neighbourhood is marked
+  // follows its chain here, on tags that mostly sit in the cache line just fetched -- a pass through eval_probe is a
+  // chain of four dependent memory steps that every chain of the wavefront waits for.  `pres` for the tail.
+  // pre: 4 bits per probe, kind | slot << 2 of the key's first slot when that is in its home bucket (eval_probe then starts
+  // at the payload word instead of walking the chain again)
+  uint32_t pend = 0, cont = 0, redir = 0, oth = 0, pre = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (!val[i]) continue;
+    const int code = c_lo + gl + G * i;
+    if (minz && tg[i].x == TAG_MARK) { cont |= 1u << i; redir |= 1u << i; continue; }
+    bool other = false;
+    int slot = 0;
+    const int st = tags_step(tg[i], mix64(key[i]), code & 1, other, slot);
+    if (other) oth |= 1u << i;
+    if (st == 1) { pend |= 1u << i; pre |= (uint32_t)((1 + ((slot >> 2) & 1)) | ((slot & 3) << 2)) << (4 * i); }
+    else if (st == 2) cont |= 1u << i;
+  }
+  for (int hop = 0; hop < QUICK_HOPS && __ballot(cont != 0); hop++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if ((cont >> i) & 1u) {
+        bk[i] = ((redir >> i) & 1u) ? (uint32_t)tab_redirect(P.tab, mix64(key[i])) : ((bk[i] + 1u) & bmask);
+        tg[i] = P.tab.buck[2 * (uint64_t)bk[i]];
+      }
+    redir = 0;
+    const uint32_t c2 = cont;
+    cont = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if ((c2 >> i) & 1u) {
+        const int code = c_lo + gl + G * i;
+        bool other = false;
+        int slot = 0;
+        const int st = tags_step(tg[i], mix64(key[i]), code & 1, other, slot);
+        if (other) oth |= 1u << i;
+        if (st == 1) pend |= 1u << i;  // (past the home bucket: eval_probe walks the chain itself)
+        else if (st == 2) cont |= 1u << i;
+      }
+  }
+  pend |= cont;  // chains longer than that: eval_probe walks them
+  oth |= cont;
+  PTW(27);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int code = c_lo + gl + G * i;
-    bool other = false;
-    if (val[i] && tags_may_hold(tg[i], mix64(key[i]), code & 1, other)) pend |= 1u << i;
-    if (code < c_hi && code < 128) S.pres[code] = other ? 1 : 0;
+    if (code < c_hi && code < 128) S.pres[code] = ((oth >> i) & 1u) ? 1 : 0;
   }
+#ifdef SR_EXP_FAKE
+  pend = tg[0].x == 0x12345u && tg[1].y == 0x54321u && tg[2].z == 77u && tg[3].w == 99u;  // (keeps the loads alive) never
+#endif
   // the closer looks of all lanes run together, one per lane and pass, lowest code first (a pass is a chain of
   // dependent loads: record / taken bit / candidate read -- four chains' worth of them in flight at once)
   int best = INF_CODE;
@@ -437,11 +555,15 @@ __device__ __forceinline__ void batch_mc(const DevParams &P, GLds &S, lds_u32_t 
       pend &= pend - 1;
       const int code = c_lo + gl + G * i;
       const int l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
-      const uint64_t k = i == 0 ? key[0] : i == 1 ? key[1] : i == 2 ? key[2] : key[3];
       if (!(*(volatile lds_u32_t *)s_best < (uint32_t)code)) {
         bool hit = false, keyok = false, other = false;
         uint32_t rid = 0, ncand = 0;
-        eval_probe<false>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k), hit, rid, keyok, ncand, other, s_best, stage, lane);
+        // (key, hash and minimizer are taken from LDS again: nothing of the quick phase stays live across the passes)
+        const int ds = l ? P.dstart[1] : P.dstart[0], o = rev ? ds - shift : ds + shift;
+        const uint64_t k = lds_window(rev ? srev : sref, 2 * o) & kmask;
+        eval_probe<false>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k),
+                                       minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u, hit, rid, keyok, ncand, other, s_best, stage,
+                                       lane, nullptr, nullptr, (int)((pre >> (4 * i)) & 15u));
         if (other && code < 128) S.pres[code] = 1;
         if (hit) { best = code; brid = rid; pend = 0; }
       } else pend = 0;  // a lower code has hit: nothing of this lane can win any more
@@ -453,9 +575,12 @@ __device__ __forceinline__ void batch_mc(const DevParams &P, GLds &S, lds_u32_t 
 }
 
 // every remaining probe (shifts [t0, maxshift)), one table fetch per distinct consensus window (see probe_tail)
-__device__ __forceinline__ void tail_mc(const DevParams &P, GLds &S, lds_u32_t *stage, int t0, int ref_len, int lane, int gl,
+template <int NQ>
+__device__ __forceinline__ void tail_mc(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, int t0, int ref_len, int lane, int gl,
                                         int &wcode, uint32_t &wrid) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD;
   const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
+  const bool minz = P.tab.minz != 0;
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
   const uint64_t kmask = 2 * wl < 64 ? ((1ull << (2 * wl)) - 1) : ~0ull;
   lds_u32_t *s_best = (lds_u32_t *)&S.best;
@@ -467,6 +592,7 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds &S, lds_u32_t *
   for (int base = 0; base < 2 * nF; base += 4 * G) {
     uint4 tg[4];
     uint64_t key[4];
+    uint32_t bk[4];
     uint32_t desc[4];  // bit 31 rev, 30 v1, 29 v0, low bits i
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -490,36 +616,89 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds &S, lds_u32_t *
       }
       desc[k] = ((uint32_t)rev << 31) | ((uint32_t)v1 << 30) | ((uint32_t)v0 << 29) | (uint32_t)i;
       key[k] = 0;
+      bk[k] = 0;
       tg[k] = make_uint4(0, 0, 0, 0);
       if (v0 || v1) {
         const int off = rev ? s1 - (t0 + i) : s0 + t0 + i;
         key[k] = lds_window(rev ? srev : sref, 2 * off) & kmask;
-        tg[k] = P.fpt[bucket_of(mix64(key[k]), P.bshift) * 2];
+#ifdef SR_EXP_FAKE
+        tg[k] = P.tab.buck[exp_fake_quad(P, sref, rev ? ref_len - wl - off : off, key[k])];
+#else
+        bk[k] = (uint32_t)tab_home(P.tab, mix64(key[k]), minz ? S.mz[rev ? ref_len - MINZ_WL - off : off] : 0u);
+        tg[k] = P.tab.buck[2 * (uint64_t)bk[k]];
+#endif
       }
     }
+    PT(28);
+    PTW(29);
     // pending (window, dictionary) pairs of this lane: bit 2k + j, j = 0 the probe with the lower priority code of
-    // window k (forward: dictionary 1, its shift is wl lower; reverse: dictionary 0)
-    uint32_t pend = 0;
+    // window k (forward: dictionary 1, its shift is wl lower; reverse: dictionary 0).  Judged on the tags alone, the
+    // chain of a full bucket followed here (batch_mc); `un`: pairs not decided yet; pre: 4 bits per pair as in batch_mc
+    uint32_t pend = 0, un = 0, cont = 0, redir = 0, pre = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t e = desc[k];
       if (!(e & (3u << 29))) continue;
       const int rev = (int)(e >> 31);
-      const uint64_t hsh = mix64(key[k]);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int l = rev ? j : 1 - j;
+        if ((e >> (29 + l)) & 1u) un |= 1u << (2 * k + j);
+      }
+      if (minz && tg[k].x == TAG_MARK) { cont |= 1u << k; redir |= 1u << k; continue; }
+      const uint64_t hsh = mix64(key[k]);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (!((un >> (2 * k + j)) & 1u)) continue;
+        const int l = rev ? j : 1 - j;
         bool other = false;
-        if (((e >> (29 + l)) & 1u) && tags_may_hold(tg[k], hsh, l, other)) pend |= 1u << (2 * k + j);
+        int slot = 0;
+        const int st = tags_step(tg[k], hsh, l, other, slot);
+        if (st == 1) { pend |= 1u << (2 * k + j); pre |= (uint32_t)((1 + ((slot >> 2) & 1)) | ((slot & 3) << 2)) << (4 * (2 * k + j)); }
+        if (st != 2) un &= ~(1u << (2 * k + j));
+      }
+      if ((un >> (2 * k)) & 3u) cont |= 1u << k;
+    }
+    for (int hop = 0; hop < QUICK_HOPS && __ballot(cont != 0); hop++) {
+      const uint32_t bmask = (uint32_t)bucket_mask(P.tab.bshift);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if ((cont >> k) & 1u) {
+          bk[k] = ((redir >> k) & 1u) ? (uint32_t)tab_redirect(P.tab, mix64(key[k])) : ((bk[k] + 1u) & bmask);
+          tg[k] = P.tab.buck[2 * (uint64_t)bk[k]];
+        }
+      redir = 0;
+      const uint32_t c2 = cont;
+      cont = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (!((c2 >> k) & 1u)) continue;
+        const int rev = (int)(desc[k] >> 31);
+        const uint64_t hsh = mix64(key[k]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (!((un >> (2 * k + j)) & 1u)) continue;
+          const int l = rev ? j : 1 - j;
+          bool other = false;
+          int slot = 0;
+          const int st = tags_step(tg[k], hsh, l, other, slot);
+          if (st == 1) pend |= 1u << (2 * k + j);
+          if (st != 2) un &= ~(1u << (2 * k + j));
+        }
+        if ((un >> (2 * k)) & 3u) cont |= 1u << k;
       }
     }
+    pend |= un;  // chains longer than that: eval_probe walks them
+    PTW(30);
+#ifdef SR_EXP_FAKE
+    pend = tg[0].x == 0x12345u && tg[1].y == 0x54321u && tg[2].z == 77u && tg[3].w == 99u;
+#endif
     while (__ballot(pend != 0)) {
       if (pend) {
         const int b = __ffs((int)pend) - 1;
         pend &= pend - 1;
         const int k = b >> 1, j = b & 1;
         const uint32_t e = k == 0 ? desc[0] : k == 1 ? desc[1] : k == 2 ? desc[2] : desc[3];
-        const uint64_t ky = k == 0 ? key[0] : k == 1 ? key[1] : k == 2 ? key[2] : key[3];
         const int rev = (int)(e >> 31), i = (int)(e & 0xfffffu);
         const int l = rev ? j : 1 - j;
         const int sh0 = rev ? t0 + i - wl : t0 + i, sh1 = rev ? t0 + i : t0 + i - wl;
@@ -527,7 +706,11 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds &S, lds_u32_t *
         if (code < best && !(*(volatile lds_u32_t *)s_best < (uint32_t)code)) {
           bool hit = false, keyok = false, other = false;
           uint32_t rid = 0, ncand = 0;
-          eval_probe<false>(P, rev ? srev : sref, l, rev, sh, ref_len, ky, mix64(ky), hit, rid, keyok, ncand, other, s_best, stage, lane);
+          const int off = rev ? s1 - (t0 + i) : s0 + t0 + i;
+          const uint64_t ky = lds_window(rev ? srev : sref, 2 * off) & kmask;
+          eval_probe<false>(P, rev ? srev : sref, l, rev, sh, ref_len, ky, mix64(ky),
+                                         minz ? S.mz[rev ? ref_len - MINZ_WL - off : off] : 0u, hit, rid, keyok, ncand, other, s_best,
+                                         stage, lane, nullptr, nullptr, (int)((pre >> (4 * b)) & 15u));
           if (hit) { best = code; brid = rid; }
         }
       }
@@ -539,8 +722,8 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds &S, lds_u32_t *
 }
 
 // phase A of one chain (search_step: proposal word + direct reservation unless MG)
-template <bool MG>
-__device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds &S, lds_u32_t *stage,
+template <int NQ, bool MG>
+__device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds<NQ> &S, lds_u32_t *stage,
                                           int lane, int gl) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
@@ -560,6 +743,7 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
       if (gl == 0) P.prop[cid] = ((unsigned long long)PK_NOSEED << 32) | (is_last ? PK_CURSOR_BIT : 0ull);
     }
     store_hot(c, h, gl, 2, 4);
+    PT(23);
     return;
   }
   if (!h.retrying) {  // iteration start bookkeeping (reorder.h:433-439), once per iteration
@@ -577,18 +761,22 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
   }
   const int ref_len = h.ref_len;
   const int wide = (h.prev_unmatched && P.seed_wide) ? 1 : 0;
+  if (P.tab.minz) minz_mc<NQ>(S, ref_len, gl);  // (batch_mc synchronises before it reads S.mz)
+  PT(18);
   int wcode = INF_CODE, t0 = 0;
   uint32_t wrid = 0;
   for (int ph = 0; ph < 6 && t0 < P.maxshift; ph++) {
     const int w = wide ? P.plan[1][ph] : P.plan[0][ph];
     if (w <= 0) break;
-    batch_mc(P, S, stage, 4 * t0, 4 * (t0 + w), ref_len, lane, gl, wcode, wrid);
+    batch_mc<NQ>(P, S, stage, 4 * t0, 4 * (t0 + w), ref_len, lane, gl, wcode, wrid);
+    if (ph == 0) PT(19); else if (ph == 1) PT(20); else PT(21);
     t0 += w;
     if (wcode != INF_CODE) break;
   }
   if (wcode == INF_CODE && t0 < P.maxshift) {
     wave_sync();  // pres
-    tail_mc(P, S, stage, t0, ref_len, lane, gl, wcode, wrid);
+    tail_mc<NQ>(P, S, stage, t0, ref_len, lane, gl, wcode, wrid);
+    PT(22);
   }
   if (wcode != INF_CODE) {
     h.prop_rid = wrid;
@@ -615,9 +803,16 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
 #endif
 template <int NQ, bool MG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES, SR_MC_WAVES))) void k_round_mc(DevParams P) {
-  __shared__ mc::GLds s_g[mc::CPW];
+  typedef mc::GLds<NQ> GL;
+  __shared__ GL s_g[mc::CPW];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
   const int lane = threadIdx.x, g = lane >> 4, gl = lane & (mc::G - 1);
+#ifdef SR_PHASE_TIMING
+  for (int i = lane; i < 66; i += 64) g_pt_lds[i] = 0;
+  wave_sync();
+  if (lane == 0) g_pt_lds[64] = (uint32_t)clock64();
+  wave_sync();
+#endif
   // this wavefront's chains: four entries of one class of one list segment (classes in the order 0, 1, 2, 3).
   // Tried and dropped (profiles/r03_experiments.txt): one global class-major list of wavefront-loads built by an extra
   // one-block kernel (longest classes dispatched first: 419 vs 417 ms, nothing), with empty placeholder blocks instead
@@ -639,18 +834,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES,
   }
   const uint32_t cid = P.c0 + li;
   Chain *c = &P.chains[li];
-  mc::GLds &S = s_g[g];
+  GL &S = s_g[g];
   ChainHot h;
   {
     const uint4 *hq = reinterpret_cast<const uint4 *>(&c->h);
     const uint4 q0 = hq[0], q1 = hq[1], q2 = hq[2], q3 = hq[3];
-    for (int i = gl; i < LDS_LIMBS; i += mc::G) {
-      const int k = i - LDS_PAD;
+    for (int i = gl; i < GL::LIMBS; i += mc::G) {
+      const int k = i - GL::PAD;
       const bool in = k >= 0 && k < P.W;
       S.refs[0][i] = in ? c->ref[k] : 0ull;
       S.refs[1][i] = in ? c->revref[k] : 0ull;
     }
-    if (gl < 2) S.rd[gl ? 17 : 0] = 0ull;
+    if (gl < 2) S.rd[gl ? GL::WMAX + 1 : 0] = 0ull;
     h.ref_pos = (long long)(((unsigned long long)q0.y << 32) | q0.x);
     h.ref_len = (int32_t)q0.z; h.e_slot = q0.w;
     h.prev = q1.x; h.first_rid = q1.y; h.n_emit = q1.z; h.n_single = q1.w;
@@ -663,11 +858,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES,
     if (gl == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
+  PTW(16);
   if (!mc::apply_mc<NQ>(P, c, cid, li, h, S, gl)) {
     if (gl == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
-  mc::search_mc<MG>(P, c, cid, h, S, (lds_u32_t *)s_stage, lane, gl);
+  PT(17);
+  mc::search_mc<NQ, MG>(P, c, cid, h, S, (lds_u32_t *)s_stage, lane, gl);
+  PTW(24);
+#ifdef SR_PHASE_TIMING  // (experiment builds) the wavefront's table goes to the chain of its first lane still here
+  {
+    wave_sync();
+    const unsigned long long ex = __ballot(1);
+    if (lane == __ffsll(ex) - 1)
+      for (int i = 0; i < 64; i++) c->pt[i] += g_pt_lds[i];
+  }
+#endif
 }
 
 #endif

@@ -41,6 +41,7 @@ class ReorderOpts:
     long_budget: int = 0      # deep pools: compare passes before a search goes to k_long (0 = default, -1 = never)
     devices: tuple = ()       # call_reorder on several GPUs: one pool over these device ordinals (may repeat: host transport)
     mg_host_transport: bool = False
+    table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
 
     def to_c(self):
         o = _lib.Opts()
@@ -52,6 +53,9 @@ class ReorderOpts:
         o.search_wpb, o.dbg_search_lds, o.dbg_apply_lds = self.search_wpb, self.dbg_search_lds, self.dbg_apply_lds
         o.fused, o.deep_bins = self.fused, self.deep_bins
         o.long_budget = self.long_budget
+        if len(self.devices) > 8:
+            raise ValueError("at most 8 devices")
+        o.table_mode = self.table_mode
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d

@@ -73,6 +73,21 @@ def named_set(name):
         a = np.repeat(base, 30, axis=0)
         np.random.default_rng(5).shuffle(a, axis=0)
         return rs.pack_fixed(a), a.shape[0], 100
+    if name == "tandem":  # a 40-base unit repeated 400 times with 4 % point mutations per copy: thousands of distinct keys
+        # share the unit's few 16-mers as minimizers -> over-subscribed table lines (TabView::minz, TAG_MARK + redirect)
+        rng = np.random.default_rng(117)
+        unit = rng.integers(0, 4, 40, dtype=np.uint8)
+        g = np.tile(unit, 400)
+        m = rng.random(len(g)) < 0.04
+        g[m] = (g[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) % 4
+        n, L = 6000, 120
+        pos = rng.integers(0, len(g) - L + 1, n)
+        r = g[pos[:, None] + np.arange(L)[None, :]]
+        e = rng.random((n, L)) < 0.01
+        r = np.where(e, (r + rng.integers(1, 4, (n, L), dtype=np.uint8)) % 4, r).astype(np.uint8)
+        rc = rng.random(n) < 0.5
+        r[rc] = (3 - r[rc])[:, ::-1]
+        return rs.pack_fixed(np.frombuffer(b"ACGT", dtype=np.uint8)[r]), n, L
     if name == "one":
         a = rs.np_reads(111, 1000, 1, 100, 0.0)
         return rs.pack_fixed(a), 1, 100
@@ -86,7 +101,7 @@ def named_set(name):
 
 SMALL_SETS = ["test_1", "test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "syn1k_511", "syn2k_20",
               "var_long", "var2k", "var_short",
-              "heavy", "repeat10k", "dups", "one", "two_same", "empty"]
+              "heavy", "repeat10k", "dups", "tandem", "one", "two_same", "empty"]
 
 
 def check_invariants(res, read, ln, L, n):

@@ -48,7 +48,7 @@ def test_unpack_matches_readDnaFile(name):
 
 
 @pytest.mark.parametrize("name", ["test_1+2", "syn2k_100", "syn5k_150", "syn3k_64", "syn2k_251", "var2k",
-                                  "var_short", "heavy", "dups"])
+                                  "var_short", "heavy", "dups", "tandem"])
 def test_dictionary_matches_constructdictionary(name):
     sa = _sa()
     dna, n, L = named_set(name)
@@ -66,6 +66,42 @@ def test_dictionary_matches_constructdictionary(name):
             assert np.array_equal(sizes[:len(keys)], np.diff(sp).astype(np.uint32))
             assert np.all(sizes[len(keys):] == 0xFFFFFFFF)
             assert np.array_equal(gids[:len(ids)], ids)  # same ids, same in-bin order, bins in key order
+
+
+@pytest.mark.parametrize("name", ["tandem", "repeat10k", "syn5k_150", "var2k"])
+def test_minimizer_table_modes_agree(name):
+    """The dictionary table addressed by the key's hash (default) and by its minimizer (table_mode = 2; applies to 32-base
+    windows, reads up to 192 bases; an experiment of the four-chain round kernel, which keeps the window minimizers of a
+    consensus in LDS): same streams as the rounds oracle.  `tandem` is built so
+    that table neighbourhoods are over-subscribed: their keys live at the redirect address (TAG_MARK)."""
+    sa = _sa()
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    with sa.ReorderStage(sa.ReorderOpts(table_mode=2)) as s:
+        s.load_dna(dna, n, L)
+        s.build_dict()
+        st = s.stats()
+        for which in (0, 1):  # every key's bin through the minimizer-addressed table, incl. redirected keys
+            keys, sp, ids = po.build_dict(read, ln, L, which)
+            sizes, gids = s.dict_lookup(which, keys)
+            assert np.array_equal(sizes, np.diff(sp).astype(np.uint32)) and np.array_equal(gids[:len(ids)], ids)
+    assert st["table_minz"] == 1
+    if name == "tandem":
+        assert st["table_marked_lines"] > 0
+    with sa.ReorderStage() as s:
+        s.load_dna(dna, n, L)
+        s.build_dict()
+        assert s.stats()["table_minz"] == 0
+    for K, T in ((1, 1), (32, 2)):
+        want = po.reorder_rounds(read, ln, L, K, T)
+        # (deep_bins = -1: `tandem` and `repeat10k` average enough reads per key for the deep-bin kernel variant, which the
+        # minimizer experiment does not cover)
+        for kw in (dict(fused=3, table_mode=2, deep_bins=-1), dict(fused=3, table_mode=2, tab_scale=4, deep_bins=-1),
+                   dict(fused=3, table_mode=2, first_shifts=16, deep_bins=-1), dict(fused=3, deep_bins=-1), dict(fused=2)):
+            _same(_gpu(name, K, T, **kw), want, (name, K, kw))
+    # the one-chain kernels do not know minimizers: the combination is refused, not silently wrong
+    with pytest.raises(sa.ReorderError):
+        _gpu(name, 8, 1, fused=2, table_mode=2)
 
 
 @pytest.mark.parametrize("fused", [0, -1])
@@ -317,8 +353,9 @@ def test_single_pool_1M_4_virtual_ranks():
 @pytest.mark.parametrize("kw", [dict(first_shifts=1), dict(first_shifts=4), dict(first_shifts=-1), dict(deep_bins=1), dict(deep_bins=-1), dict(first_shifts=16), dict(seed_wide=-1),
                                 dict(tab_scale=1), dict(tab_scale=4), dict(search_wpb=2), dict(search_wpb=4),
                                 dict(dbg_search_lds=20000), dict(dbg_apply_lds=20000, fused=-1), dict(fused=-1),
-                                dict(first_shifts=3, seed_wide=-1, tab_scale=1, search_wpb=4, fused=-1)])
-@pytest.mark.parametrize("name,K,T", [("syn5k_150", 64, 3), ("var2k", 7, 2), ("heavy", 16, 1)])
+                                dict(first_shifts=3, seed_wide=-1, tab_scale=1, search_wpb=4, fused=-1),
+                                dict(table_mode=1, tab_scale=4)])
+@pytest.mark.parametrize("name,K,T", [("syn5k_150", 64, 3), ("var2k", 7, 2), ("heavy", 16, 1), ("tandem", 32, 2)])
 def test_tuning_opts_do_not_change_results(name, K, T, kw):
     """Every tuning / experiment field of spring_reorder_opts at a non-default value: same streams, same per-tid
     offsets, same reference-equivalent work counters as the rounds oracle (the fields only move work between

@@ -4,6 +4,8 @@ import torch, numpy as np
 import spring_amd
 from spring_amd import _lib
 L_ = _lib.lib()
+# extra fields of ReorderOpts for A/B runs: SP_OPTS="table_mode=1,fused=2"
+XO = {k: int(v) for k, v in (kv.split("=") for kv in __import__("os").environ.get("SP_OPTS", "").split(",") if kv)}
 def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False, cov=25):
     G = max(n * L // cov, 4 * L)
     nb = L_.spring_synth_dna_bytes(n, L)
@@ -11,7 +13,7 @@ def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False, cov=
     rc = L_.spring_synth_dna_device(C.c_void_p(buf.data_ptr()), n, L, G, 11, err | (0x80000000 if repeats else 0)); assert rc == 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    s = spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8, collect_stats=stats, time_search=timed, rounds_per_sync=rps))
+    s = spring_amd.ReorderStage(spring_amd.ReorderOpts(num_chains=K, num_thr=8, collect_stats=stats, time_search=timed, rounds_per_sync=rps, **XO))
     s.load_dna_device(buf.data_ptr(), nb, n, L, True)
     s.run()
     t1 = time.perf_counter()
