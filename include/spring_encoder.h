@@ -49,6 +49,9 @@ typedef struct {
 
 int spring_encoder_create(int device, spring_encoder_ctx **out);
 void spring_encoder_destroy(spring_encoder_ctx *ctx);
+/* test hook: on = 1 makes the next encodes use one table per dictionary and the one-thread-per-window alignment kernel (what
+ * runs anyway when the two dictionary windows differ in length, max_readlen <= 50) instead of the merged table.  Same output. */
+int spring_encoder_set_split_tables(spring_encoder_ctx *ctx, int32_t on);
 
 /* Encode straight from a finalized reorder context: reads and streams never leave HBM.
  * dnaN / order_N: image of input_N.dna (util.cpp:322-348 records) and read_order_N.bin

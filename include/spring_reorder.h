@@ -58,7 +58,8 @@ typedef struct {
                              least 49 152 chains; else one chain per wavefront, k_round); 2: always one chain per wavefront;
                              3: four chains per wavefront wherever that kernel applies, whatever the chain count (tests) */
   int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
-  /* ---- spring_reorder_run / spring_reorder_encode_run on several GPUs of one node (one read pool):
+  /* ---- spring_reorder_run on several GPUs of one node (one read pool; spring_reorder_encode_run
+   * runs on `device` alone and rejects num_devices >= 2):
    * num_devices >= 2 runs the stage on devices[0 .. num_devices) -- one host thread and one context per entry inside
    * the library, the reads loaded on every device, the chains sharded, one RCCL all-gather per round -- and writes the
    * merged per-tid file set.  The output equals the single-device output with the same num_chains (the default chain
@@ -71,6 +72,14 @@ typedef struct {
                              where that applies (32-base windows, reads of 100..192 bases): consecutive windows of a
                              consensus share cache lines -- 60 % fewer memory requests per round, the same run time
                              (DESIGN.md section 6), a dictionary stage twice as long: an experiment, not the default */
+  /* ---- more experiment switches (all 0 = default, none changes the output; they used to be environment variables) */
+  int32_t plan0[6];       /* ordered probe batches of a search, in shifts: up to six widths of 1..16, sum <= 32, 0-terminated
+                             (e.g. {4, 8, 16}); the tail covers the remaining shifts.  plan1: the same for a chain whose seed
+                             has no match yet.  An empty plan = the library's choice (first_shifts, kernel, dictionary depth) */
+  int32_t plan1[6];
+  int32_t long_min;       /* k_long: bin entries that must still be ahead of a search for it to be handed over (0 = default 2048) */
+  int32_t long_blocks;    /* k_long: grid size (0 = default 512) */
+  int32_t debug;          /* 1: stage / phase timings on stderr */
 } spring_reorder_opts;
 
 typedef struct {
@@ -188,6 +197,10 @@ int spring_reorder_mg_slice(spring_reorder_ctx *ctx, void **d_prop, size_t *slic
                             size_t *total_bytes);
 int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32_t *alive);
 int spring_reorder_mg_end(spring_reorder_ctx *ctx);
+/* test hook, between mg_apply and the next mg_search: violations[0] = bitmap words with an untaken read above the cursor,
+ * violations[1] = blocks below the cursor's block whose untaken-read count differs from the bitmap (what the seed pick,
+ * reorder.h:576-592 on the GPU, relies on). */
+int spring_reorder_debug_check_seed_state(spring_reorder_ctx *ctx, uint64_t *violations);
 /* all-gather between `world` contexts living in ONE process on one device (tests). */
 int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world);
 

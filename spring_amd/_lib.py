@@ -10,7 +10,7 @@ EXPORTS = [
     "spring_reorder_destroy", "spring_reorder_load_dna", "spring_reorder_load_dna_device",
     "spring_reorder_build_dict", "spring_reorder_run_chains", "spring_reorder_auto_chains", "spring_reorder_finalize",
     "spring_reorder_mg_begin", "spring_reorder_mg_search", "spring_reorder_mg_slice", "spring_reorder_mg_apply",
-    "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual",
+    "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual", "spring_reorder_debug_check_seed_state",
     "spring_mg_rccl_unique_id", "spring_mg_comm_create_rccl", "spring_mg_comm_create_host", "spring_mg_comm_destroy",
     "spring_reorder_mg_run",
     "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
@@ -19,7 +19,7 @@ EXPORTS = [
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct", "spring_order_pe_encode",
     "spring_fastq_reorder",
     "spring_synth_dna_host", "spring_synth_genome_host", "spring_synth_dna_device", "spring_reorder_load_synth", "spring_reorder_download_dna",
-    "spring_encoder_create", "spring_encoder_destroy", "spring_encoder_encode_reorder", "spring_encoder_download",
+    "spring_encoder_create", "spring_encoder_destroy", "spring_encoder_set_split_tables", "spring_encoder_encode_reorder", "spring_encoder_download",
     "spring_encoder_download_seq_packed", "spring_encoder_get_info", "spring_reorder_encode_run", "spring_encoder_encode_host", "spring_encoder_run",
 ]
 
@@ -32,7 +32,8 @@ class Opts(C.Structure):
                 ("search_wpb", C.c_int32), ("dbg_search_lds", C.c_int32), ("dbg_apply_lds", C.c_int32),
                 ("fused", C.c_int32), ("deep_bins", C.c_int32),
                 ("num_devices", C.c_int32), ("devices", C.c_int32 * 8), ("mg_host_transport", C.c_int32),
-                ("table_mode", C.c_int32)]
+                ("table_mode", C.c_int32), ("plan0", C.c_int32 * 6), ("plan1", C.c_int32 * 6), ("long_min", C.c_int32),
+                ("long_blocks", C.c_int32), ("debug", C.c_int32)]
 
 
 class FastqInfo(C.Structure):

@@ -782,6 +782,7 @@ struct spring_encoder_ctx {
   int T = 0;
   spring_encoder_info info;
   bool have = false;
+  bool split_tables = false;     // spring_encoder_set_split_tables (tests)
   // results (device)
   DBuf refc, pos, noise, noisepos, order, rlen, rc, unaligned;
   std::vector<uint64_t> tid_seq;  // T + 1 offsets into refc
@@ -805,6 +806,11 @@ int spring_encoder_create(int device, spring_encoder_ctx **out) {
   return 0;
 }
 
+int spring_encoder_set_split_tables(spring_encoder_ctx *ctx, int32_t on) {
+  if (!ctx) return -1;
+  ctx->split_tables = on != 0;
+  return 0;
+}
 void spring_encoder_destroy(spring_encoder_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev);
@@ -998,7 +1004,7 @@ static int encode_core(spring_encoder_ctx *ctx, const EncSrc &E, const uint8_t *
   else { dstart[0] = 0; dend[0] = 20 * Lmax / 50; dstart[1] = 20 * Lmax / 50 + 1; dend[1] = 41 * Lmax / 50; }
   // one table for both dictionaries when their windows have the same length (max_readlen > 50 and most others)
   const bool merged = (dend[0] - dstart[0]) == (dend[1] - dstart[1]) && dend[0] - dstart[0] + 1 <= 31 &&
-                      !getenv("SPRING_ENC_SPLIT_TABLES");
+                      !ctx->split_tables;
   uint32_t max_bin = 0;
   DALLOC(sread, (size_t)(np ? np : 1) * S * 8); DALLOC(srev, (size_t)(np ? np : 1) * S * 8);
   DALLOC(nmask, (size_t)(np ? np : 1) * SM * 8); DALLOC(nmask_r, (size_t)(np ? np : 1) * SM * 8);

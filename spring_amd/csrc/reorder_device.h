@@ -196,6 +196,7 @@ void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
 void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n, uint32_t *ublk);
 void launch_init_chains(hipStream_t st, const DevParams &P);
+void launch_check_seed_state(hipStream_t st, const DevParams &P, uint64_t nwords, unsigned long long *bad);
 // two-kernel round (one GPU): search -> apply
 void launch_search(hipStream_t st, const DevParams &P, bool stats);
 void launch_apply(hipStream_t st, const DevParams &P, bool literal);

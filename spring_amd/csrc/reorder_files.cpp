@@ -7,6 +7,7 @@
 // reference's operator interface (call_reorder.h).
 #include <cerrno>
 #include <chrono>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -155,6 +156,7 @@ struct FilePair {
     uint8_t *d = (uint8_t *)dst;
     while (len) {
       const int k = off < f->sz[0] ? 0 : 1;
+      if (k && off - f->sz[0] >= f->sz[1]) return fail(SPRING_REORDER_E_IO, "read past the end of %s", f->name[1].c_str());
       const size_t o = k ? off - f->sz[0] : off, take = std::min(len, f->sz[k] - o);
       size_t got = 0;
       while (got < take) {
@@ -171,11 +173,14 @@ struct FilePair {
 
 // ---- output: the streams go device -> pinned chunk -> file, one writer thread per tid (at most 16), so that the
 // copies of the next stream run while the previous ones are still being framed, checksummed and written
+// (the "copy done" event of a chunk is made per copy, under the device whose stream records it -- an event belongs to the
+// device that was current when it was created, and the chunks of this ring serve every rank of a multi-GPU call -- and
+// is destroyed by the writer thread once it has waited for it)
 struct Slot { void *pin = nullptr; hipEvent_t ev = nullptr; };
-class Ring {  // a bounded set of pinned chunks + their "copy done" events
+class Ring {  // a bounded set of pinned chunks
  public:
   explicit Ring(int n) : cap_(n) {}
-  ~Ring() { for (auto &s : all_) { if (s.ev) (void)hipEventDestroy(s.ev); sr::pinned_put(s.pin); } }
+  ~Ring() { for (auto &s : all_) sr::pinned_put(s.pin); }
   bool acquire(Slot *out) {
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
@@ -183,7 +188,7 @@ class Ring {  // a bounded set of pinned chunks + their "copy done" events
       if ((int)all_.size() < cap_) {
         Slot s;
         s.pin = sr::pinned_get();
-        if (!s.pin || hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { sr::pinned_put(s.pin); return false; }
+        if (!s.pin) return false;
         all_.push_back(s);
         *out = s;
         return true;
@@ -191,7 +196,8 @@ class Ring {  // a bounded set of pinned chunks + their "copy done" events
       cv_.wait(lk);
     }
   }
-  void release(const Slot &s) {
+  void release(Slot s) {
+    s.ev = nullptr;
     { std::lock_guard<std::mutex> lk(mu_); free_.push_back(s); }
     cv_.notify_one();
   }
@@ -267,6 +273,7 @@ class Writer {
         }
         case Msg::DATA:
           if (hipEventSynchronize(m.slot.ev) != hipSuccess && !rc) { rc = SPRING_REORDER_E_HIP; err = "device to host copy failed"; }
+          (void)hipEventDestroy(m.slot.ev);
           put((const uint8_t *)m.slot.pin, m.len);
           ring_->release(m.slot);
           break;
@@ -318,8 +325,14 @@ int w_device(Writer &w, Ring &ring, int dev, hipStream_t st, const void *d, size
     m.kind = Msg::DATA;
     m.len = len;
     if (!ring.acquire(&m.slot)) return fail(SPRING_REORDER_E_HIP, "cannot pin a staging chunk for the output streams");
+    if (hipEventCreateWithFlags(&m.slot.ev, hipEventDisableTiming) != hipSuccess) {  // (device `dev` is current)
+      ring.release(m.slot);
+      return fail(SPRING_REORDER_E_HIP, "cannot create an event on device %d", dev);
+    }
     if (hipMemcpyAsync(m.slot.pin, (const uint8_t *)d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipEventRecord(m.slot.ev, st) != hipSuccess) {
+      (void)hipStreamSynchronize(st);  // (a copy that did start must not land in a chunk handed to someone else)
+      (void)hipEventDestroy(m.slot.ev);
       ring.release(m.slot);
       return fail(SPRING_REORDER_E_HIP, "device to host copy of an output stream failed");
     }
@@ -363,7 +376,7 @@ struct HostGather {
 
 extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, int32_t num_thr, int32_t paired_end,
                                   uint32_t n0, uint32_t n1, const spring_reorder_opts *opts) {
-  const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;  // phase timings on stderr, no effect on results
+  const bool dbg = opts && opts->debug != 0;  // phase timings on stderr, no effect on results
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!dbg) return;
@@ -433,12 +446,27 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
         if (!e) e = spring_reorder_auto_chains(g[(size_t)k].c, &autok[(size_t)k], nullptr);
         if (e) { rcs[(size_t)k] = e; errs[(size_t)k] = spring_reorder_last_error(); }
       };
-      {
+      // (a thread that cannot be started must not unwind past its running siblings: std::terminate)
+      // ... nor may some ranks enter a collective that the missing one never joins: the threads wait at a gate until all exist)
+      auto run_ranks = [&](auto &&body) -> bool {
         std::vector<std::thread> th;
-        for (int k = 1; k < world; k++) th.emplace_back(phase1, k);
-        phase1(0);
+        std::atomic<int> gate{0};  // 0 wait, 1 go, -1 give up
+        bool ok = true;
+        for (int k = 1; k < world && ok; k++) {
+          try {
+            th.emplace_back([&gate, &body, k] {
+              int g;
+              while ((g = gate.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+              if (g > 0) body(k);
+            });
+          } catch (const std::system_error &) { ok = false; }
+        }
+        gate.store(ok ? 1 : -1, std::memory_order_release);
+        if (ok) body(0);
         for (auto &x : th) x.join();
-      }
+        return ok;
+      };
+      if (!run_ranks(phase1)) return fail(SPRING_REORDER_E_IO, "cannot start the rank threads");
       for (int k = 0; k < world; k++) if (rcs[(size_t)k]) return fail(rcs[(size_t)k], "%s", errs[(size_t)k].c_str());
       lap("read + H2D + dictionaries");
       uint32_t Ktot = o.num_chains ? o.num_chains : autok[0];
@@ -452,18 +480,11 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
         if (e) { rcs[(size_t)k] = e; errs[(size_t)k] = spring_reorder_last_error(); hg.abort_all(); }
         spring_mg_comm_destroy(comm);
       };
-      {
-        std::vector<std::thread> th;
-        for (int k = 1; k < world; k++) th.emplace_back(phase2, k);
-        phase2(0);
-        for (auto &x : th) x.join();
-      }
+      if (!run_ranks(phase2)) return fail(SPRING_REORDER_E_IO, "cannot start the rank threads");
       for (int k = 0; k < world; k++) if (rcs[(size_t)k]) return fail(rcs[(size_t)k], "%s", errs[(size_t)k].c_str());
     }
     lap("dict + chains + final");
     in.close_all();
-    remove((base + "/input_clean_1.dna").c_str());  // the stage consumes its inputs (reorder.h:232,241)
-    if (paired_end) remove((base + "/input_clean_2.dna").c_str());
 
     // ---- output: tid t of the job = every rank's tid-t segment, ranks ascending (chain c -> tid c % num_thr)
     std::vector<sr::ReorderView> v((size_t)world);
@@ -549,6 +570,9 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
     for (auto &w : W) w->finish();
     if (ret) return ret;
     for (auto &w : W) if (w->rc) return fail(w->rc, "%s", w->err.c_str());
+    // the stage consumes its inputs (reorder.h:232,241) -- once its outputs exist: a failed call leaves them in place
+    remove((base + "/input_clean_1.dna").c_str());
+    if (paired_end) remove((base + "/input_clean_2.dna").c_str());
     lap("D2H + write files");
     printf("Reordering done, %llu were unmatched\n", (unsigned long long)unmatched);  // reorder.h:633-635
     return 0;
@@ -628,6 +652,8 @@ extern "C" int spring_reorder_encode_run(const char *temp_dir, uint32_t max_read
   spring_reorder_opts o;
   if (opts) o = *opts; else spring_reorder_default_opts(&o);
   o.num_thr = num_thr;
+  if (o.num_devices >= 2)
+    return fail(SPRING_REORDER_E_ARG, "spring_reorder_encode_run runs on one device (opts.device): a device list is taken by spring_reorder_run only");
   const std::string base(temp_dir);
   const std::string in1 = base + "/input_clean_1.dna", in2 = base + "/input_clean_2.dna";
   const std::string inN = base + "/input_N.dna", inON = base + "/read_order_N.bin";  // encoder.h:587,:583

@@ -50,6 +50,7 @@ struct DnaSource {
   // copies bytes [off, off + len) of the stream to dst; 0 on success (thread-safe)
   int (*fill)(void *self, size_t off, void *dst, size_t len) = nullptr;
   void *self = nullptr;
+  const uint8_t *image = nullptr;  // set when the stream already IS a host memory image: a fallback that has to walk the records walks it in place
 };
 // readDnaFile (reorder.h:222-244) from such a source: host threads fill pinned chunks while earlier chunks are on
 // their way to the device (double buffering per thread), then the unpack kernel.  A stream of exactly

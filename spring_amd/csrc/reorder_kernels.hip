@@ -2264,6 +2264,33 @@ void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
   if (!n) return;
   hipLaunchKernelGGL(k_fill_u32, GRID1(n, 256), dim3(256), 0, st, p, n, v);
 }
+// test hook (spring_reorder_debug_check_seed_state): find_seed relies on (1) every read above the cursor being taken and
+// (2) ublk[b] being the exact number of untaken reads of every block b below the cursor's block.  bad[0] / bad[1]
+// count the violations between two rounds.
+__global__ void k_check_seed_state(DevParams P, uint64_t nwords, unsigned long long *bad) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  const long long top = P.glob->cursor;
+  const uint64_t v = P.taken[w];
+  // (1) bits of reads > cursor
+  const long long first = (long long)w * 64;
+  if (first + 63 > top) {
+    const int lo = top < first ? 0 : (int)(top - first + 1);
+    const uint64_t must = lo >= 64 ? 0ull : (~0ull << lo);
+    if ((v & must) != must) atomicAdd(&bad[0], 1ull);
+  }
+  // (2) one thread per block: the first word of the block
+  constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);
+  if ((w % WPB_) == 0 && top >= 0 && (long long)(w / WPB_) < (top >> UBLK_SHIFT)) {
+    int cnt = 0;
+    for (int k = 0; k < WPB_; k++) cnt += __popcll(~P.taken[w + k]);
+    if ((uint32_t)cnt != P.ublk[w / WPB_]) atomicAdd(&bad[1], 1ull);
+  }
+}
+void launch_check_seed_state(hipStream_t st, const DevParams &P, uint64_t nwords, unsigned long long *bad) {
+  if (!nwords) return;
+  hipLaunchKernelGGL(k_check_seed_state, GRID1(nwords, 256), dim3(256), 0, st, P, nwords, bad);
+}
 void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n, uint32_t *ublk) {
   if (!nwords) return;
   hipLaunchKernelGGL(k_init_taken, GRID1(nwords, 256), dim3(256), 0, st, taken, nwords, n, ublk);

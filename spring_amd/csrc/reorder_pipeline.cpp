@@ -142,6 +142,7 @@ struct spring_reorder_ctx {
   int bshift = 63;        // plain home bucket = hash >> bshift (nb = 2^(64 - bshift) buckets)
   int minz = 0, lshift = 31;  // minimizer-addressed table (TabView)
   uint32_t marked_lines = 0;  // ... lines of it whose keys were sent to the redirect address
+  bool user_plan0 = false;    // opts.plan0 was given (fill_params)
   DevParams P;
   uint32_t K = 0;
   uint64_t nrec = 0, nsing = 0, cap = 0;
@@ -523,6 +524,12 @@ int load_dna_source(spring_reorder_ctx *ctx, const DnaSource &src, uint32_t n, u
     ctx->dfree(ctx->d_dna); ctx->d_dna = nullptr;
   }
   // variable-length (or malformed) stream: the record starts are sequentially dependent -> a host image is walked
+  if (src.image) {  // (the caller's own buffer: no second copy of a multi-GB stream)
+    ctx->in_source_fallback = true;
+    r = spring_reorder_load_dna(ctx, src.image, nbytes, n, max_readlen);
+    ctx->in_source_fallback = false;
+    return r;
+  }
   std::unique_ptr<uint8_t[]> img;
   try { img.reset(new uint8_t[nbytes + 1]); } catch (const std::bad_alloc &) { return fail(SPRING_REORDER_E_IO, "out of host memory for a %zu-byte record stream", nbytes); }
   {
@@ -584,6 +591,7 @@ int spring_reorder_load_dna(spring_reorder_ctx *ctx, const uint8_t *dna, size_t 
     DnaSource src;
     src.nbytes = nbytes;
     src.self = const_cast<uint8_t *>(dna);
+    src.image = dna;
     src.fill = [](void *self, size_t o, void *dst, size_t len) -> int { memcpy(dst, (const uint8_t *)self + o, len); return 0; };
     ctx->in_source_fallback = true;  // (load_dna_source comes back here when the lengths turn out to vary)
     const int rs = load_dna_source(ctx, src, n, max_readlen);
@@ -984,9 +992,9 @@ static TabView tab_view(const spring_reorder_ctx *ctx) {
 }
 
 int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
-  const bool dbg = getenv("SPRING_REORDER_DEBUG") != nullptr;  // stage timings on stderr, no effect on results
   double t_last = now_ms();
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
+  const bool dbg = ctx->o.debug != 0;  // stage timings on stderr, no effect on results
   if (ctx->stage != ST_LOADED) return fail(SPRING_REORDER_E_STATE, "build_dict: load reads first");
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
@@ -1245,19 +1253,21 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
     P.plan[0][0] = 4; P.plan[0][1] = 8; P.plan[0][2] = 16;
   } else { P.plan[0][0] = 8; P.plan[0][1] = 16; }   // one narrow batch, one wide
   P.plan[1][0] = 16; P.plan[1][1] = 16;
-  for (int w = 0; w < 2; w++) {  // A/B runs of the tools: SPRING_REORDER_PLAN0 / _PLAN1 = "4,4,8,16" (same results)
-    const char *e = getenv(w ? "SPRING_REORDER_PLAN1" : "SPRING_REORDER_PLAN0");
-    if (!e) continue;
+  bool user_plan[2] = {false, false};
+  for (int w = 0; w < 2; w++) {  // opts.plan0 / plan1: an explicit plan wins over every rule here and below
+    const int32_t *up = w ? o.plan1 : o.plan0;
+    if (up[0] <= 0) continue;
     int k = 0, sum = 0;
-    memset(P.plan[w], 0, sizeof(P.plan[w]));
-    for (const char *q = e; *q && k < 6;) {
-      const int v = atoi(q);
-      if (v <= 0 || v > 16 || sum + v > 32) break;
-      P.plan[w][k++] = v; sum += v;
-      while (*q && *q != ',') q++;
-      if (*q == ',') q++;
+    int tmp[6] = {0, 0, 0, 0, 0, 0};
+    for (; k < 6 && up[k] > 0; k++) {
+      if (up[k] > 16 || sum + up[k] > 32) break;
+      tmp[k] = up[k]; sum += up[k];
     }
+    if (k == 0) continue;
+    memcpy(P.plan[w], tmp, sizeof(tmp));
+    user_plan[w] = true;
   }
+  ctx->user_plan0 = user_plan[0];
   P.seed_wide = o.seed_wide < 0 ? 0 : 1;
   P.search_wpb = (o.search_wpb == 1 || o.search_wpb == 2 || o.search_wpb == 4) ? o.search_wpb : 1;  // 1: a block is a chain; its slot frees when that chain is done
   P.dbg_search_lds = std::max(0, o.dbg_search_lds);
@@ -1275,18 +1285,18 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // ... and the next read of a chain sits at shift 0 or 1 nearly always, while every verified bin a batch holds past the
   // winner is scanned for nothing: a narrow first batch (2 + 6 + 8 + 16 shifts instead of 4 + 8 + 16: 1 600x -3 %, 6 400x
   // -4 %, 25 600x -7 %, PhiX-like -5 %; 1 + 3 + 4 + 8 + 16 the same within 1 %, 1 + 1 + 2 + 4 + 8 + 16 slower at 400x)
-  if (P.deep_bins && !dict_is_deep(ctx) && o.first_shifts == 0 && !getenv("SPRING_REORDER_PLAN0")) {
+  if (P.deep_bins && !dict_is_deep(ctx) && o.first_shifts == 0 && !user_plan[0]) {
     // (between the two thresholds bins hold two or three reads: 8 + 16 as for one chain per wavefront elsewhere)
     memset(P.plan[0], 0, sizeof(P.plan[0]));
     P.plan[0][0] = 8; P.plan[0][1] = 16;
   }
   if (P.deep_bins && dict_is_deep(ctx) && o.first_shifts == 0 && o.fused >= 0 && !o.collect_stats && !o.force_literal_update &&
-      !getenv("SPRING_REORDER_PLAN0")) {
+      !user_plan[0]) {
     memset(P.plan[0], 0, sizeof(P.plan[0]));
     P.plan[0][0] = 2; P.plan[0][1] = 6; P.plan[0][2] = 8; P.plan[0][3] = 16;
     // (a fresh seed of such a pool finds its first match like any other chain: 4 + 12 + 16 instead of the wide 16 + 16:
     // PhiX-like -3 %, the 20 M-read pools within 1 %)
-    if (!getenv("SPRING_REORDER_PLAN1")) {
+    if (!user_plan[1]) {
       memset(P.plan[1], 0, sizeof(P.plan[1]));
       P.plan[1][0] = 4; P.plan[1][1] = 12; P.plan[1][2] = 16;
     }
@@ -1299,13 +1309,12 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   const bool very_deep = P.deep_bins && dict_is_very_deep(ctx);
   P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : (very_deep ? 8 : 0));
   P.long_blocks = 512;
-  if (const char *e = getenv("SPRING_REORDER_LONG")) P.long_budget = atoi(e) < 0 ? P.long_budget : atoi(e);  // A/B runs of the tools (-1: the default)
   // ... and only when at least this many bin entries are still ahead of it (32 compare passes of one wavefront, two
   // steps of k_long); budgets below 8 hand over unconditionally (tests).  PhiX-like pool, chains stage, same box: off
   // 300 ms; budget 8 with 2 048 / 4 096 / 8 192 entries 219 / 225 / 228; 24 unconditionally 218; 8 unconditionally 238
   P.long_min = P.long_budget < 8 ? 0 : 2048;
-  if (const char *e = getenv("SPRING_REORDER_LONG_MIN")) P.long_min = std::max(0, atoi(e));
-  if (const char *e = getenv("SPRING_REORDER_LONG_BLOCKS")) P.long_blocks = std::max(1, atoi(e));
+  if (o.long_min > 0) P.long_min = o.long_min;
+  if (o.long_blocks > 0) P.long_blocks = o.long_blocks;
   P.longq = nullptr;
 }
 // Default chain count.  ~1000 reads per chain: the compressed size grows with the chain count on ordinary coverage
@@ -1364,11 +1373,10 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // kernel's lead below 40 000 chains is 5-16 %)
   if (K < 49152 && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
   if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
-  if (const char *e = getenv("SPRING_REORDER_MC")) P.mc = atoi(e) != 0;  // A/B runs of the tools (same results)
   if (ctx->minz && !(fused && P.mc && !ctx->o.collect_stats && !P.deep_bins))
     return fail(SPRING_REORDER_E_ARG, "table_mode = 2 (minimizer-addressed table) is an experiment of the four-chain round kernel: "
                 "shallow dictionary, at least 49152 chains or fused = 3, no work counters");
-  if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !getenv("SPRING_REORDER_PLAN0")) {
+  if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !ctx->user_plan0) {
     memset(P.plan[0], 0, sizeof(P.plan[0]));   // (fill_params assumed the four-chain kernel: 4 + 8 + 16)
     P.plan[0][0] = 8; P.plan[0][1] = 16;
   }
@@ -1466,7 +1474,6 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   if (r0) return r0;
   DevParams &P = ctx->P;
   int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : (K >= 256 ? 16 : 256);
-  if (const char *e = getenv("SPRING_REORDER_RPS")) R = std::max(1, atoi(e));  // A/B runs of the tools (same results)
   std::vector<hipEvent_t> tev;
   if (timed) {
     tev.resize(2 * (size_t)R);
@@ -1508,7 +1515,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
       HIPCHK(hipStreamSynchronize(st));
     }
     HIPCHK(hipGetLastError());
-    if (getenv("SPRING_REORDER_DEBUG")) fprintf(stderr, "[chains] rounds %llu running %u\n", (unsigned long long)rounds, *h_alive);
+    if (ctx->o.debug) fprintf(stderr, "[chains] rounds %llu running %u\n", (unsigned long long)rounds, *h_alive);
     if (timed) {
       for (int r = 0; r < R; r++) {
         float ms = 0;
@@ -1602,6 +1609,23 @@ int spring_reorder_mg_end(spring_reorder_ctx *ctx) {
   HIPCHK(hipEventRecord(ctx->ev[5], ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->stage = ST_CHAINS;
+  return 0;
+}
+
+// test hook: the invariants the seed pick relies on, checked between two rounds of the step-wise API (after mg_apply)
+int spring_reorder_debug_check_seed_state(spring_reorder_ctx *ctx, uint64_t *violations /* [2] */) {
+  if (!ctx || !ctx->mg || ctx->stage != ST_DICT || !violations) return fail(SPRING_REORDER_E_STATE, "debug_check_seed_state: between mg_begin and mg_end");
+  HIPCHK(hipSetDevice(ctx->dev));
+  unsigned long long *d_bad = nullptr;
+  DMALLOC(d_bad, 16);
+  HIPCHK(hipMemsetAsync(d_bad, 0, 16, ctx->st));
+  const uint64_t nblk = ((uint64_t)ctx->n + (1ull << UBLK_SHIFT) - 1) >> UBLK_SHIFT;
+  launch_check_seed_state(ctx->st, ctx->P, nblk << (UBLK_SHIFT - 6), d_bad);
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->dfree(d_bad);
+  violations[0] = h[0]; violations[1] = h[1];
   return 0;
 }
 

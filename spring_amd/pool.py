@@ -56,6 +56,13 @@ class _MgStage(ReorderStage):
     def mg_end(self):
         _chk(self._L.spring_reorder_mg_end(self._h))
 
+    def check_seed_state(self):
+        """Between two rounds: (bitmap words with an untaken read above the cursor, blocks below the cursor's block
+        whose untaken-read count is off) -- both must be zero for the seed pick to be exact."""
+        v = (C.c_uint64 * 2)()
+        _chk(self._L.spring_reorder_debug_check_seed_state(self._h, v))
+        return int(v[0]), int(v[1])
+
     def mg_slice(self):
         p, off, nb, tot = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
         _chk(self._L.spring_reorder_mg_slice(self._h, C.byref(p), C.byref(off), C.byref(nb), C.byref(tot)))
@@ -67,6 +74,7 @@ class VirtualPool:
 
     def __init__(self, world, total_chains, num_thr=1, **opt_kw):
         self.world, self.K, self.T = world, total_chains, num_thr
+        self.check_every = 7  # rounds between checks of the seed-pick invariants (ublk[] / cursor vs the bitmap)
         self.stages = [_MgStage(ReorderOpts(num_chains=total_chains, num_thr=num_thr, **opt_kw)) for _ in range(world)]
 
     def run(self, load):
@@ -84,6 +92,9 @@ class VirtualPool:
             _chk(L_.spring_reorder_mg_exchange_virtual(arr, self.world))
             alive = [s.mg_apply(True) for s in self.stages]
             rounds += 1
+            if rounds % self.check_every == 0:  # what find_seed relies on, on every rank's replica
+                for s in self.stages:
+                    assert s.check_seed_state() == (0, 0), "seed-pick invariants broken after round %d" % rounds
             assert len(set(alive)) == 1, "ranks disagree on the number of running chains: %r" % (alive,)
             if alive[0] == 0:
                 break

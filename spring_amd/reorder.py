@@ -41,6 +41,11 @@ class ReorderOpts:
     long_budget: int = 0      # deep pools: compare passes before a search goes to k_long (0 = default, -1 = never)
     devices: tuple = ()       # call_reorder on several GPUs: one pool over these device ordinals (may repeat: host transport)
     mg_host_transport: bool = False
+    plan0: tuple = ()         # explicit probe plan (shifts per ordered batch, e.g. (4, 8, 16)); plan1: for a chain whose seed is unmatched
+    plan1: tuple = ()
+    long_min: int = 0
+    long_blocks: int = 0
+    debug: bool = False       # stage timings on stderr
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
 
     def to_c(self):
@@ -56,6 +61,11 @@ class ReorderOpts:
         if len(self.devices) > 8:
             raise ValueError("at most 8 devices")
         o.table_mode = self.table_mode
+        for i, v in enumerate(tuple(self.plan0)[:6]):
+            o.plan0[i] = int(v)
+        for i, v in enumerate(tuple(self.plan1)[:6]):
+            o.plan1[i] = int(v)
+        o.long_min, o.long_blocks, o.debug = self.long_min, self.long_blocks, int(self.debug)
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d

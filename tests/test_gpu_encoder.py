@@ -10,7 +10,7 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-def _run(name, K, T, nN=0, deep=0, seed=1):
+def _run(name, K, T, nN=0, deep=0, seed=1, split_tables=False):
     import spring_amd
     from spring_amd.encoder import EncoderStage
     dna, n, L = named_set(name)
@@ -24,6 +24,8 @@ def _run(name, K, T, nN=0, deep=0, seed=1):
         st.run()
         streams = st.streams()
         with EncoderStage() as enc:
+            if split_tables:
+                assert enc._L.spring_encoder_set_split_tables(enc._h, 1) == 0
             info = enc.encode(st, dnaN, order_N)
             got = enc.streams()
             packed, tails = enc.seq_packed()
@@ -291,11 +293,10 @@ def test_encoder_run_file_contract_after_reorder_run(tmp_path, recompress):
 
 
 @pytest.mark.parametrize("name", ["syn5k_150", "var2k"])
-def test_split_table_alignment_kernel_agrees(name, monkeypatch):
-    """SPRING_ENC_SPLIT_TABLES forces the one-thread-per-window kernel (the one used when the two dictionary
+def test_split_table_alignment_kernel_agrees(name):
+    """spring_encoder_set_split_tables forces the one-thread-per-window kernel (the one used when the two dictionary
     windows differ in length, max_readlen <= 50) on data that normally takes the merged-table kernel."""
-    monkeypatch.setenv("SPRING_ENC_SPLIT_TABLES", "1")
-    got, want, info, _, _ = _run(name, 16, 2, nN=300, deep=1200, seed=6)
+    got, want, info, _, _ = _run(name, 16, 2, nN=300, deep=1200, seed=6, split_tables=True)
     same_encoding(got, want, name)
 
 

@@ -14,7 +14,7 @@ rm -rf $O/prof
 bash tools/pmc_probe.sh $O/pmc 100000000 > $O/pmc.log 2>&1
 python tools/pmc_aggregate.py $O/pmc 100000000 $O/pmc_100Mx150.json > $O/pmc_aggregate.txt 2>&1
 rm -rf $O/pmc
-for mc in 1 0 1 0; do echo "SPRING_REORDER_MC=$mc"; SPRING_REORDER_MC=$mc python tools/scale_probe.py 100000000,150,65536 2>&1 | tail -1; done > $O/ab_round_kernels.txt
+for mc in 3 2 3 2; do echo "fused=$mc (3: four chains per wavefront, 2: one)"; SP_OPTS=fused=$mc python tools/scale_probe.py 100000000,150,65536 2>&1 | tail -1; done > $O/ab_round_kernels.txt
 python bench.py --force-pool --pool-reads 100000000 --pool-chains 65536 --steps 2 --no-single > $O/bench_pool_world1.json 2> $O/bench_pool.err
 # the shared 400 M-read pool at world = 1 (what the N > 1 lines of the driver's scaling run are compared with)
 python bench.py --force-pool --steps 2 --no-single > $O/bench_pool400M_world1.json 2>> $O/bench_pool.err

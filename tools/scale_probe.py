@@ -4,8 +4,9 @@ import torch, numpy as np
 import spring_amd
 from spring_amd import _lib
 L_ = _lib.lib()
-# extra fields of ReorderOpts for A/B runs: SP_OPTS="table_mode=1,fused=2"
-XO = {k: int(v) for k, v in (kv.split("=") for kv in __import__("os").environ.get("SP_OPTS", "").split(",") if kv)}
+# extra fields of ReorderOpts for A/B runs: SP_OPTS="table_mode=2,fused=3,plan0=4:8:16" (same results whatever they are)
+XO = {k: (tuple(int(x) for x in v.split(":")) if ":" in v or k.startswith("plan") else int(v))
+      for k, v in (kv.split("=") for kv in __import__("os").environ.get("SP_OPTS", "").split(",") if kv)}
 def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False, cov=25):
     G = max(n * L // cov, 4 * L)
     nb = L_.spring_synth_dna_bytes(n, L)

@@ -12,10 +12,9 @@ for cov in [int(x) for x in (sys.argv[1:] or ["60", "100", "200", "400"])]:
     G = n * L // cov
     out = {}
     for name, kw, plan in VARS:
-        os.environ["SPRING_REORDER_PLAN0"] = plan
         best = None
         for it in range(3):
-            with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=0, num_thr=8, **kw)) as s:
+            with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=0, num_thr=8, plan0=tuple(int(x) for x in plan.split(",")), **kw)) as s:
                 s.load_synth(n, L, G, 11, 10000)
                 s.run()
                 st = s.stats()
