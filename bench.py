@@ -379,6 +379,14 @@ def main():
             # from the same PMC summary: the share of the launch during which a SIMD's vector ALU is issuing
             # (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)), and the instruction mix per wavefront
             "valu_issue_frac": ks.get("valu_issue_frac") if traffic is not None else None,
+            # the L1 miss queue (profiles/r03_tcp_queue.txt, r04_minimizer_table.txt): L1 -> L2 read requests per chain and round,
+            # their mean latency in L1 clocks, and how many are in flight per CU on average (the queue is 64 deep)
+            "l1_requests_per_chain_round": (round(ks["l1_read_requests_per_launch"] / st["chains"], 1)
+                                            if traffic is not None and ks.get("l1_read_requests_per_launch") else None),
+            "l1_request_latency_clocks": (round(ks["l1_read_request_latency_clocks"], 0)
+                                          if traffic is not None and ks.get("l1_read_request_latency_clocks") else None),
+            "l1_requests_in_flight_per_cu": (round(ks["l1_requests_in_flight_per_cu"], 1)
+                                             if traffic is not None and ks.get("l1_requests_in_flight_per_cu") else None),
             "insts_per_wavefront": ks.get("insts_per_wave") if traffic is not None else None,
             "hbm_write_bytes_per_launch": round(ks["write_bytes_per_launch"], 1) if traffic is not None else None,
         })
@@ -473,12 +481,15 @@ def main():
             torch.cuda.empty_cache()
             sweep = []
             ns = a.sweep_sample
-            pools = [(ns, c, max(ns * L // c, 4 * L), "%dx" % c) for c in (100, 400, 1600, 6400, 25600)]
+            pools = [(ns, 0, max(ns * L // c, 4 * L), "%dx" % c) for c in (100, 400, 1600, 6400, 25600)]
             pools.append((ns // 2, 0, 5400, "PhiX-like (%d reads over 5.4 kb)" % (ns // 2)))
-            for pn, _, pG, name in pools:
+            # a genome with the repeat structure of a real one (SPRING_SYNTH_GENOMIC: Zipf-sized repeat families, tandem
+            # repeats, low-complexity runs; 25x): bins of thousands of reads beside single-read bins
+            pools.append((ns, 0x20000000, max(ns * L // 25, 4 * L), "genome-like 25x (repeat families, tandem repeats)"))
+            for pn, pflag, pG, name in pools:
                 pb = L_.spring_synth_dna_bytes(pn, L)
                 tb = torch.empty(pb, dtype=torch.uint8, device="cuda")
-                assert L_.spring_synth_dna_device(C.c_void_p(tb.data_ptr()), pn, L, pG, 11, a.err_ppm) == 0
+                assert L_.spring_synth_dna_device(C.c_void_p(tb.data_ptr()), pn, L, pG, 11, a.err_ppm | pflag) == 0
                 torch.cuda.synchronize()
                 for it in range(2):
                     t0 = time.perf_counter()
@@ -490,7 +501,7 @@ def main():
                     s.close()
                 sweep.append({"pool": name, "reads": pn, "Mreads_per_s": round(pn / t1 / 1e6, 1), "chains": ps["chains"],
                               "rounds": ps["rounds"], "lost_proposals": ps["lost"], "searches_by_k_long": ps["long_searches"],
-                              "chains_stage_ms": round(ps["ms_chains"], 1)})
+                              "chains_stage_ms": round(ps["ms_chains"], 1), "dictionary": {"deep": bool(ps["deep_pool"] & 1), "heavy_tail": bool(ps["deep_pool"] & 2)}})
                 del tb
             out["coverage_sweep"] = {"read_len": L, "err_ppm": a.err_ppm, "pools": sweep,
                                      "what": "the same stage, library defaults, inputs resident in HBM, whole-stage wall clock"}
@@ -542,6 +553,23 @@ def main():
             "single_thread": {"value": round(ns1 / t1 / 1e6, 4), "sample_reads": ns1, "seconds": round(t1, 1)},
             "host_cpus": os.cpu_count(),
         }
+        # the same port on a genome-like pool (SPRING_SYNTH_GENOMIC: repeat families, tandem repeats; coverage_sweep has the
+        # GPU's figure): what realistic repeat structure costs the CPU algorithm
+        try:
+            nsg = min(max(ns // 16, 200_000), ns)
+            Gg = max(nsg * L // a.coverage, 2 * L)
+            bg = torch.empty(L_.spring_synth_dna_bytes(nsg, L), dtype=torch.uint8, device="cuda")
+            assert L_.spring_synth_dna_device(C.c_void_p(bg.data_ptr()), nsg, L, Gg, 11, a.err_ppm | 0x20000000) == 0
+            dnag = bg.cpu().numpy().tobytes()
+            del bg
+            t0 = time.perf_counter()
+            readg, lng = po.load_dna(dnag, nsg, L)
+            po.reorder_omp(readg, lng, L, T)
+            tg = time.perf_counter() - t0
+            out["cpu_baseline"]["genome_like"] = {"value": round(nsg / tg / 1e6, 4), "sample_reads": nsg, "threads": T, "seconds": round(tg, 1)}
+            del readg, lng, dnag
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"]["genome_like"] = {"error": repr(e)}
     if rank == 0 and world == 1 and a.cpu_sample > 0 and "cpu_baseline" in out:
         # the reference's own span ("Time for this step", spring.cpp:152-160): input_clean_1.dna from disk, load,
         # dictionaries, reorder, and the per-tid output files written -- the CPU twin of stage_incl_files

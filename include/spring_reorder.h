@@ -98,7 +98,8 @@ typedef struct {
    * the round kernel over the rank's own chains */
   double ms_exchange, ms_resolve_mark;
   uint64_t chains;         /* K the chain phase ran with (opts.num_chains, or what the default rule chose) */
-  uint64_t deep_pool;      /* 1: the dictionary averages >= 1.3 reads per key (the deep-coverage default applies) */
+  uint64_t deep_pool;      /* bit 0: the dictionary averages >= 1.3 reads per key (the deep-coverage default applies); bit 1: it has a
+                              heavy tail -- >= 0.5 % of its reads in bins of >= 256 entries (repeat families of a real genome) */
   uint64_t long_searches;  /* searches a wavefront handed over to a block of 16 (k_long; deep-coverage pools only) */
   uint64_t table_minz;     /* 1: the dictionary table is addressed by minimizers (opts.table_mode) */
   uint64_t table_marked_lines; /* ... and this many of its lines were over-subscribed: their keys live at the redirect address */
@@ -300,6 +301,10 @@ int spring_fastq_reorder(const uint8_t *fastq, size_t nbytes, const uint32_t *or
                                             read n/2 + i its mate: the two ends of a fragment of ~N(400, 50) bases, on
                                             opposite strands (BASELINE config 4; reorder.h:233-242 lays a paired pool
                                             out as file-1 reads followed by file-2 reads) */
+#define SPRING_SYNTH_GENOMIC 0x20000000u /* OR into err_ppm: a genome with the repeat structure of a real one -- per 512-base
+                                            segment: 20 % a copy of one of 64 Zipf-sized interspersed-repeat families (5-20 %
+                                            divergence from the family consensus), 5 % a tandem repeat (unit 2..40 bases), 3 %
+                                            low-complexity runs, the rest unique sequence (synth_common.h) */
 size_t spring_synth_dna_bytes(uint32_t n, uint32_t L);
 int spring_synth_dna_host(uint8_t *dst, uint32_t n, uint32_t L, uint64_t G, uint64_t seed, uint32_t err_ppm);
 /* the genome the reads are drawn from, as G letters (tests of the generator itself); flags = SPRING_SYNTH_REPEATS or 0 */

@@ -12,6 +12,7 @@ constexpr int MAX_READ_LEN = 511;   // params.h:22
 constexpr int MAX_SEARCH = 1000;    // params.h:26 MAX_SEARCH_REORDER
 constexpr int THRESH = 4;           // params.h:27 THRESH_REORDER
 constexpr uint32_t DEEP_BIN = 16;   // bins with at least this many reads are tail-trimmed between rounds
+constexpr uint32_t MID_BIN = 64;    // reads in bins of at least this size are counted too (DictBuild::ndeep[2]): the heavy-tail rule
 constexpr uint32_t BIG_BIN = 256;   // reads in bins of at least this size are counted (DictBuild::ndeep[1]): long searches, k_long
 constexpr uint32_t CHUNK = 64;      // emission slots a chain reserves per global atomic
 constexpr uint32_t MARK_BLOCK = 256; // chains per block of k_mg_mark = per class-list segment (k_round_mc)
@@ -120,6 +121,7 @@ struct DevParams {
   TabView tab;                // ONE table for both dictionaries (tab_find)
   const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key (multi-read bins)
   const uint32_t *ids[2];
+  const ulonglong2 *sig[2];   // k_long only (else null): {first limb, last limb} of the read of every entry of ids[l] (k_build_sig)
   // shared mutable state
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
   uint32_t *ublk;     // untaken reads per block of 2^UBLK_SHIFT reads, exact between rounds (seed selection, find_seed)
@@ -137,7 +139,7 @@ struct DevParams {
   // writes the four class sizes to ord_cnt[block].  No atomics, rewritten every round; done chains are in no list.
   uint32_t *ord;
   uint4 *ord_cnt;
-  // long searches (deep-bin pools, k_long): [0] = searches k_round handed over this round, [1 + i] = their local chain
+  // long searches (deep-bin pools, k_long): [0] = searches k_round handed over this round, [1] = k_long's ticket counter, [2 + i] = their local chain
   // indices; k_mg_mark zeroes the count.  long_budget: 64-lane compare passes (balanced scan) / bin entries walked by
   // one lane (tail) a wavefront of k_round spends on a search before it hands it over; 0 = never.
   // long_min: bin entries that must still be ahead of the search at that point (else the wavefront carries on).
@@ -173,7 +175,7 @@ void launch_keys(hipStream_t st, const uint64_t *reads, const uint16_t *lens, co
 struct DictBuild {
   const uint32_t *ustart, *ucount, *ids;
   ulonglong2 *urec;
-  uint32_t *deep, *ndeep;   // ndeep[0] bins listed in deep[], ndeep[1] reads in bins of >= BIG_BIN entries
+  uint32_t *deep, *ndeep;   // ndeep[0] bins listed in deep[], ndeep[1] reads in bins of >= BIG_BIN entries, ndeep[2] ... of >= MID_BIN
 };
 void launch_tab_insert(hipStream_t st, const uint64_t *mhash, const uint64_t *mval, uint64_t nmerged, DictBuild d0,
                        DictBuild d1, uint32_t *fpt, int bshift);
@@ -189,7 +191,8 @@ hipError_t merge_by_hash(hipStream_t st, void *tmp, size_t &tmp_bytes, const uin
                          const uint64_t *v0, const uint64_t *v1, uint64_t *kout, uint64_t *vout, size_t n0, size_t n1);
 void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag);
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
-                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken);
+                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken, ulonglong2 *sig /* or null: moved with the ids */);
+void launch_build_sig(hipStream_t st, const uint32_t *ids, uint64_t m, const uint64_t *reads, int S, int W, ulonglong2 *sig);
 void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
                         uint32_t *start, uint32_t *count);

@@ -471,13 +471,21 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
       lap("read + H2D + dictionaries");
       uint32_t Ktot = o.num_chains ? o.num_chains : autok[0];
       Ktot = (Ktot + (uint32_t)world - 1) / (uint32_t)world * (uint32_t)world;
+      std::vector<spring_mg_comm *> comms((size_t)world, nullptr);
+      std::mutex comms_mu;
       auto phase2 = [&](int k) {
         spring_mg_comm *comm = nullptr;
         int e = host_transport ? spring_mg_comm_create_host(&comm, &HostGather::fn, &hg, (uint32_t)k, (uint32_t)world)
                                : spring_mg_comm_create_rccl(&comm, devs[(size_t)k], id, (uint32_t)k, (uint32_t)world);
+        { std::lock_guard<std::mutex> lk(comms_mu); comms[(size_t)k] = comm; }
         if (!e) e = spring_reorder_mg_run(g[(size_t)k].c, comm, Ktot);
         if (!e) e = spring_reorder_finalize(g[(size_t)k].c);
-        if (e) { rcs[(size_t)k] = e; errs[(size_t)k] = spring_reorder_last_error(); hg.abort_all(); }
+        if (e) {  // the peers must not wait for this rank for ever: host transport and RCCL alike
+          rcs[(size_t)k] = e; errs[(size_t)k] = spring_reorder_last_error(); hg.abort_all();
+          std::lock_guard<std::mutex> lk(comms_mu);
+          for (int j = 0; j < world; j++) if (j != k) sr::mg_comm_abort(comms[(size_t)j]);
+        }
+        { std::lock_guard<std::mutex> lk(comms_mu); comms[(size_t)k] = nullptr; }
         spring_mg_comm_destroy(comm);
       };
       if (!run_ranks(phase2)) return fail(SPRING_REORDER_E_IO, "cannot start the rank threads");

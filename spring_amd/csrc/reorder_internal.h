@@ -64,6 +64,7 @@ int emit_dna_device(spring_reorder_ctx *ctx, int32_t tid, uint8_t **d_out, size_
                     uint64_t s_cnt = ~0ull);
 void emit_dna_free(spring_reorder_ctx *ctx, uint8_t *d);
 
+void mg_comm_abort(spring_mg_comm *c);  // a failed rank of an in-process pool unblocks its peers (ncclCommAbort)
 hipError_t dev_alloc(int dev, size_t bytes, void **out);     // pooled (reorder_pipeline.cpp)
 void dev_free(int dev, void *p);
 int fail(int code, const char *fmt, ...);

@@ -141,12 +141,14 @@ __device__ __forceinline__ uint64_t tab_redirect(const TabView &T, uint64_t h) {
 // 2 = single.  `other` is set when the other dictionary may hold the key too: a slot of it with the same
 // fingerprint in a bucket this call looked at, or a full bucket (its slots may continue in the next one);
 // other == false proves the key absent from the other dictionary.
+// MZ = false: the caller only ever sees hash-addressed tables (the one-chain-per-wavefront kernels: no mark, no redirect)
+template <bool MZ = false>
 __device__ __forceinline__ int tab_find(const TabView &T, uint64_t h, uint32_t mz, int l, int skip,
                                         uint32_t &pay, bool &other) {
   const uint32_t mine = (fp30_of(h) << 2) | ((uint32_t)l << 1), theirs = mine ^ 2u;
   const uint64_t bmask = bucket_mask(T.bshift);
-  uint64_t b = tab_home(T, h, mz);
-  bool first = T.minz != 0;
+  uint64_t b = MZ ? tab_home(T, h, mz) : bucket_of(h, T.bshift);
+  bool first = MZ && T.minz != 0;
   for (;;) {
     // tags only: 98 % of the probes end here
 #if defined(SR_TAGS_NT)
@@ -161,7 +163,7 @@ __device__ __forceinline__ int tab_find(const TabView &T, uint64_t h, uint32_t m
 #else
     const uint4 t = T.buck[b * 2];
 #endif
-    if (first) {  // an over-subscribed line: its keys live on the chain that starts at tab_redirect
+    if (MZ && first) {  // an over-subscribed line: its keys live on the chain that starts at tab_redirect
       first = false;
       if (t.x == TAG_MARK) { b = tab_redirect(T, h); continue; }
     }
@@ -300,6 +302,7 @@ __global__ void k_tab_insert(const uint64_t *__restrict__ mhash, const uint64_t 
   const uint32_t pay = single ? d.ids[st] : u;
   if (cn >= DEEP_BIN) d.deep[atomicAdd(d.ndeep, 1u)] = u;  // bins worth trimming (k_trim_bins); none on low-coverage data
   if (cn >= BIG_BIN) atomicAdd(d.ndeep + 1, cn);
+  if (cn >= MID_BIN) atomicAdd(d.ndeep + 2, cn);
   d.urec[u] = make_ulonglong2(unmix64(h), (uint64_t)st | ((uint64_t)cn << 32));
   if (!OVERFLOW) {
     fpt[b0 * 8 + rank] = tag;
@@ -341,6 +344,7 @@ __global__ void k_minz_prepare(const uint64_t *__restrict__ mhash, const uint64_
   const uint32_t pay = single ? d.ids[st] : u;
   if (cn >= DEEP_BIN) d.deep[atomicAdd(d.ndeep, 1u)] = u;
   if (cn >= BIG_BIN) atomicAdd(d.ndeep + 1, cn);
+  if (cn >= MID_BIN) atomicAdd(d.ndeep + 2, cn);
   d.urec[u] = make_ulonglong2(key, (uint64_t)st | ((uint64_t)cn << 32));
   bucket[i] = ((minz_of_key(key) >> lshift) << 2) | (uint32_t)((h >> 30) & 3ull);
   tagpay[i] = (uint64_t)tag | ((uint64_t)pay << 32);
@@ -402,7 +406,7 @@ __global__ void k_iota_tag(uint64_t *v, uint64_t n, uint64_t tag) {
 // TRIM kernel variants only cuts the dead tail.)
 __global__ __launch_bounds__(256) void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *__restrict__ ndeep,
                                                    ulonglong2 *__restrict__ urec, uint32_t *__restrict__ ids,
-                                                   const uint64_t *__restrict__ taken) {
+                                                   const uint64_t *__restrict__ taken, ulonglong2 *__restrict__ sig /* or null */) {
   const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= *ndeep) return;
@@ -414,9 +418,11 @@ __global__ __launch_bounds__(256) void k_trim_bins(const uint32_t *__restrict__ 
     const uint32_t j = base + lane;
     const uint32_t r = j < count ? ids[start + j] : 0u;
     const bool live = j < count && !is_taken(taken, r);
+    ulonglong2 sg = make_ulonglong2(0, 0);
+    if (sig && live) sg = sig[start + j];
     const uint64_t m = __ballot(live);
     const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-    if (live && pos != j) ids[start + pos] = r;  // (every lane has read its entry before any lane writes)
+    if (live && pos != j) { ids[start + pos] = r; if (sig) sig[start + pos] = sg; }  // (every lane has read its entry before any lane writes)
     w += (uint32_t)__popcll(m);
   }
   if (lane == 0 && w != count) urec[u].y = (uint64_t)start | ((uint64_t)w << 32);
@@ -436,7 +442,7 @@ __global__ void k_dict_lookup(TabView tab, const ulonglong2 *__restrict__ urec, 
   for (int skip = 0;; skip++) {
     uint32_t pay;
     bool other = false;
-    const int kind = tab_find(tab, h, mz, which, skip, pay, other);
+    const int kind = tab_find<true>(tab, h, mz, which, skip, pay, other);
     if (kind == 0) break;
     if (kind == 1) {
       const ulonglong2 r = urec[pay];
@@ -1030,7 +1036,7 @@ struct PendBin { bool on; uint32_t start, count, pay; };
 // SPEC (k_round_mc): candidate reads are fetched speculatively beside their taken bit (cmp_candidate).
 // pre != 0: the caller has seen the key's first slot in the tags of its HOME bucket already (tab_find's result for skip = 0):
 // pre = kind (1 / 2) | slot << 2 -- the walk is skipped for it, the payload word comes from the line the tags came from.
-template <bool TRIM, bool DEFER = false, bool SPEC = false>
+template <bool TRIM, bool DEFER = false, bool SPEC = false, bool MZ = false>
 __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *sx, int l, int rev, int shift,
                                            int ref_len, uint64_t key, uint64_t hsh, uint32_t mz, bool &hit, uint32_t &rid,
                                            bool &keyok, uint32_t &ncand, bool &other, lds_u32_t *s_best, lds_u32_t *stage,
@@ -1058,10 +1064,10 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
     if (skip && beaten()) break;
     uint32_t pay;
     int kind;
-    if (skip == 0 && pre) {
+    if (MZ && skip == 0 && pre) {
       kind = pre & 3;
       pay = reinterpret_cast<const uint32_t *>(P.tab.buck)[tab_home(P.tab, hsh, mz) * 8 + 4 + (pre >> 2)];
-    } else kind = tab_find(P.tab, hsh, mz, l, skip, pay, other);
+    } else kind = tab_find<MZ>(P.tab, hsh, mz, l, skip, pay, other);
     if (skip == 0) PTW(12);
     if (kind == 0) break;  // key absent
     // a single-read bin (kind 2: pay is the read id) runs through the same scan as a bin of one entry; its key is
@@ -1503,9 +1509,11 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   }
   if (!handed_over && !o.found && t0 < P.maxshift) {
     wave_sync();  // s_pres
-    int walk_left = budget;  // (what the ordered batches left of it)
+    // (what the ordered batches left of the budget; "no budget" is a huge one rather than a null pointer: a pointer that is
+    // selected at run time keeps the variable in scratch memory)
+    int walk_left = (lng && t0 > 0) ? budget : 0x7fffffff;
     probe_tail<STATS, TRIM>(P, sref, srev, s_list, s_stat, t0, s_pres, lane, ref_len, s_best, s_stage, min_code, o,
-                            (lng && t0 > 0) ? &walk_left : nullptr);
+                            LONG ? &walk_left : nullptr);
     if (lng && t0 > 0) {
       wave_sync();
       handed_over = __builtin_amdgcn_readfirstlane((int)*(volatile lds_u32_t *)s_best) == 0;
@@ -1518,7 +1526,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
     // the iteration bookkeeping above stays; the proposal fields still hold the last proposal (k_long derives the
     // resume point from them exactly as this search did) and k_long writes the new one
     store_hot(c, h, lane, 2, 4);
-    if (lane == 0) P.longq[1 + atomicAdd(&P.longq[0], 1u)] = cid - P.c0;
+    if (lane == 0) P.longq[2 + atomicAdd(&P.longq[0], 1u)] = cid - P.c0;
     return -4;
   }
   {
@@ -1557,7 +1565,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
 // ------------------------------------------------------------ K4 search (phase A of the two-kernel round)
 // WPB = chains (wavefronts) per block.
 template <bool STATS, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_search(DevParams P) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_search(DevParams P) {  // (7: no scratch)
   __shared__ uint64_t s_refs[WPB][2][LDS_LIMBS];
   __shared__ uint16_t s_list[WPB][TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
@@ -1776,11 +1784,12 @@ __global__ __launch_bounds__(256) void k_apply(DevParams P) {
 // taken bits, the cursor and the needy bitmap from the proposal words -- runs between the two launches; the
 // resv[] entries the apply halves read belong to reads that are all taken by then, so the proposals of round t
 // never touch them.
-// MG (one pool over several GPUs): a rank runs its own chains only and publishes one word per chain; the lowest-
-// chain-id resolution (k_mg_resolve) runs after the all-gather on every rank, then k_mg_mark.  One GPU: the
-// proposals go straight to resv[] (atomicMin) and the words are only k_mg_mark's input.
-template <int NP, bool STATS, bool MG, bool TRIM, bool LONG = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_round(DevParams P) {
+// MG (one pool over several GPUs): a rank runs its own chains only and publishes one word per chain.  Its own proposals go
+// straight to resv[] (atomicMin), as on one GPU; after the all-gather k_mg_resolve adds the other ranks' words (lowest
+// chain id wins whatever the order), then k_mg_mark.  (MG no longer changes the code of the round kernels: round 3 left
+// ALL the resolution to k_mg_resolve, a pass over every chain of the pool on every rank.)
+template <int NP, bool STATS, bool MG, bool TRIM, bool LONG>
+__device__ __forceinline__ void round_body(const DevParams &P) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
   __shared__ uint16_t s_list[TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? 2 * TAIL_CAP : 2];
@@ -1824,7 +1833,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     PT_FLUSH(c);
     return;
   }
-  (void)search_step<STATS, true, !MG, TRIM, LONG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
+  (void)search_step<STATS, true, true, TRIM, LONG>(P, c, cid, h, lane, &s_refs[0][0], s_list, s_stat, s_pres, (lds_u32_t *)&s_best, (lds_u32_t *)s_stage);
   PT_FLUSH(c);
 #ifdef SR_PHASE_TIMING
   {
@@ -1835,6 +1844,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
   }
 #endif
+}
+// Two kernels over the one body, because the register budget is a kernel attribute: the shallow-dictionary variant sits at
+// 64 VGPRs (8 waves per SIMD) without scratch; the deep-bin variants (TRIM: tail trimming, balanced scan, resumed
+// searches, owner-first apply, k_long hand-over) carry more live state and get SR_TRIM_WAVES waves per SIMD.
+// Measured (profiles/r04_trim_waves.txt, 20 M-read pools, chains stage, 8 / 7 / 6 waves per SIMD): 400x 110.3 / 109.0 / 114.8 ms,
+// 1 600x 124.3 / 122.0 / 128.4, 6 400x 143.4 / 139.5 / 148.2, 25 600x 183.2 / 177.5 / 184.3, PhiX-like 196.7 / 191.8 / 194.4:
+// 7 waves (72 VGPRs) -- at 8 the variants spill 8-13 VGPRs to 20-40 bytes of scratch per lane, at 7 none; the variant with
+// the k_long hand-over still spills one there and gets 6 (79 VGPRs).  No chain kernel uses scratch memory.
+#ifndef SR_TRIM_WAVES
+#define SR_TRIM_WAVES 7
+#endif
+#ifndef SR_LONG_WAVES
+#define SR_LONG_WAVES 6
+#endif
+template <int NP, bool STATS, bool MG, bool TRIM, bool LONG = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_ROUND_WAVES, SR_ROUND_WAVES))) void k_round(DevParams P) {
+  static_assert(!TRIM, "deep-bin variants: k_round_t");
+  round_body<NP, STATS, MG, false, false>(P);
+}
+template <int NP, bool STATS, bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_TRIM_WAVES, SR_TRIM_WAVES))) void k_round_t(DevParams P) {
+  round_body<NP, STATS, MG, true, false>(P);
+}
+template <int NP, bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_LONG_WAVES, SR_LONG_WAVES))) void k_round_tl(DevParams P) {
+  round_body<NP, false, MG, true, true>(P);
+}
+
+template <int NP, bool STATS, bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_ROUND_WAVES, SR_ROUND_WAVES))) void k_round_nt(DevParams P) {
+  round_body<NP, STATS, MG, false, false>(P);
 }
 
 // ------------------------------------------------------------ long searches: one block of 16 wavefronts per chain
@@ -1849,7 +1889,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 //      entry whose bin has fewer than MAX_SEARCH_REORDER live entries ahead of it wins, a bin that reaches the limit
 //      is left for the next one.  The scan stops at the first winner, so nothing behind it is compared.
 // Dead bin tails are not trimmed here (k_round's scans and k_trim_bins do that).
+// Signatures (k_long): beside every dictionary entry (same index as ids[l]) the first and the last limb of its read.  The
+// Hamming distance over the bases of those two limbs that lie inside the compared range is a lower bound of the distance
+// reorder.h:291-301 computes, so an entry whose bound already exceeds THRESH_REORDER is rejected from 16 bytes that arrive
+// coalesced with its id -- exactly the entries the full compare would reject, minus a random 64-byte read each.  In the
+// bins that matter here (the 32-mers of a repeat family: reads of hundreds of diverged copies) that is nine entries in ten.
+__global__ void k_build_sig(const uint32_t *__restrict__ ids, uint64_t m, const uint64_t *__restrict__ reads, int S, int W,
+                            ulonglong2 *__restrict__ sig) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint64_t *r = reads + (uint64_t)ids[i] * S;
+  sig[i] = make_ulonglong2(r[0], r[W - 1]);
+}
+void launch_build_sig(hipStream_t st, const uint32_t *ids, uint64_t m, const uint64_t *reads, int S, int W, ulonglong2 *sig) {
+  if (m) hipLaunchKernelGGL(k_build_sig, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, ids, m, reads, S, W, sig);
+}
+// lower bound of cmp_candidate's Hamming distance from the signature limbs (same range and masks as there)
+__device__ __forceinline__ int sig_bound(const DevParams &P, const uint64_t *sx, int bitshift, int lo, int mref, uint32_t r,
+                                         const ulonglong2 &sg) {
+  const int W = P.W;
+  const int clen = P.uniform_len ? P.L : (int)P.lens[r];
+  const int m = clen < mref ? clen : mref;
+  const int blo = 2 * lo, bhi = 2 * m;
+  if (bhi <= blo) return 0;
+  const int first = blo >> 6, last = (bhi - 1) >> 6;
+  int hd = 0;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int i = t ? W - 1 : 0;
+    if ((t && W == 1) || i < first || i > last) continue;
+    uint64_t y = lds_window(sx, i * 64 + bitshift) ^ (t ? sg.y : sg.x);
+    if (i == first) y &= ~0ull << (blo & 63);
+    if (i == last) y &= ~0ull >> (63 - ((bhi - 1) & 63));
+    hd += __popcll(y);
+  }
+  return hd;
+}
+
 constexpr int LONG_WAVES = 16;
+// chunks of 64 bin entries a wavefront takes per step.  4 (4 096 entries per block and step, the survivors of the signature
+// test packed into one or two compare passes) cuts the steps of a search from 15 to 5 and makes each 3.2 times as long:
+// 100 M genome-like reads 4.94 s against 3.35 s with 1 (profiles/r04_genomic.txt) -- a step costs what its entries cost
+constexpr int LONG_CPW = 1;
 struct LongRes { uint32_t live, first, before, rid; };  // live entries of the chunk; first passing entry (64: none), live ones ahead of it, its read
 __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direct) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
@@ -1858,16 +1939,26 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
   __shared__ uint16_t s_bcode[64 * LONG_WAVES];
   __shared__ uint32_t s_wcnt[LONG_WAVES];
   __shared__ uint32_t s_best, s_bestrid, s_ctl, s_win_code, s_win_rid, s_capped;
-  __shared__ LongRes s_res[LONG_WAVES];
-  __shared__ uint32_t s_asg_bin[LONG_WAVES], s_asg_q[LONG_WAVES];
+  __shared__ LongRes s_res[LONG_WAVES * LONG_CPW];
+  __shared__ uint32_t s_asg_bin[LONG_WAVES * LONG_CPW], s_asg_q[LONG_WAVES * LONG_CPW];
+  __shared__ uint32_t s_srv[LONG_WAVES][64 * LONG_CPW];   // per wavefront: the entries of its chunks that survive the signature test ...
+  __shared__ uint8_t s_srv_at[LONG_WAVES][64 * LONG_CPW]; // ... where each came from (chunk << 6 | lane) ...
+  __shared__ uint8_t s_pass[LONG_WAVES][64 * LONG_CPW];   // ... and which of them pass the full compare
   const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
   const uint32_t npend = P.longq[0];
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   lds_u32_t *stage = (lds_u32_t *)s_stage[wave];
   const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
-  for (uint32_t qi = blockIdx.x; qi < npend; qi += gridDim.x) {
-    const uint32_t li = P.longq[1 + qi];
+  // the blocks take the queued searches as they become free (a ticket counter, longq[1]): searches differ in length by two
+  // orders of magnitude and a launch lasts as long as its most loaded block
+  __shared__ uint32_t s_qi;
+  for (;;) {
+    if (tid == 0) s_qi = atomicAdd(&P.longq[1], 1u);
+    __syncthreads();
+    const uint32_t qi = s_qi;
+    if (qi >= npend) break;
+    const uint32_t li = P.longq[2 + qi];
     const uint32_t cid = P.c0 + li;
     Chain *c = &P.chains[li];
     if (tid < LDS_LIMBS) {
@@ -1886,6 +1977,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       const int pr = (int)h.prop_rev;
       if (pr & 4) min_code = ((int)h.prop_shift << 2) | ((pr & 1) << 1) | ((pr >> 1) & 1);
     }
+#ifdef SR_LONG_COUNT
+    const long long lc_t0 = clock64();
+#endif
     // ---- 1. one thread per probe
     const int code = tid, l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
     const bool valid = probe_valid(P, l, rev, shift, ref_len) && code >= min_code;
@@ -1915,6 +2009,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         s_bstart[at] = pend.start; s_bcount[at] = pend.count; s_bcode[at] = (uint16_t)code;
       }
     }
+#ifdef SR_LONG_COUNT
+    const long long lc_t1 = clock64();
+#endif
     // ---- 2. the bins, 16 chunks per step
     uint32_t nx_bin = 0, nx_q = 0, cur = 0xffffffffu, cur_live = 0;  // thread 0: next chunk; bin whose live count is cur_live
     bool cur_skip = false, have_res = false, done = false;
@@ -1940,7 +2037,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         }
         n_asg = 0;
         if (!done) {
-          while (n_asg < (uint32_t)LONG_WAVES && nx_bin < nb) {
+          while (n_asg < (uint32_t)(LONG_WAVES * LONG_CPW) && nx_bin < nb) {
             if ((uint32_t)s_bcode[nx_bin] > best_single) { nx_bin = nb; break; }  // behind a single-read bin that hit
             if ((uint64_t)nx_q * 64 >= s_bcount[nx_bin]) { nx_bin++; nx_q = 0; continue; }
             s_asg_bin[n_asg] = nx_bin; s_asg_q[n_asg] = nx_q;
@@ -1953,38 +2050,91 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       __syncthreads();
       const uint32_t na = s_ctl;
       if (na == 0) break;
-      if ((uint32_t)wave < na) {
-        const uint32_t b = s_asg_bin[wave], q = s_asg_q[wave];
-        const int pcode = (int)s_bcode[b];
-        const int pl = pcode & 1, prev = (pcode >> 1) & 1, psh = pcode >> 2;
-        const uint32_t cnt = s_bcount[b], st0 = s_bstart[b];
-        const long long j = (long long)cnt - 1 - ((long long)q * 64 + lane);
-        bool lv = false, ps = false;
-        uint32_t r = 0;
-        if (j >= 0) {
-          typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
-          g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
-          r = pids[st0 + (uint32_t)j];
-          // (the limbs are fetched while the taken word is on its way: one dependent step less per chunk; the memory
-          // system is idle in the rounds this kernel matters in)
-          const uint64_t tw = P.taken[r >> 6];
-          const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
-          const bool pass = cmp_candidate<true, true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
-                                                      prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
-          lv = !((tw >> (r & 63)) & 1ull);
-          ps = lv && pass;
+      if ((uint32_t)wave * LONG_CPW < na) {
+        // ---- this wavefront's chunks: assignments LONG_CPW * wave + k.  A: id, signature and taken bit of every entry (coalesced
+        // but for the bitmap word); entries that are live and pass the signature bound survive.  B: the survivors of all the
+        // chunks, packed into as few 64-lane passes as they need, fetch their reads and are compared in full.  C: per
+        // chunk, what thread 0 folds: live entries, first passing entry, live entries ahead of it.
+        typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+        uint32_t rk[LONG_CPW];
+        uint64_t Lm[LONG_CPW], Sm[LONG_CPW];
+        uint32_t nsrv = 0;
+#pragma unroll
+        for (int k = 0; k < LONG_CPW; k++) {
+          const uint32_t a = (uint32_t)wave * LONG_CPW + k;
+          bool lv = false, sv = false;
+          uint32_t r = 0;
+          if (a < na) {
+            const uint32_t b = s_asg_bin[a], q = s_asg_q[a];
+            const int pcode = (int)s_bcode[b];
+            const int pl = pcode & 1, prev = (pcode >> 1) & 1, psh = pcode >> 2;
+            const uint32_t cnt = s_bcount[b], st0 = s_bstart[b];
+            const long long j = (long long)cnt - 1 - ((long long)q * 64 + lane);
+            if (j >= 0) {
+              g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
+              const ulonglong2 *psig = pl ? uni_ptr(P.sig[1]) : uni_ptr(P.sig[0]);
+              r = pids[st0 + (uint32_t)j];
+              const ulonglong2 sg = psig[st0 + (uint32_t)j];
+              const uint64_t tw = P.taken[r >> 6];
+              lv = !((tw >> (r & 63)) & 1ull);
+              sv = lv && sig_bound(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                   prev ? ref_len + psh : ref_len - psh, r, sg) <= THRESH;
+            }
+          }
+          rk[k] = r;
+          Lm[k] = __ballot(lv);
+          Sm[k] = __ballot(sv);
+          if (sv) {
+            const uint32_t at = nsrv + (uint32_t)__popcll(Sm[k] & ((1ull << lane) - 1));
+            s_srv[wave][at] = r;
+            s_srv_at[wave][at] = (uint8_t)((k << 6) | lane);
+          }
+          s_pass[wave][k * 64 + lane] = 0;
+          nsrv += (uint32_t)__popcll(Sm[k]);
         }
-        const uint64_t Lm = __ballot(lv), Pm = __ballot(ps);
-        const int fp = Pm ? __ffsll((unsigned long long)Pm) - 1 : 64;
-        const uint32_t wr = (uint32_t)__shfl((int)r, fp & 63, 64);
+        wave_sync();
+#ifdef SR_LONG_COUNT
         if (lane == 0) {
-          LongRes o;
-          o.live = (uint32_t)__popcll(Lm); o.first = (uint32_t)fp;
-          o.before = fp < 64 ? (uint32_t)__popcll(Lm & ((1ull << fp) - 1)) : 0u; o.rid = wr;
-          s_res[wave] = o;
+          unsigned long long e = 0, l = 0;
+          for (int k = 0; k < LONG_CPW; k++) { l += __popcll(Lm[k]); e += __popcll(Sm[k]); }
+          atomicAdd((unsigned long long *)&c->st_keyok, e);   // survivors of the signature test
+          atomicAdd((unsigned long long *)&c->st_cands, l);   // live entries
+          atomicAdd((unsigned long long *)&c->st_probes, 1ull);
+        }
+#endif
+        for (uint32_t base = 0; base < nsrv; base += 64) {
+          const uint32_t idx = base + lane;
+          if (idx < nsrv) {
+            const uint32_t r = s_srv[wave][idx];
+            const uint32_t at = s_srv_at[wave][idx];
+            const uint32_t a = (uint32_t)wave * LONG_CPW + (at >> 6);
+            const int pcode = (int)s_bcode[s_asg_bin[a]];
+            const int pl = pcode & 1, prev = (pcode >> 1) & 1, psh = pcode >> 2;
+            const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+            if (cmp_candidate<true, true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                          prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1)
+              s_pass[wave][at] = 1;
+          }
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < LONG_CPW; k++) {
+          const uint32_t a = (uint32_t)wave * LONG_CPW + k;
+          const uint64_t Pm = __ballot(s_pass[wave][k * 64 + lane] != 0);
+          const int fp = Pm ? __ffsll((unsigned long long)Pm) - 1 : 64;
+          const uint32_t wr = (uint32_t)__shfl((int)rk[k], fp & 63, 64);
+          if (lane == 0 && a < na) {
+            LongRes o;
+            o.live = (uint32_t)__popcll(Lm[k]); o.first = (uint32_t)fp;
+            o.before = fp < 64 ? (uint32_t)__popcll(Lm[k] & ((1ull << fp) - 1)) : 0u; o.rid = wr;
+            s_res[a] = o;
+          }
         }
       }
     }
+#ifdef SR_LONG_COUNT
+    if (tid == 0) { c->st_iter += (unsigned long long)(lc_t1 - lc_t0); c->st_hits += (unsigned long long)(clock64() - lc_t1); }
+#endif
     // ---- the proposal (as the end of search_step)
     if (wave == 0) {
       const uint32_t wm = s_win_code, ws = best_single;
@@ -2023,9 +2173,11 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
 // (Work per rank that grows with the number of GPUs: two thread-per-chain passes, a few microseconds.)
 
 // lowest chain id wins a contested read
+// (the OTHER ranks' words only: a rank settles its own proposals in its round kernel, as a single GPU does)
 __global__ void k_mg_resolve(DevParams P) {
-  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cid >= P.Ktot) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.Ktot - P.K) return;
+  const uint32_t cid = t < P.c0 ? t : t + P.K;
   const unsigned long long pv = P.prop[cid];
   const int pk = (int)(pv >> 32) & 7;
   if (pk == PK_MATCH || pk == PK_SEED) atomicMin(&P.resv[(uint32_t)pv], cid);
@@ -2073,7 +2225,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   }
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
-  if (cid == 0 && P.longq) P.longq[0] = 0;  // this round's long searches are done (k_long ran before this kernel)
+  if (cid == 0 && P.longq) { P.longq[0] = 0; P.longq[1] = 0; }  // this round's long searches are done (k_long ran before this kernel)
   if (P.ord) {  // class lists of this block's chains (k_round_mc): class 0 first, no atomics
     static_assert(MARK_BLOCK == 256, "k_mg_mark runs 256 chains per block");
     __shared__ uint32_t s_wc[4][4];  // [wave][class]
@@ -2249,9 +2401,9 @@ void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag) {
   hipLaunchKernelGGL(k_iota_tag, GRID1(n, 256), dim3(256), 0, st, v, n, tag);
 }
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
-                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken) {
+                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken, ulonglong2 *sig) {
   if (!ndeep_host) return;
-  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 4), dim3(256), 0, st, deep, ndeep, urec, const_cast<uint32_t *>(ids), taken);
+  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 4), dim3(256), 0, st, deep, ndeep, urec, const_cast<uint32_t *>(ids), taken, sig);
 }
 void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,
@@ -2354,8 +2506,8 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
       if (mg) hipLaunchKernelGGL((k_round_mc<3, true>), g4, b, 0, st, P);
       else hipLaunchKernelGGL((k_round_mc<3, false>), g4, b, 0, st, P);
     } else {
-      if (mg) hipLaunchKernelGGL((k_round_mc<8, true>), g4, b, 0, st, P);
-      else hipLaunchKernelGGL((k_round_mc<8, false>), g4, b, 0, st, P);
+      if (mg) hipLaunchKernelGGL((k_round_mc_long<true>), g4, b, 0, st, P);
+      else hipLaunchKernelGGL((k_round_mc_long<false>), g4, b, 0, st, P);
     }
     return;
   }
@@ -2363,29 +2515,30 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   if (stats || mg || P.deep_bins || P.Lpad > 192) abort();
   hipLaunchKernelGGL((k_round<3, false, false, false>), g, b, dyn, st, P);
 #else
-#define RCALL2(N, T)                                                                         \
+#define RCALL2(N, KERN)                                                                      \
   do {                                                                                       \
-    if (mg) { if (stats) hipLaunchKernelGGL((k_round<N, true, true, T>), g, b, dyn, st, P);  \
-              else hipLaunchKernelGGL((k_round<N, false, true, T>), g, b, dyn, st, P); }     \
-    else { if (stats) hipLaunchKernelGGL((k_round<N, true, false, T>), g, b, dyn, st, P);    \
-           else hipLaunchKernelGGL((k_round<N, false, false, T>), g, b, dyn, st, P); }       \
+    if (mg) { if (stats) hipLaunchKernelGGL((KERN<N, true, true>), g, b, dyn, st, P);        \
+              else hipLaunchKernelGGL((KERN<N, false, true>), g, b, dyn, st, P); }           \
+    else { if (stats) hipLaunchKernelGGL((KERN<N, true, false>), g, b, dyn, st, P);          \
+           else hipLaunchKernelGGL((KERN<N, false, false>), g, b, dyn, st, P); }             \
   } while (0)
-#define RCALL(N) do { if (P.deep_bins) RCALL2(N, true); else RCALL2(N, false); } while (0)
+#define RCALL(N) do { if (P.deep_bins) RCALL2(N, k_round_t); else RCALL2(N, k_round_nt); } while (0)
   if (P.deep_bins && !stats && P.long_budget > 0 && P.longq) {
     // pools of very deep bins: the variant that hands long searches over, then k_long for them (a fixed grid, each
     // block takes queue entries in turn)
-#define LCALL(N) do { if (mg) hipLaunchKernelGGL((k_round<N, false, true, true, true>), g, b, dyn, st, P); \
-                      else hipLaunchKernelGGL((k_round<N, false, false, true, true>), g, b, dyn, st, P); } while (0)
+#define LCALL(N) do { if (mg) hipLaunchKernelGGL((k_round_tl<N, true>), g, b, dyn, st, P); \
+                      else hipLaunchKernelGGL((k_round_tl<N, false>), g, b, dyn, st, P); } while (0)
     if (P.Lpad <= 192) LCALL(3); else LCALL(8);
 #undef LCALL
-    hipLaunchKernelGGL(k_long, dim3(std::min<uint32_t>(P.K, (uint32_t)P.long_blocks)), dim3(64 * LONG_WAVES), 0, st, P, mg ? 0 : 1);
+    hipLaunchKernelGGL(k_long, dim3(std::min<uint32_t>(P.K, (uint32_t)P.long_blocks)), dim3(64 * LONG_WAVES), 0, st, P, 1);
   } else if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL
 #endif
 }
 void launch_mg_resolve(hipStream_t st, const DevParams &P) {
-  hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
+  if (P.Ktot == P.K) return;  // one rank: nothing foreign
+  hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot - P.K, 256), dim3(256), 0, st, P);
 }
 void launch_mg_mark(hipStream_t st, const DevParams &P) {
   hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);

@@ -118,6 +118,7 @@ struct DictDev {
   uint32_t *deep = nullptr, *d_ndeep = nullptr;  // bins with >= DEEP_BIN reads (k_trim_bins)
   uint32_t ndeep = 0;
   uint32_t big_reads = 0;   // reads in bins of >= BIG_BIN entries (d_ndeep[1]): the pools whose long searches go to k_long
+  uint32_t mid_reads = 0;   // reads in bins of >= MID_BIN entries (d_ndeep[2]): the heavy-tail rule
 };
 
 struct spring_reorder_ctx {
@@ -223,6 +224,7 @@ struct Rccl {
   int (*GetUniqueId)(void *) = nullptr;
   int (*CommInitRank)(void **, int, RcclId128, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommAbort)(void *) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
@@ -237,6 +239,7 @@ int rccl_load() {
   g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");  // (optional: only used to unblock the peers of a failed rank)
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather)
@@ -247,12 +250,37 @@ int rccl_load() {
 const char *rccl_err(int e) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error"; }
 constexpr int RCCL_UINT64 = 5;  // ncclUint64 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4, ncclUint64 5)
 }  // namespace
+// The prototypes above are written by hand so that the library builds and runs where RCCL's header is absent and never links
+// against librccl.  Where the header IS present at build time they are checked against it: same argument lists (an enum or
+// an opaque handle where this file says int / void *, which the x86-64 ABI passes alike), same ncclUniqueId size, same
+// datatype code.
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert(sizeof(ncclUniqueId) == sizeof(RcclId128) && NCCL_UNIQUE_ID_BYTES == 128, "ncclUniqueId is not 128 bytes");
+static_assert((int)ncclUint64 == RCCL_UINT64, "ncclUint64 has another code");
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclComm_t) == sizeof(void *),
+              "enum / handle sizes differ from the hand-written prototypes");
+static_assert(std::is_same<decltype(&ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId *)>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t *, int, ncclUniqueId, int)>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclCommAbort), ncclResult_t (*)(ncclComm_t)>::value, "ncclCommAbort");
+static_assert(std::is_same<decltype(&ncclAllGather),
+                           ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value, "ncclAllGather");
+static_assert(std::is_same<decltype(&ncclGetErrorString), const char *(*)(ncclResult_t)>::value, "ncclGetErrorString");
+#endif
+#endif
+namespace {
+}  // namespace
 
 // exchange transport of mg_run: an RCCL communicator or a caller-supplied host all-gather
 struct spring_mg_comm {
   uint32_t rank = 0, world = 1;
   int dev = 0;
   void *rccl = nullptr;
+  std::mutex mu;          // rccl handle: destroy / abort
+  bool aborted = false;
   spring_mg_allgather_fn host_fn = nullptr;
   void *host_user = nullptr;
 };
@@ -917,7 +945,7 @@ int spring_synth_genome_host(uint8_t *dst, uint64_t G, uint64_t seed, uint32_t f
       const uint64_t seg = G / 8, k = seg ? gp / seg : 0;
       if (seg && k < 8 && (k & 1) == 0) gp %= seg;
     }
-    dst[p] = (uint8_t)"ACGT"[syn_genome_base(seed, gp)];
+    dst[p] = (uint8_t)"ACGT"[(flags & SYN_GENOMIC_FLAG) ? syn_genomic_base(seed, gp) : syn_genome_base(seed, gp)];
   }
   return 0;
 }
@@ -1028,13 +1056,13 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     }
     d.numreads = m;
     d.numkeys = 0;
-    d.ndeep = 0; d.big_reads = 0;
+    d.ndeep = 0; d.big_reads = 0; d.mid_reads = 0;
     if (m == 0) {
       DMALLOC(d.urec, 16);
       DMALLOC(d.ids, 16);
       DMALLOC(d.deep, 16);
       DMALLOC(d.d_ndeep, 16);
-      HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 8, st));
+      HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 12, st));
       if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
       continue;
     }
@@ -1084,7 +1112,7 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
     // deep-bin list: at most one entry per DEEP_BIN reads of the dictionary
     DMALLOC(d.deep, ((size_t)m / DEEP_BIN + 1) * 4);
     DMALLOC(d.d_ndeep, 16);
-    HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 8, st));
+    HIPCHK(hipMemsetAsync(d.d_ndeep, 0, 12, st));
     HIPCHK(hipStreamSynchronize(st));
     ctx->dfree(d_tmp);
     if (d_flag) { ctx->dfree(d_flag); ctx->dfree(d_slot); }
@@ -1161,11 +1189,14 @@ int spring_reorder_build_dict(spring_reorder_ctx *ctx) {
       HIPCHK(hipMemcpyAsync(&ctx->marked_lines, d_marked, 4, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipGetLastError());
-    uint32_t nd[2][2] = {{0, 0}, {0, 0}};
+    uint32_t nd[2][3] = {{0, 0, 0}, {0, 0, 0}};
     for (int l = 0; l < 2; l++)
-      HIPCHK(hipMemcpyAsync(nd[l], ctx->dict[l].d_ndeep, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(nd[l], ctx->dict[l].d_ndeep, 12, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int l = 0; l < 2; l++) { ctx->dict[l].ndeep = nd[l][0]; ctx->dict[l].big_reads = nd[l][1]; }
+    for (int l = 0; l < 2; l++) { ctx->dict[l].ndeep = nd[l][0]; ctx->dict[l].big_reads = nd[l][1]; ctx->dict[l].mid_reads = nd[l][2]; }
+    if (dbg) fprintf(stderr, "[dict] reads %u + %u, keys %u + %u, bins >= %u: %u + %u, reads in bins >= %u: %u + %u, >= %u: %u + %u\n",
+                     ctx->dict[0].numreads, ctx->dict[1].numreads, ctx->dict[0].numkeys, ctx->dict[1].numkeys, DEEP_BIN, nd[0][0], nd[1][0],
+                     MID_BIN, nd[0][2], nd[1][2], BIG_BIN, nd[0][1], nd[1][1]);
     ctx->stats.table_marked_lines = ctx->marked_lines;
     DBG_T("insert");
     ctx->dfree(mv0); ctx->dfree(mv1); ctx->dfree(mh); ctx->dfree(mv); ctx->dfree(d_tmp);
@@ -1229,9 +1260,19 @@ static bool dict_is_deep(const spring_reorder_ctx *ctx) {
 // of compressed size).  tools/variant_probe2.py, chains stage in ms, four chains per wavefront / one chain / one chain
 // with the deep-bin machinery: 100 M reads at 100x (1.09 reads per key) 418 / 423 / 439, at 200x (1.18) 493 / 472 / 471;
 // 20 M reads at 100x 130 / 109 / 113, at 200x 159 / 124 / 125; at 400x and up (>= 1.3) the deep variant wins by 15-40 %
+// A HEAVY TAIL of bins: at least 0.1 % of the dictionary's reads sit in bins of >= MID_BIN (64) entries although the
+// average bin may hold a single read (uniform genomes have none there up to 6 400x; genome-like pools 0.15 % at 5 M reads,
+// 1.1 % at 20 M, 1.3 % at 100 M) -- what the repeat families of a real genome do to the dictionary (round 4,
+// SPRING_SYNTH_GENOMIC pools: 1.02 reads per key on average, bins of thousands of reads for the 32-mers of the big
+// families).  Averages do not see it, and the shallow-dictionary kernels then walk those bins one candidate per
+// dependent step: 100 M x 150 bp took 41 s (2.4 Mreads/s) before this rule, against 0.44 s on the uniform genome.
+static bool dict_has_heavy_tail(const spring_reorder_ctx *ctx) {
+  const uint64_t mid = (uint64_t)ctx->dict[0].mid_reads + ctx->dict[1].mid_reads, nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads;
+  return nd > 0 && mid * 1000 >= nd;
+}
 static bool dict_wants_deep_kernel(const spring_reorder_ctx *ctx) {
   const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
-  return nd * 100 >= nk * 115;
+  return nd * 100 >= nk * 115 || dict_has_heavy_tail(ctx);
 }
 // ... and a quarter of its reads sit in bins of >= BIG_BIN entries: bins of hundreds of reads are the rule (PhiX-like
 // pools, tens of thousands x): long searches go to k_long, and more than 65 536 chains make it slower, not faster
@@ -1306,7 +1347,9 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // entries: PhiX-like, tens of thousands x), where a failing search compares thousands of candidates.  Below that a
   // hand-over does not pay (k_long's own latency is added to the round: 25 600x +-0, 6 400x -4 %), so those pools run
   // the variant of k_round without it; opts.long_budget > 0 forces it on (tests), -1 off.
-  const bool very_deep = P.deep_bins && dict_is_very_deep(ctx);
+  // (heavy tail on a dictionary that is shallow on average: the long searches are what a round waits for; pools that are
+  // deep on average keep their own rule -- 25 600x: 178 ms without the hand-over, 195 with)
+  const bool very_deep = P.deep_bins && (dict_is_very_deep(ctx) || (dict_has_heavy_tail(ctx) && !dict_is_deep(ctx)));
   P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : (very_deep ? 8 : 0));
   P.long_blocks = 512;
   // ... and only when at least this many bin entries are still ahead of it (32 compare passes of one wavefront, two
@@ -1316,6 +1359,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   if (o.long_min > 0) P.long_min = o.long_min;
   if (o.long_blocks > 0) P.long_blocks = o.long_blocks;
   P.longq = nullptr;
+  P.sig[0] = P.sig[1] = nullptr;
 }
 // Default chain count.  ~1000 reads per chain: the compressed size grows with the chain count on ordinary coverage
 // (+7 % from n/1024 to 65 536 chains at 16 M reads).  On deep-coverage pools (the dictionary
@@ -1327,9 +1371,12 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
 // instead of 65 536 chains run 1 600x / 6 400x / 25 600x 5 / 13 / 20 % faster at -1.4 / -0.6 / +0.3 % of the compressed
 // size (profiles/r03_chain_count_deep.txt), so their cap is 131 072; pools of very deep bins stay at 65 536 (the
 // PhiX-like pool takes 220 ms with 65 536 chains, 350 with 131 072).
-static uint32_t auto_chains(uint32_t n, bool deep, bool very_deep) {
-  uint64_t k = deep ? n >> 7 : n >> 10;
-  const uint64_t cap = (deep && !very_deep) ? 131072 : 65536;
+// Pools with a heavy tail of bins (dict_has_heavy_tail; shallow on average): a round lasts as long as its longest bin scans
+// whatever the chain count, so more chains per round are nearly free: 20 M genome-like reads, chains stage 1 453 / 737 /
+// 511 / 483 ms with 19 531 / 65 536 / 131 072 / 262 144 chains (profiles/r04_genomic.txt) -- n / 128 up to 131 072 as well.
+static uint32_t auto_chains(uint32_t n, bool deep, bool very_deep, bool heavy_tail = false) {
+  uint64_t k = (deep || heavy_tail) ? n >> 7 : n >> 10;
+  const uint64_t cap = ((deep && !very_deep) || (heavy_tail && !deep)) ? 131072 : 65536;
   if (k < 1) k = 1;
   if (k > cap) k = cap;
   return (uint32_t)k;
@@ -1396,8 +1443,15 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     DMALLOC(P.ord, nmark * MARK_BLOCK * 4);
     DMALLOC(P.ord_cnt, nmark * sizeof(uint4));
     if (P.deep_bins && P.long_budget > 0) {  // queue of the searches k_round hands to k_long
-      DMALLOC(P.longq, ((size_t)K + 1) * 4);
-      HIPCHK(hipMemsetAsync(P.longq, 0, 4, st));
+      DMALLOC(P.longq, ((size_t)K + 2) * 4);
+      HIPCHK(hipMemsetAsync(P.longq, 0, 8, st));
+      for (int l = 0; l < 2; l++) {  // ... and the signatures k_long rejects most bin entries from (16 bytes per dictionary entry)
+        ulonglong2 *sg = nullptr;
+        const uint64_t m = ctx->dict[l].numreads;
+        DMALLOC(sg, std::max<uint64_t>(m, 1) * sizeof(ulonglong2));
+        launch_build_sig(st, ctx->dict[l].ids, m, ctx->d_reads, ctx->S, ctx->W, sg);
+        P.sig[l] = sg;
+      }
     }
   } else {
     P.ord = nullptr; P.ord_cnt = nullptr;
@@ -1451,7 +1505,7 @@ int spring_reorder_auto_chains(spring_reorder_ctx *ctx, uint32_t *chains, int32_
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage < ST_DICT) return fail(SPRING_REORDER_E_STATE, "auto_chains: build_dict first");
   const bool d = dict_is_deep(ctx);
-  if (chains) *chains = auto_chains(ctx->n, d, dict_is_very_deep(ctx));
+  if (chains) *chains = auto_chains(ctx->n, d, dict_is_very_deep(ctx), dict_has_heavy_tail(ctx));
   if (deep) *deep = d ? 1 : 0;
   return 0;
 }
@@ -1462,14 +1516,14 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
   const uint32_t n = ctx->n;
-  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n, dict_is_deep(ctx), dict_is_very_deep(ctx));
+  const uint32_t K = ctx->o.num_chains ? ctx->o.num_chains : auto_chains(n, dict_is_deep(ctx), dict_is_very_deep(ctx), dict_has_heavy_tail(ctx));
   const bool stats = ctx->o.collect_stats != 0;
   const bool timed = ctx->o.time_search != 0;
   const bool literal = ctx->o.force_literal_update != 0;
   // one chain kernel per round (k_round + k_mg_mark) unless the literal consensus path or the two-kernel round is asked for
   const bool fused = !literal && ctx->o.fused >= 0;
   ctx->stats.chains = K;
-  ctx->stats.deep_pool = dict_is_deep(ctx) ? 1 : 0;
+  ctx->stats.deep_pool = (dict_is_deep(ctx) ? 1 : 0) | (dict_has_heavy_tail(ctx) ? 2 : 0);
   int r0 = setup_chains(ctx, K, 0, K, fused, nullptr);
   if (r0) return r0;
   DevParams &P = ctx->P;
@@ -1505,7 +1559,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
     }
     rounds += R;
     for (int l = 0; l < 2; l++)  // shrink deep bins whose tail has been consumed (exact; see k_trim_bins)
-      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
+      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]));
     // chains still running: the two-kernel round keeps the count, the fused round recounts it every round
     if (fused) {
       int ra = running_chains(ctx, alive_tmp, h_alive);
@@ -1552,7 +1606,7 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   HIPCHK(hipSetDevice(ctx->dev));
   const uint32_t K = total_chains / world;
   ctx->stats.chains = total_chains;
-  ctx->stats.deep_pool = dict_is_deep(ctx) ? 1 : 0;
+  ctx->stats.deep_pool = (dict_is_deep(ctx) ? 1 : 0) | (dict_has_heavy_tail(ctx) ? 2 : 0);
   int r = setup_chains(ctx, K, rank * K, total_chains, true, d_prop);
   if (r) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));
@@ -1592,7 +1646,7 @@ int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32
   ctx->stats.rounds++;
   if (ctx->stats.rounds % 16 == 0)
     for (int l = 0; l < 2; l++)
-      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, ctx->P.taken);
+      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, ctx->P.taken, const_cast<ulonglong2 *>(ctx->P.sig[l]));
   if (check_alive) {
     uint32_t a = 0;
     std::vector<uint32_t> tmp;
@@ -1684,12 +1738,32 @@ int spring_mg_comm_create_host(spring_mg_comm **out, spring_mg_allgather_fn fn, 
 
 void spring_mg_comm_destroy(spring_mg_comm *c) {
   if (!c) return;
-  if (c->rccl && g_rccl.CommDestroy) {
-    (void)hipSetDevice(c->dev);
-    (void)g_rccl.CommDestroy(c->rccl);
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->rccl && !c->aborted && g_rccl.CommDestroy) {
+      (void)hipSetDevice(c->dev);
+      (void)g_rccl.CommDestroy(c->rccl);
+    }
+    c->rccl = nullptr;
   }
   delete c;
 }
+}  // extern "C"
+// A rank of an in-process pool failed: its peers sit in (or are about to enter) a collective that will never complete.
+// ncclCommAbort ends it -- their stream operations then fail and their threads come back with an error instead of hanging.
+extern "C++" {
+namespace sr {
+void mg_comm_abort(spring_mg_comm *c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->rccl && !c->aborted && g_rccl.CommAbort) {
+    (void)g_rccl.CommAbort(c->rccl);
+    c->aborted = true;
+  }
+}
+}  // namespace sr
+}
+extern "C" {
 
 // one pool over the communicator's ranks with the exchange inside the library; see include/spring_reorder.h
 int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_t total_chains) {
@@ -1753,7 +1827,7 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
       ctx->stats.rounds++;
       if (ctx->stats.rounds % 16 == 0)
         for (int l = 0; l < 2; l++)
-          launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken);
+          launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]));
     }
     if (ret) break;
     if (timed) {

@@ -561,7 +561,7 @@ __device__ __forceinline__ void batch_mc(const DevParams &P, GLds<NQ> &S, lds_u3
         // (key, hash and minimizer are taken from LDS again: nothing of the quick phase stays live across the passes)
         const int ds = l ? P.dstart[1] : P.dstart[0], o = rev ? ds - shift : ds + shift;
         const uint64_t k = lds_window(rev ? srev : sref, 2 * o) & kmask;
-        eval_probe<false>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k),
+        eval_probe<false, false, false, true>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k),
                                        minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u, hit, rid, keyok, ncand, other, s_best, stage,
                                        lane, nullptr, nullptr, (int)((pre >> (4 * i)) & 15u));
         if (other && code < 128) S.pres[code] = 1;
@@ -708,7 +708,7 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds<NQ> &S, lds_u32
           uint32_t rid = 0, ncand = 0;
           const int off = rev ? s1 - (t0 + i) : s0 + t0 + i;
           const uint64_t ky = lds_window(rev ? srev : sref, 2 * off) & kmask;
-          eval_probe<false>(P, rev ? srev : sref, l, rev, sh, ref_len, ky, mix64(ky),
+          eval_probe<false, false, false, true>(P, rev ? srev : sref, l, rev, sh, ref_len, ky, mix64(ky),
                                          minz ? S.mz[rev ? ref_len - MINZ_WL - off : off] : 0u, hit, rid, keyok, ncand, other, s_best,
                                          stage, lane, nullptr, nullptr, (int)((pre >> (4 * b)) & 15u));
           if (hit) { best = code; brid = rid; }
@@ -721,7 +721,7 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds<NQ> &S, lds_u32
   wrid = (uint32_t)__shfl((int)brid, __ffs((int)wm) - 1, G);
 }
 
-// phase A of one chain (search_step: proposal word + direct reservation unless MG)
+// phase A of one chain (search_step: proposal word + direct reservation of the read)
 template <int NQ, bool MG>
 __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds<NQ> &S, lds_u32_t *stage,
                                           int lane, int gl) {
@@ -734,7 +734,7 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
       h.cursor_writer = is_last;  // the last-ranked needy chain proposes the lowest seed of the round
       if (gl == 0) {
         P.prop[cid] = ((unsigned long long)PK_SEED << 32) | (uint32_t)seed | (is_last ? PK_CURSOR_BIT : 0ull);
-        if (!MG) atomicMin(&P.resv[seed], cid);
+        atomicMin(&P.resv[seed], cid);  // (multi-GPU pools too: the rank's own proposals are settled here, k_mg_resolve adds the other ranks')
       }
     } else {
       h.prop_kind = PROP_NONE;
@@ -785,7 +785,7 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
     h.prop_kind = PROP_MATCH;
     if (gl == 0) {
       P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid;
-      if (!MG) atomicMin(&P.resv[wrid], cid);
+      atomicMin(&P.resv[wrid], cid);
     }
   } else {
     h.prop_kind = PROP_NONE;
@@ -802,7 +802,7 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
 #define SR_MC_WAVES 5  // waves per SIMD the kernel is compiled for (512 / SR_MC_WAVES VGPRs)
 #endif
 template <int NQ, bool MG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES, SR_MC_WAVES))) void k_round_mc(DevParams P) {
+__device__ __forceinline__ void round_mc_body(const DevParams &P) {
   typedef mc::GLds<NQ> GL;
   __shared__ GL s_g[mc::CPW];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
@@ -874,6 +874,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES,
       for (int i = 0; i < 64; i++) c->pt[i] += g_pt_lds[i];
   }
 #endif
+}
+// reads up to 192 bases: 5 waves per SIMD (96 VGPRs); longer reads (eight position quads per lane in the update) spill 14
+// VGPRs there and get 4 (128 VGPRs): no chain kernel uses scratch memory
+template <int NQ, bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES, SR_MC_WAVES))) void k_round_mc(DevParams P) {
+  static_assert(NQ <= 3, "long reads: k_round_mc_long");
+  round_mc_body<NQ, MG>(P);
+}
+template <bool MG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round_mc_long(DevParams P) {
+  round_mc_body<8, MG>(P);
 }
 
 #endif

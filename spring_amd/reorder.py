@@ -244,6 +244,7 @@ def synth_dna_host(n, L, G, seed, err_ppm=10000) -> bytes:
 
 SYNTH_REPEATS = 0x80000000  # OR into err_ppm (include/spring_reorder.h)
 SYNTH_PAIRED = 0x40000000
+SYNTH_GENOMIC = 0x20000000  # genome with interspersed repeat families, tandem repeats and low-complexity runs (synth_common.h)
 
 
 def synth_genome_host(G, seed, flags=0) -> bytes:

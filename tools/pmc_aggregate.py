@@ -33,7 +33,7 @@ def kernels_sha():
 kern = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
 dur = collections.defaultdict(lambda: collections.defaultdict(float))
-for p in ("fetch", "write", "sq", "insts", "tcc", "grbm"):
+for p in ("fetch", "write", "sq", "insts", "tcc", "grbm", "tcp"):
     d = os.path.join(pmc_dir, p)
     if not os.path.isdir(d):
         continue
@@ -57,6 +57,13 @@ for k, c in kern.items():
     e["rdreq_per_launch"] = c.get("TCC_EA0_RDREQ_sum", 0) / n
     hm = c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)
     e["l2_hit_rate"] = c.get("TCC_HIT_sum", 0) / hm if hm else None
+    # the L1's side of the story (round 3: the launch = L1 -> L2 read requests x their latency / (64 in flight x 256 CUs) while
+    # the miss queue is full): requests per launch, mean latency in L1 clocks, requests in flight per CU
+    if c.get("TCP_TCC_READ_REQ_sum"):
+        e["l1_read_requests_per_launch"] = c["TCP_TCC_READ_REQ_sum"] / n
+        e["l1_read_request_latency_clocks"] = c.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / c["TCP_TCC_READ_REQ_sum"]
+        if c.get("TCP_GATE_EN2_sum"):
+            e["l1_requests_in_flight_per_cu"] = c.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / c["TCP_GATE_EN2_sum"]
     e["wait_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
     # share of the launch during which a SIMD's vector ALU is issuing: SQ_ACTIVE_INST_VALU counts quad-cycles summed over
     # the waves; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE = busy clocks summed over the 8 XCDs (4.3 M per 217 us launch in
