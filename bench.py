@@ -556,7 +556,7 @@ def main():
         # the same port on a genome-like pool (SPRING_SYNTH_GENOMIC: repeat families, tandem repeats; coverage_sweep has the
         # GPU's figure): what realistic repeat structure costs the CPU algorithm
         try:
-            nsg = min(max(ns // 16, 200_000), ns)
+            nsg = min(max(ns // 4, 200_000), ns)  # (large enough for the repeat families to make deep bins: the cost grows with the pool)
             Gg = max(nsg * L // a.coverage, 2 * L)
             bg = torch.empty(L_.spring_synth_dna_bytes(nsg, L), dtype=torch.uint8, device="cuda")
             assert L_.spring_synth_dna_device(C.c_void_p(bg.data_ptr()), nsg, L, Gg, 11, a.err_ppm | 0x20000000) == 0

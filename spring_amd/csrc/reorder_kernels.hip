@@ -2075,10 +2075,17 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
               const ulonglong2 *psig = pl ? uni_ptr(P.sig[1]) : uni_ptr(P.sig[0]);
               r = pids[st0 + (uint32_t)j];
               const ulonglong2 sg = psig[st0 + (uint32_t)j];
-              const uint64_t tw = P.taken[r >> 6];
-              lv = !((tw >> (r & 63)) & 1ull);
-              sv = lv && sig_bound(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
-                                   prev ? ref_len + psh : ref_len - psh, r, sg) <= THRESH;
+              const bool sp = sig_bound(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                        prev ? ref_len + psh : ref_len - psh, r, sg) <= THRESH;
+              // The bitmap word is one random request per entry -- what the kernel is bound by once the signatures have
+              // removed the candidate reads.  The number of LIVE entries only matters for the MAX_SEARCH_REORDER window
+              // (reorder.h:287-288), and a bin of at most that many entries can never reach it: there the bitmap is
+              // asked about the entries that pass the signature test only (one in twelve on genome-like pools).
+              if (cnt > (uint32_t)MAX_SEARCH || sp) {
+                const uint64_t tw = P.taken[r >> 6];
+                lv = !((tw >> (r & 63)) & 1ull);
+              }
+              sv = lv && sp;
             }
           }
           rk[k] = r;
