@@ -1884,10 +1884,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_ROUND_WAV
 // same probes, same priority order, same MAX_SEARCH_REORDER rule, hence the same winner -- is spread over a block:
 //   1. one thread per probe (code = shift << 2 | rev << 1 | dict, the reference's order): bucket fetch, single-read
 //      bins compared at once, verified multi-read bins collected in code order;
-//   2. the collected bins are cut into chunks of 64 entries (bin tail first); a step gives the next 16 chunks in
-//      priority order to the 16 wavefronts, thread 0 then folds the 16 results in that order: the first passing
-//      entry whose bin has fewer than MAX_SEARCH_REORDER live entries ahead of it wins, a bin that reaches the limit
-//      is left for the next one.  The scan stops at the first winner, so nothing behind it is compared.
+//   2. the collected bins are cut into chunks of 64 entries (bin tail first), numbered in priority order; the 16
+//      wavefronts take chunk numbers from a ticket counter and publish a passing entry with an atomicMin on its chunk
+//      number: the first passing entry whose bin has fewer than MAX_SEARCH_REORDER live entries ahead of it wins (checked
+//      for bins of more than that many entries only; a bin whose pass lies outside the window is left for the next one).
+//      Nothing beyond the lowest passing chunk is started.  (Round 3 dealt 16 chunks per step between two block barriers,
+//      thread 0 folding the results: 70 % of a search's clocks, profiles/r04_genomic.txt.)
 // Dead bin tails are not trimmed here (k_round's scans and k_trim_bins do that).
 // Signatures (k_long): beside every dictionary entry (same index as ids[l]) the first and the last limb of its read.  The
 // Hamming distance over the bases of those two limbs that lie inside the compared range is a lower bound of the distance
@@ -1927,11 +1929,11 @@ __device__ __forceinline__ int sig_bound(const DevParams &P, const uint64_t *sx,
 }
 
 constexpr int LONG_WAVES = 16;
-// chunks of 64 bin entries a wavefront takes per step.  4 (4 096 entries per block and step, the survivors of the signature
-// test packed into one or two compare passes) cuts the steps of a search from 15 to 5 and makes each 3.2 times as long:
-// 100 M genome-like reads 4.94 s against 3.35 s with 1 (profiles/r04_genomic.txt) -- a step costs what its entries cost
-constexpr int LONG_CPW = 1;
-struct LongRes { uint32_t live, first, before, rid; };  // live entries of the chunk; first passing entry (64: none), live ones ahead of it, its read
+#ifndef SR_LONG_NCH
+#define SR_LONG_NCH 2
+#endif
+constexpr int LONG_NCH = SR_LONG_NCH;  // chunks of 64 bin entries per ticket
+static_assert(2 * 64 * LONG_NCH <= STAGE_WORDS, "the packed survivors of a ticket fit the staging rows");
 __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direct) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[LONG_WAVES][STAGE_WORDS];
@@ -1939,11 +1941,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
   __shared__ uint16_t s_bcode[64 * LONG_WAVES];
   __shared__ uint32_t s_wcnt[LONG_WAVES];
   __shared__ uint32_t s_best, s_bestrid, s_ctl, s_win_code, s_win_rid, s_capped;
-  __shared__ LongRes s_res[LONG_WAVES * LONG_CPW];
-  __shared__ uint32_t s_asg_bin[LONG_WAVES * LONG_CPW], s_asg_q[LONG_WAVES * LONG_CPW];
-  __shared__ uint32_t s_srv[LONG_WAVES][64 * LONG_CPW];   // per wavefront: the entries of its chunks that survive the signature test ...
-  __shared__ uint8_t s_srv_at[LONG_WAVES][64 * LONG_CPW]; // ... where each came from (chunk << 6 | lane) ...
-  __shared__ uint8_t s_pass[LONG_WAVES][64 * LONG_CPW];   // ... and which of them pass the full compare
+  __shared__ uint32_t s_bchunk0[64 * LONG_WAVES];   // listed chunks ahead of bin b in this turn
+  __shared__ uint32_t s_binlive[64 * LONG_WAVES];   // live entries seen in bin b (bins of more than MAX_SEARCH entries only)
+  __shared__ uint32_t s_bdone[64 * LONG_WAVES];     // chunks of bin b that have been compared (all of them: the bin is out)
+  __shared__ unsigned long long s_ticket;           // 64 * the next listed chunk of the turn
+  __shared__ unsigned long long s_minpass;          // lowest key (bin << 32 | chunk << 6 | lane) of a passing entry ...
+  __shared__ unsigned long long s_valid;            // ... and the lowest one that has been checked against its bin's window
   const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
   const uint32_t npend = P.longq[0];
   const int klen2 = 2 * P.wl;
@@ -1956,7 +1959,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
   for (;;) {
     if (tid == 0) s_qi = atomicAdd(&P.longq[1], 1u);
     __syncthreads();
-    const uint32_t qi = s_qi;
+    const uint32_t qi = uni_u32(s_qi);
     if (qi >= npend) break;
     const uint32_t li = P.longq[2 + qi];
     const uint32_t cid = P.c0 + li;
@@ -1995,11 +1998,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     }
     __syncthreads();
     if (hit && s_best == (uint32_t)code) s_bestrid = rid;  // (eval_probe left the lowest hitting code in s_best)
-    const bool mine = pend.on && pend.count > 0;
+    const uint32_t best_single = s_best;
+    // (a bin behind a single-read bin that hit can never win: it is not listed)
+    const bool mine = pend.on && pend.count > 0 && (uint32_t)code < best_single;
     const uint64_t pb = __ballot(mine);
     if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(pb);
     __syncthreads();
-    const uint32_t best_single = s_best;
     uint32_t nb = 0;
     {
       uint32_t base = 0;
@@ -2012,135 +2016,281 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
 #ifdef SR_LONG_COUNT
     const long long lc_t1 = clock64();
 #endif
-    // ---- 2. the bins, 16 chunks per step
-    uint32_t nx_bin = 0, nx_q = 0, cur = 0xffffffffu, cur_live = 0;  // thread 0: next chunk; bin whose live count is cur_live
-    bool cur_skip = false, have_res = false, done = false;
-    uint32_t n_asg = 0;
+    // ---- 2. the bins in chunks of 64 entries, in the reference's order (bins by priority code, a bin from its tail).
+    // No step-by-step hand-out any more (round 4: thread 0 folding 16 results and dealing the next 16 chunks between two
+    // block barriers was 70 % of a search's clocks).  A TURN lists a range of chunks [done, target) per bin; chunk0[b] = listed
+    // chunks ahead of bin b; a wavefront takes the next listed chunk from a ticket counter, finds its bin, compares, and
+    // publishes a passing entry with a 64-bit atomicMin on the key bin << 32 | chunk << 6 | lane; wavefronts stop taking
+    // tickets beyond the lowest key.  Keys order the entries as the reference visits them.
+    // The MAX_SEARCH_REORDER window (reorder.h:287-288) can only matter in a bin of more than that many entries (a "big"
+    // bin).  Big bins count their live entries (s_binlive) and are listed LONG_FIRST chunks at first; a pass found in one is
+    // checked after the turn's barrier against the live entries ahead of it (exact recount) -- outside the window the bin is
+    // left, as the reference leaves it, and the scan goes on behind it.  A big bin ahead of the best pass that has neither
+    // been listed to its end nor reached the limit is listed four times as far in the next turn: the result is the first
+    // pass inside its bin's window in key order, whatever the number of turns.
+    constexpr uint32_t LONG_FIRST = (MAX_SEARCH + 63) / 64;
+    __syncthreads();  // (s_wcnt is about to be reused; s_b* of every wavefront written)
+    nb = uni_u32(nb);
+    const uint32_t my_cnt = (uint32_t)tid < nb ? s_bcount[tid] : 0u;
+    const uint32_t my_nch = (my_cnt + 63u) / 64u;
+    const bool my_big = my_cnt > (uint32_t)MAX_SEARCH;
+    s_binlive[tid] = 0;
+    s_bdone[tid] = 0;
+    if (tid == 0) { s_minpass = ~0ull; s_valid = ~0ull; }
+#ifdef SR_LONG_COUNT
+    unsigned long long lc_chunks = 0, lc_live = 0, lc_cmp = 0, lc_busy = 0, lc_turns = 0;
+    long long lc_q[5] = {0, 0, 0, 0, 0};
+#endif
     for (;;) {
-      __syncthreads();  // s_b* / s_res written
-      if (tid == 0) {
-        if (have_res) {
-          for (uint32_t w = 0; w < n_asg && !done; w++) {
-            const uint32_t b = s_asg_bin[w];
-            if (b != cur) { cur = b; cur_live = 0; cur_skip = false; }
-            if (cur_skip) continue;
-            const LongRes r = s_res[w];
-            if (r.first < 64) {
-              if (cur_live + r.before < (uint32_t)MAX_SEARCH) { s_win_code = s_bcode[b]; s_win_rid = r.rid; done = true; }
-              else { s_capped = 1; cur_skip = true; }
-            } else {
-              cur_live += r.live;
-              if (cur_live >= (uint32_t)MAX_SEARCH) { s_capped = 1; cur_skip = true; }
-            }
-          }
-          if (cur_skip && nx_bin == cur) { nx_bin = cur + 1; nx_q = 0; }  // the rest of a bin that reached the limit
-        }
-        n_asg = 0;
-        if (!done) {
-          while (n_asg < (uint32_t)(LONG_WAVES * LONG_CPW) && nx_bin < nb) {
-            if ((uint32_t)s_bcode[nx_bin] > best_single) { nx_bin = nb; break; }  // behind a single-read bin that hit
-            if ((uint64_t)nx_q * 64 >= s_bcount[nx_bin]) { nx_bin++; nx_q = 0; continue; }
-            s_asg_bin[n_asg] = nx_bin; s_asg_q[n_asg] = nx_q;
-            n_asg++; nx_q++;
-          }
-        }
-        have_res = true;
-        s_ctl = n_asg;
-      }
       __syncthreads();
-      const uint32_t na = s_ctl;
-      if (na == 0) break;
-      if ((uint32_t)wave * LONG_CPW < na) {
-        // ---- this wavefront's chunks: assignments LONG_CPW * wave + k.  A: id, signature and taken bit of every entry (coalesced
-        // but for the bitmap word); entries that are live and pass the signature bound survive.  B: the survivors of all the
-        // chunks, packed into as few 64-lane passes as they need, fetch their reads and are compared in full.  C: per
-        // chunk, what thread 0 folds: live entries, first passing entry, live entries ahead of it.
+#ifdef SR_LONG_COUNT
+      lc_turns++;
+      const long long lc_w0 = clock64();
+#endif
+      // the range of thread tid's bin in this turn
+      const uint32_t my_done = s_bdone[tid], live_prev = s_binlive[tid];
+      uint32_t my_tgt = my_nch;
+      if (my_big) {
+        if (live_prev >= (uint32_t)MAX_SEARCH) my_tgt = my_done;
+        else { const uint32_t far = my_done * 4u > LONG_FIRST ? my_done * 4u : LONG_FIRST; my_tgt = far < my_nch ? far : my_nch; }
+      }
+      if (my_tgt < my_done) my_tgt = my_done;
+      const uint32_t nch = my_tgt - my_done;
+      const uint32_t incl = (uint32_t)wave_incl_scan_i((int)nch, lane);
+      if (lane == 63) s_wcnt[wave] = incl;
+      __syncthreads();
+      uint32_t base = 0, total = 0;
+      for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; total += v; }
+      // (everything a barrier depends on is made a scalar: a branch the compiler takes for divergent is run through with an
+      // empty EXEC mask, and an s_barrier inside it still counts)
+      total = uni_u32(total);
+      s_bchunk0[tid] = base + incl - nch;
+      if (tid == 0) s_ticket = 0;
+      __syncthreads();
+      if (total == 0) break;
+      for (;;) {
+        // No `if (lane == 0)` around the atomics of this loop: with one at the end of an iteration (the atomicMin) and one
+        // at the start of the next (the ticket) the compiler threads the two branches, and lanes 1-63 go round the loop on
+        // their own with readfirstlane(g) == 0 -- the same chunk for ever (seen in the ISA, round 4).  Every lane takes part
+        // in the atomic instead: the 64 lanes add 1 each (the backend folds that into one LDS add of 64), so s_ticket counts
+        // in units of 64.
+        // A ticket is LONG_NCH consecutive listed chunks: a chunk is three dependent memory round trips (id + signature,
+        // bitmap word, the survivors' reads) and a wavefront has nothing else to do meanwhile -- 9.6 k clocks per chunk one
+        // at a time; with four in flight the round trips are shared, and the survivors of all four (one entry in twelve
+        // passes the signature bound on genome-like pools) are packed into one compare pass.
+#if SR_LONG_COUNT == 3
+        const long long lq0 = clock64();
+#endif
+        const uint32_t g = uni_u32((uint32_t)(atomicAdd(&s_ticket, 1ull) >> 6));
+        if (g >= (total + LONG_NCH - 1) / LONG_NCH) break;
+        const uint32_t c0 = g * LONG_NCH;
+        uint32_t lo = 0, hi = nb;  // the bin of listed chunk c0: the last b with chunk0[b] <= c0 (it has chunks: c0 < total)
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (uni_u32(s_bchunk0[mid]) <= c0) lo = mid; else hi = mid; }
+        {
+          const uint32_t q0 = uni_u32(s_bdone[lo]) + (c0 - uni_u32(s_bchunk0[lo]));
+          // (s_minpass only decreases during a turn: a key seen below this ticket's first means the final one is below it too)
+          const unsigned long long mp = __hip_atomic_load(&s_minpass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t mp_hi = uni_u32((uint32_t)(mp >> 32)), mp_lo = uni_u32((uint32_t)mp);
+          if (mp_hi < lo || (mp_hi == lo && (mp_lo >> 6) < q0)) break;
+        }
         typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
-        uint32_t rk[LONG_CPW];
-        uint64_t Lm[LONG_CPW], Sm[LONG_CPW];
-        uint32_t nsrv = 0;
+#if SR_LONG_COUNT == 3
+        const long long lq1 = clock64();
+#endif
+        // A: id and signature of every entry of the chunks
+        uint32_t kb[LONG_NCH], kq[LONG_NCH], rk[LONG_NCH];
+        bool kbig[LONG_NCH], has[LONG_NCH];
+        int kcode[LONG_NCH];
+        ulonglong2 sgk[LONG_NCH];
+        {
+          uint32_t bb = lo;
 #pragma unroll
-        for (int k = 0; k < LONG_CPW; k++) {
-          const uint32_t a = (uint32_t)wave * LONG_CPW + k;
-          bool lv = false, sv = false;
-          uint32_t r = 0;
-          if (a < na) {
-            const uint32_t b = s_asg_bin[a], q = s_asg_q[a];
-            const int pcode = (int)s_bcode[b];
-            const int pl = pcode & 1, prev = (pcode >> 1) & 1, psh = pcode >> 2;
-            const uint32_t cnt = s_bcount[b], st0 = s_bstart[b];
-            const long long j = (long long)cnt - 1 - ((long long)q * 64 + lane);
-            if (j >= 0) {
+          for (int k = 0; k < LONG_NCH; k++) {
+            const uint32_t cc = c0 + k;
+            const bool kv = cc < total;
+            if (kv) while (bb + 1 < nb && uni_u32(s_bchunk0[bb + 1]) <= cc) bb++;
+            kb[k] = bb;
+            kq[k] = kv ? uni_u32(s_bdone[bb]) + (cc - uni_u32(s_bchunk0[bb])) : 0u;
+            kcode[k] = uni_i32((int)s_bcode[bb]);
+            const uint32_t cnt = uni_u32(s_bcount[bb]), st0 = uni_u32(s_bstart[bb]);
+            kbig[k] = cnt > (uint32_t)MAX_SEARCH;
+            const long long j = (long long)cnt - 1 - ((long long)kq[k] * 64 + lane);
+            has[k] = kv && j >= 0;
+            rk[k] = 0; sgk[k] = make_ulonglong2(0, 0);
+            if (has[k]) {
+              const int pl = kcode[k] & 1;
               g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
               const ulonglong2 *psig = pl ? uni_ptr(P.sig[1]) : uni_ptr(P.sig[0]);
-              r = pids[st0 + (uint32_t)j];
-              const ulonglong2 sg = psig[st0 + (uint32_t)j];
-              const bool sp = sig_bound(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
-                                        prev ? ref_len + psh : ref_len - psh, r, sg) <= THRESH;
-              // The bitmap word is one random request per entry -- what the kernel is bound by once the signatures have
-              // removed the candidate reads.  The number of LIVE entries only matters for the MAX_SEARCH_REORDER window
-              // (reorder.h:287-288), and a bin of at most that many entries can never reach it: there the bitmap is
-              // asked about the entries that pass the signature test only (one in twelve on genome-like pools).
-              if (cnt > (uint32_t)MAX_SEARCH || sp) {
-                const uint64_t tw = P.taken[r >> 6];
-                lv = !((tw >> (r & 63)) & 1ull);
-              }
-              sv = lv && sp;
+              rk[k] = pids[st0 + (uint32_t)j];
+              sgk[k] = psig[st0 + (uint32_t)j];
             }
           }
-          rk[k] = r;
-          Lm[k] = __ballot(lv);
-          Sm[k] = __ballot(sv);
-          if (sv) {
-            const uint32_t at = nsrv + (uint32_t)__popcll(Sm[k] & ((1ull << lane) - 1));
-            s_srv[wave][at] = r;
-            s_srv_at[wave][at] = (uint8_t)((k << 6) | lane);
-          }
-          s_pass[wave][k * 64 + lane] = 0;
-          nsrv += (uint32_t)__popcll(Sm[k]);
         }
-        wave_sync();
-#ifdef SR_LONG_COUNT
-        if (lane == 0) {
-          unsigned long long e = 0, l = 0;
-          for (int k = 0; k < LONG_CPW; k++) { l += __popcll(Lm[k]); e += __popcll(Sm[k]); }
-          atomicAdd((unsigned long long *)&c->st_keyok, e);   // survivors of the signature test
-          atomicAdd((unsigned long long *)&c->st_cands, l);   // live entries
-          atomicAdd((unsigned long long *)&c->st_probes, 1ull);
-        }
+#if SR_LONG_COUNT == 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long lq2 = clock64();
 #endif
-        for (uint32_t base = 0; base < nsrv; base += 64) {
-          const uint32_t idx = base + lane;
+        // B: signature bound; the bitmap word (one random request per entry) only where it matters -- the number of live
+        // entries counts in a big bin only, elsewhere the entries that pass the bound are asked
+        bool sp[LONG_NCH];
+        uint64_t tw[LONG_NCH];
+#pragma unroll
+        for (int k = 0; k < LONG_NCH; k++) {
+          const int prev = (kcode[k] >> 1) & 1, psh = kcode[k] >> 2;
+          sp[k] = has[k] && sig_bound(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                      prev ? ref_len + psh : ref_len - psh, rk[k], sgk[k]) <= THRESH;
+          tw[k] = ~0ull;
+          if (has[k] && (kbig[k] || sp[k])) tw[k] = P.taken[rk[k] >> 6];
+        }
+#if SR_LONG_COUNT == 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long lq3 = clock64();
+#endif
+        // C: the entries that are free and pass the bound, packed in key order (chunk, then lane) into the staging rows
+        uint32_t nsrv = 0;
+#pragma unroll
+        for (int k = 0; k < LONG_NCH; k++) {
+          const bool lv = !((tw[k] >> (rk[k] & 63)) & 1ull);
+          const bool sv = lv && sp[k];
+          const uint64_t Lm = __ballot(lv), Sm = __ballot(sv);
+#ifdef SR_LONG_COUNT
+          lc_chunks += has[k] ? 1 : 0; lc_live += __popcll(Lm);
+#endif
+          if (kbig[k] && Lm) atomicAdd(&s_binlive[kb[k]], lv ? 1u : 0u);
+          if (sv) {
+            const uint32_t at = nsrv + (uint32_t)__popcll(Sm & ((1ull << lane) - 1));
+            stage[at] = rk[k];
+            stage[64 * LONG_NCH + at] = (uint32_t)((k << 6) | lane);
+          }
+          nsrv += (uint32_t)__popcll(Sm);
+        }
+        nsrv = uni_u32(nsrv);
+#if SR_LONG_COUNT == 3
+        lc_q[0] += lq1 - lq0; lc_q[1] += lq2 - lq1; lc_q[2] += lq3 - lq2; lc_q[3] -= clock64(); lc_q[4] += nsrv;
+#endif
+        if (nsrv == 0) {
+#if SR_LONG_COUNT == 3
+          lc_q[3] += clock64();
+#endif
+          continue;
+        }
+        // (the compare stages reads through the same rows: everything is taken out first)
+        uint32_t pr[LONG_NCH], po[LONG_NCH];
+#pragma unroll
+        for (int pp = 0; pp < LONG_NCH; pp++) {
+          const uint32_t idx = (uint32_t)pp * 64 + lane;
+          pr[pp] = idx < nsrv ? stage[idx] : 0u;
+          po[pp] = idx < nsrv ? stage[64 * LONG_NCH + idx] : 0u;
+        }
+#pragma unroll
+        for (int pp = 0; pp < LONG_NCH; pp++) {
+          if ((uint32_t)pp * 64 >= nsrv) break;
+          const uint32_t idx = (uint32_t)pp * 64 + lane;
+          const int ok_ = (int)(po[pp] >> 6);
+          uint32_t myb = kb[0], myq = kq[0];
+          int pcode = kcode[0];
+#pragma unroll
+          for (int k = 1; k < LONG_NCH; k++) if (ok_ == k) { myb = kb[k]; myq = kq[k]; pcode = kcode[k]; }
+          bool ps = false;
           if (idx < nsrv) {
-            const uint32_t r = s_srv[wave][idx];
-            const uint32_t at = s_srv_at[wave][idx];
-            const uint32_t a = (uint32_t)wave * LONG_CPW + (at >> 6);
-            const int pcode = (int)s_bcode[s_asg_bin[a]];
             const int pl = pcode & 1, prev = (pcode >> 1) & 1, psh = pcode >> 2;
             const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
-            if (cmp_candidate<true, true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
-                                          prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1)
-              s_pass[wave][at] = 1;
+            ps = cmp_candidate<true, true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
+                                           prev ? ref_len + psh : ref_len - psh, pds, klen2, pr[pp], false, stage, lane) == 1;
+          }
+          const uint64_t Pm = __ballot(ps);
+          if (Pm) {
+            const int fp = __ffsll((unsigned long long)Pm) - 1;
+            const uint32_t wb_ = (uint32_t)__shfl((int)myb, fp, 64), wq_ = (uint32_t)__shfl((int)myq, fp, 64);
+            const uint32_t wl_ = (uint32_t)__shfl((int)(po[pp] & 63u), fp, 64);
+            atomicMin(&s_minpass, ((unsigned long long)wb_ << 32) | ((unsigned long long)wq_ << 6) | wl_);  // (the same value from every lane)
+            break;  // (the packed order is the key order: nothing behind the first pass matters)
           }
         }
-        wave_sync();
-#pragma unroll
-        for (int k = 0; k < LONG_CPW; k++) {
-          const uint32_t a = (uint32_t)wave * LONG_CPW + k;
-          const uint64_t Pm = __ballot(s_pass[wave][k * 64 + lane] != 0);
-          const int fp = Pm ? __ffsll((unsigned long long)Pm) - 1 : 64;
-          const uint32_t wr = (uint32_t)__shfl((int)rk[k], fp & 63, 64);
-          if (lane == 0 && a < na) {
-            LongRes o;
-            o.live = (uint32_t)__popcll(Lm[k]); o.first = (uint32_t)fp;
-            o.before = fp < 64 ? (uint32_t)__popcll(Lm[k] & ((1ull << fp) - 1)) : 0u; o.rid = wr;
-            s_res[a] = o;
-          }
+#if SR_LONG_COUNT == 3
+        lc_q[3] += clock64();
+#endif
+      }
+#ifdef SR_LONG_COUNT
+      lc_busy += (unsigned long long)(clock64() - lc_w0);
+#endif
+      __syncthreads();
+      // Every listed chunk with a key below the final s_minpass has been compared (tickets go out in key order and a
+      // wavefront only stops on a key lower than its chunk's), so the final s_minpass is the first pass of this turn's list.
+      const uint32_t c_hi = uni_u32(((const uint32_t *)&s_minpass)[1]), c_lo = uni_u32(((const uint32_t *)&s_minpass)[0]);
+      const uint32_t v_hi = uni_u32(((const uint32_t *)&s_valid)[1]), v_lo = uni_u32(((const uint32_t *)&s_valid)[0]);
+      const bool fresh = c_hi != v_hi || c_lo != v_lo;  // a pass ahead of the best checked one
+      bool ok = true;
+      const uint32_t cb = c_hi, cq = c_lo >> 6, cfp = c_lo & 63u;
+      if (fresh) {
+        const uint32_t cnt = uni_u32(s_bcount[cb]);
+        if (cnt > (uint32_t)MAX_SEARCH && uni_u32(s_binlive[cb]) >= (uint32_t)MAX_SEARCH) {
+          // the live entries of bin cb ahead of the passing entry (every thread counts its share; rare)
+          typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+          g_u32_t *pids = (g_u32_t *)((uni_u32(s_bcode[cb]) & 1) ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
+          const uint32_t st0 = uni_u32(s_bstart[cb]);
+          __syncthreads();
+          if (tid == 0) s_ctl = 0;
+          __syncthreads();
+          const unsigned long long ahead = (unsigned long long)cq * 64 + cfp;  // entries of the bin visited before the pass
+          uint32_t mycnt = 0;
+          for (unsigned long long pp = (unsigned long long)tid; pp < ahead; pp += 64 * LONG_WAVES)
+            mycnt += !is_taken(P.taken, pids[st0 + (cnt - 1 - (uint32_t)pp)]);
+          const uint32_t wsum = (uint32_t)wave_sum_i((int)mycnt);
+          if (wsum) atomicAdd(&s_ctl, lane == 0 ? wsum : 0u);
+          __syncthreads();
+          ok = uni_u32(s_ctl) < (uint32_t)MAX_SEARCH;
         }
       }
+      __syncthreads();
+      // the lists of the next turn
+      if (!fresh) {
+        s_bdone[tid] = my_tgt;  // nothing stopped early: every listed chunk was compared
+      } else if (ok) {
+        // the best pass so far: the bins behind it are out, the bins ahead of it are complete up to their targets
+        if (tid == 0) s_valid = ((unsigned long long)c_hi << 32) | c_lo;
+        s_bdone[tid] = (uint32_t)tid >= cb ? my_nch : my_tgt;
+      } else {
+        // outside the window: bin cb is left.  The chunks behind it may or may not have been compared (wavefronts stopped at
+        // the key): their bins keep their lists and forget this turn's live entries
+        if (tid == 0) { s_capped = 1; s_minpass = s_valid; }
+        if ((uint32_t)tid < cb) s_bdone[tid] = my_tgt;
+        else if ((uint32_t)tid == cb) s_bdone[tid] = my_nch;
+        else s_binlive[tid] = live_prev;
+      }
     }
+    // a bin ahead of the winner (any bin when nothing won) that held MAX_SEARCH live entries stopped its probe at the window
+    {
+      const uint32_t v_hi = uni_u32(((const uint32_t *)&s_valid)[1]), v_lo = uni_u32(((const uint32_t *)&s_valid)[0]);
+      const uint32_t wb = v_hi != 0xffffffffu ? v_hi : nb;
+      if ((uint32_t)tid < wb && my_big && s_binlive[tid] >= (uint32_t)MAX_SEARCH) s_capped = 1;
+      if (tid == 0 && v_hi != 0xffffffffu) {
+        typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+        g_u32_t *pids = (g_u32_t *)((s_bcode[v_hi] & 1) ? P.ids[1] : P.ids[0]);
+        s_win_code = s_bcode[v_hi];
+        s_win_rid = pids[s_bstart[v_hi] + (s_bcount[v_hi] - 1 - ((v_lo >> 6) * 64 + (v_lo & 63u)))];
+      }
+    }
+    __syncthreads();
 #ifdef SR_LONG_COUNT
-    if (tid == 0) { c->st_iter += (unsigned long long)(lc_t1 - lc_t0); c->st_hits += (unsigned long long)(clock64() - lc_t1); }
+#if SR_LONG_COUNT != 3
+    if (tid == 0) { c->st_iter += (unsigned long long)(lc_t1 - lc_t0); c->st_hits += (unsigned long long)(clock64() - lc_t1); c->st_lost += lc_turns; }
+#endif
+    if (lane == 0) {
+      atomicAdd((unsigned long long *)&c->st_probes, lc_chunks);
+#if SR_LONG_COUNT == 3
+      // per wavefront clocks: st_iter ticket + bin lookup, st_hits id/signature round trip, st_keyok bound + bitmap round trip,
+      // st_cands packing + compare; st_lost survivors
+      atomicAdd((unsigned long long *)&c->st_iter, (unsigned long long)lc_q[0]);
+      atomicAdd((unsigned long long *)&c->st_hits, (unsigned long long)lc_q[1]);
+      atomicAdd((unsigned long long *)&c->st_keyok, (unsigned long long)lc_q[2]);
+      atomicAdd((unsigned long long *)&c->st_cands, (unsigned long long)lc_q[3]);
+      atomicAdd((unsigned long long *)&c->st_lost, (unsigned long long)lc_q[4]);
+#else
+      atomicAdd((unsigned long long *)&c->st_cands, lc_live);
+      atomicAdd((unsigned long long *)&c->st_keyok, lc_busy);
+#endif
+    }
 #endif
     // ---- the proposal (as the end of search_step)
     if (wave == 0) {

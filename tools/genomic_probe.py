@@ -16,6 +16,6 @@ for kw in VARS:
         s.load_synth(n, L, G, 11, 10000 | sa.SYNTH_GENOMIC)
         s.run()
         st = s.stats()
-    print("%-70s chains=%8.1f ms rounds=%5d K=%d lost=%d long=%d unmatched=%d single=%d cands/read=%.1f probes/read=%.1f keyok/read=%.1f hits=%d iterations=%d" % (
+    print("%-70s chains=%8.1f ms rounds=%5d K=%d lost=%d long=%d unmatched=%d single=%d cands/read=%.1f probes/read=%.1f keyok/read=%.1f hits=%d iterations=%d lost=%d" % (
         json.dumps(dict(kw, num_chains=K)), st["ms_chains"], st["rounds"], st["chains"], st["lost"], st["long_searches"], st["unmatched"],
-        st["n_single"], st["cands"] / n, st["probes"] / n, st["keyok"] / n, st["hits"], st["iterations"]), flush=True)
+        st["n_single"], st["cands"] / n, st["probes"] / n, st["keyok"] / n, st["hits"], st["iterations"], st["lost"]), flush=True)
