@@ -80,6 +80,8 @@ typedef struct {
   int32_t long_min;       /* k_long: bin entries that must still be ahead of a search for it to be handed over (0 = default 2048) */
   int32_t long_blocks;    /* k_long: grid size (0 = default 512) */
   int32_t debug;          /* 1: stage / phase timings on stderr */
+  int32_t long_split;     /* k_long: a search with at least 4 x this many 64-entry chunks of bin entries ahead of it is split
+                             into parts that idle blocks take over (0 = default 128, -1 = never) */
 } spring_reorder_opts;
 
 typedef struct {
@@ -103,6 +105,7 @@ typedef struct {
   uint64_t long_searches;  /* searches a wavefront handed over to a block of 16 (k_long; deep-coverage pools only) */
   uint64_t table_minz;     /* 1: the dictionary table is addressed by minimizers (opts.table_mode) */
   uint64_t table_marked_lines; /* ... and this many of its lines were over-subscribed: their keys live at the redirect address */
+  uint64_t long_splits;    /* long searches that were split into parts over several blocks (k_long) */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);

@@ -102,6 +102,18 @@ constexpr int MINZ_HEAVY = 12;              // keys a line may be the home of
 constexpr int MINZ_K = 16;                  // minimizer length in bases
 constexpr int MINZ_WL = 32;                 // ... of windows of this length only (MINZ_WL - MINZ_K + 1 = 17 k-mers per window)
 
+constexpr int LONG_MAX_BINS = 1024;  // one bin per probe code of a search (k_long: one thread per probe)
+constexpr int LONG_MAX_PARTS = 8;
+// A long search whose bins hold far more entries than the average one is split into parts (ranges of its bins in priority
+// order) that blocks without a search of their own take over: the block that ran the probes publishes the bin list here.
+struct LongSlot {
+  uint32_t li, nb, nparts, done, best_single, bestrid, bestpart, pad;
+  uint32_t blo[LONG_MAX_PARTS + 1];          // part p scans bins [blo[p], blo[p + 1])
+  uint32_t capped[LONG_MAX_PARTS];
+  unsigned long long res[LONG_MAX_PARTS];    // part p's first pass inside its bin's window (key), ~0: none
+  uint32_t bstart[LONG_MAX_BINS], bcount[LONG_MAX_BINS];
+  uint16_t bcode[LONG_MAX_BINS];
+};
 struct DevParams {
   // reads
   const uint64_t *reads;  // n * S limbs (S = limb stride, power of two >= W, <= 16)
@@ -144,7 +156,13 @@ struct DevParams {
   // one lane (tail) a wavefront of k_round spends on a search before it hands it over; 0 = never.
   // long_min: bin entries that must still be ahead of the search at that point (else the wavefront carries on).
   uint32_t *longq;
-  int long_budget, long_min, long_blocks;
+  int long_budget, long_min, long_blocks, long_split;
+  // split long searches (k_long): lctl[0] = next help ticket, [1] = help tasks pushed, [2] = searches finished this round;
+  // ltask[i] = (slot + 1) << 4 | part of help task i (0: not pushed yet), ltask_cap entries; lslot[block] = what the parts of
+  // a split search share.  k_mg_mark zeroes lctl and ltask with the queue.
+  uint32_t *lctl, *ltask;
+  uint32_t ltask_cap;
+  struct LongSlot *lslot;
 #ifdef SR_PHASE_TIMING
   unsigned long long *dbg;  // [0..63] phase clocks / visits summed over the wavefronts that ran > 1M clocks, [64] how many
 #endif

@@ -1929,6 +1929,10 @@ __device__ __forceinline__ int sig_bound(const DevParams &P, const uint64_t *sx,
 }
 
 constexpr int LONG_WAVES = 16;
+// what the blocks of k_long tell each other goes past the caches (agent scope: the XCDs have an L2 each); no fence is
+// needed beside it -- a fence here writes back / invalidates a whole L2
+template <typename T> __device__ __forceinline__ T ag_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void ag_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifndef SR_LONG_NCH
 #define SR_LONG_NCH 2
 #endif
@@ -1955,13 +1959,46 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
   const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
   // the blocks take the queued searches as they become free (a ticket counter, longq[1]): searches differ in length by two
   // orders of magnitude and a launch lasts as long as its most loaded block
-  __shared__ uint32_t s_qi;
+  // A search far longer than the average one would keep its block busy long after the others have run out of work (100 M
+  // genome-like reads: 2 600 searches of 80 us on average per launch, the longest > 1 ms; the launch lasted 2.1 ms on 256
+  // blocks).  Such a search is SPLIT: the block that ran its probes publishes the bin list (LongSlot) and pushes help tasks,
+  // one per part = range of bins in priority order; a block that finds the queue empty takes help tickets (ltask[], served in
+  // order) until every search of the round is finished (lctl[2]).  A part is an ordinary scan of its bins; the part that
+  // finishes last combines: the lowest part with a pass wins.
+  __shared__ uint32_t s_qi, s_mode, s_blo[LONG_MAX_PARTS + 1];
+  static_assert(LONG_MAX_BINS == 64 * LONG_WAVES, "one bin per thread");
+  const uint32_t LONG_SPLIT_PART = (uint32_t)P.long_split, LONG_SPLIT_MIN = 4 * LONG_SPLIT_PART;  // listed chunks per part / to split at all
+  LongSlot *const myslot = P.lslot + blockIdx.x;
+  uint32_t my_help_ticket = 0xffffffffu;  // (thread 0) a help ticket taken and not yet served
+  bool main_empty = false;                // (thread 0) the queue of searches has run out
   for (;;) {
-    if (tid == 0) s_qi = atomicAdd(&P.longq[1], 1u);
+    if (tid == 0) {
+      uint32_t mode = 0, val = 0;
+      if (!main_empty) { val = atomicAdd(&P.longq[1], 1u); main_empty = val >= npend; }
+      if (main_empty) {
+        mode = 2;
+        if (my_help_ticket == 0xffffffffu) my_help_ticket = atomicAdd(&P.lctl[0], 1u);
+        for (;;) {
+          if (my_help_ticket < P.ltask_cap) {
+            const uint32_t t = __hip_atomic_load(&P.ltask[my_help_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t) { mode = 1; val = t; my_help_ticket = 0xffffffffu; break; }
+          }
+          // (every search finished: all help tasks have been served, none will come for this ticket)
+          if (__hip_atomic_load(&P.lctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= npend) break;
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      s_mode = mode; s_qi = val;
+    }
     __syncthreads();
-    const uint32_t qi = uni_u32(s_qi);
-    if (qi >= npend) break;
-    const uint32_t li = P.longq[2 + qi];
+    const uint32_t mode = uni_u32(s_mode), qv = uni_u32(s_qi);
+    if (mode == 2) break;
+    LongSlot *const slot = mode == 1 ? P.lslot + ((qv >> 4) - 1) : myslot;
+    const uint32_t part = mode == 1 ? (qv & 15u) : 0u;
+    uint32_t nparts = 1;
+    // (the slot was written by another block: every access to it is an agent-scope one)
+    const uint32_t li = mode == 1 ? uni_u32(ag_ld(&slot->li)) : uni_u32(P.longq[2 + qv]);
+    if (mode == 1) nparts = uni_u32(ag_ld(&slot->nparts));
     const uint32_t cid = P.c0 + li;
     Chain *c = &P.chains[li];
     if (tid < LDS_LIMBS) {
@@ -1983,6 +2020,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
 #ifdef SR_LONG_COUNT
     const long long lc_t0 = clock64();
 #endif
+    uint32_t best_single = 0x7fffffffu, nb = 0, b_lo = 0, b_hi = 0;
+    if (mode == 1) {  // a part of a split search: the bins come from the slot
+      nb = uni_u32(ag_ld(&slot->nb));
+      b_lo = uni_u32(ag_ld(&slot->blo[part])); b_hi = uni_u32(ag_ld(&slot->blo[part + 1]));
+      if ((uint32_t)tid < nb) { s_bstart[tid] = ag_ld(&slot->bstart[tid]); s_bcount[tid] = ag_ld(&slot->bcount[tid]); s_bcode[tid] = ag_ld(&slot->bcode[tid]); }
+    } else {
     // ---- 1. one thread per probe
     const int code = tid, l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
     const bool valid = probe_valid(P, l, rev, shift, ref_len) && code >= min_code;
@@ -1998,13 +2041,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     }
     __syncthreads();
     if (hit && s_best == (uint32_t)code) s_bestrid = rid;  // (eval_probe left the lowest hitting code in s_best)
-    const uint32_t best_single = s_best;
+    best_single = s_best;
     // (a bin behind a single-read bin that hit can never win: it is not listed)
     const bool mine = pend.on && pend.count > 0 && (uint32_t)code < best_single;
     const uint64_t pb = __ballot(mine);
     if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(pb);
     __syncthreads();
-    uint32_t nb = 0;
     {
       uint32_t base = 0;
       for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; nb += v; }
@@ -2012,6 +2054,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         const uint32_t at = base + (uint32_t)__popcll(pb & ((1ull << lane) - 1));
         s_bstart[at] = pend.start; s_bcount[at] = pend.count; s_bcode[at] = (uint16_t)code;
       }
+    }
+    nb = uni_u32(nb);
+    b_hi = nb;
     }
 #ifdef SR_LONG_COUNT
     const long long lc_t1 = clock64();
@@ -2035,8 +2080,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     const uint32_t my_nch = (my_cnt + 63u) / 64u;
     const bool my_big = my_cnt > (uint32_t)MAX_SEARCH;
     s_binlive[tid] = 0;
-    s_bdone[tid] = 0;
+    s_bdone[tid] = ((uint32_t)tid >= b_lo && (uint32_t)tid < b_hi) ? 0u : my_nch;  // (all chunks done = the bin is out)
     if (tid == 0) { s_minpass = ~0ull; s_valid = ~0ull; }
+    bool split_tried = mode == 1 || P.lslot == nullptr || P.long_split == 0, aborted = false;
 #ifdef SR_LONG_COUNT
     unsigned long long lc_chunks = 0, lc_live = 0, lc_cmp = 0, lc_busy = 0, lc_turns = 0;
     long long lc_q[5] = {0, 0, 0, 0, 0};
@@ -2068,6 +2114,56 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       if (tid == 0) s_ticket = 0;
       __syncthreads();
       if (total == 0) break;
+      if (nparts > 1 && uni_u32(__hip_atomic_load(&slot->bestpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < part) {
+        aborted = true;  // a part ahead of this one has a pass inside its window: nothing here can win
+        break;
+      }
+      if (!split_tried) {
+        split_tried = true;
+        if (total >= LONG_SPLIT_MIN) {
+          if (tid == 0) s_ctl = __hip_atomic_load(&myslot->nparts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;  // (the last split of this block is over)
+          if (tid <= LONG_MAX_PARTS) s_blo[tid] = tid == 0 ? 0u : nb;
+          __syncthreads();
+          if (uni_u32(s_ctl)) {
+            uint32_t np = total / LONG_SPLIT_PART;
+            if (np > (uint32_t)LONG_MAX_PARTS) np = LONG_MAX_PARTS;
+            // part p starts at the first bin with p / np of the listed chunks ahead of it
+            if ((uint32_t)tid < nb)
+              for (uint32_t pp = 1; pp < np; pp++)
+                if (s_bchunk0[tid] >= (uint32_t)((unsigned long long)pp * total / np)) atomicMin(&s_blo[pp], (uint32_t)tid);
+            if ((uint32_t)tid < nb) { ag_st(&myslot->bstart[tid], s_bstart[tid]); ag_st(&myslot->bcount[tid], s_bcount[tid]); ag_st(&myslot->bcode[tid], s_bcode[tid]); }
+            __syncthreads();
+            if ((uint32_t)tid <= np) ag_st(&myslot->blo[tid], (uint32_t)tid == np ? nb : s_blo[tid]);
+            if (tid == 0) {
+              ag_st(&myslot->li, li); ag_st(&myslot->nb, nb); ag_st(&myslot->done, 0u); ag_st(&myslot->best_single, best_single);
+              ag_st(&myslot->bestrid, (uint32_t)s_bestrid); ag_st(&myslot->bestpart, 0xffffffffu);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every store of this wavefront has been acknowledged ...
+            __syncthreads();                                   // ... and so have the other wavefronts')
+            if (tid == 0) {
+              const uint32_t base = atomicAdd(&P.lctl[1], np - 1);
+              uint32_t okp = 0;
+              if (base + np - 1 <= P.ltask_cap) {
+                ag_st(&myslot->nparts, np);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (uint32_t pp = 1; pp < np; pp++)
+                  __hip_atomic_store(&P.ltask[base + pp - 1], ((blockIdx.x + 1u) << 4) | pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                okp = np;
+                atomicAdd(&P.lctl[3], 1u);
+              }
+              s_ctl = okp;
+            }
+            __syncthreads();
+            const uint32_t okp = uni_u32(s_ctl);
+            if (okp) {  // this block keeps part 0
+              nparts = okp;
+              b_hi = uni_u32(s_blo[1]);
+              if ((uint32_t)tid >= b_hi) s_bdone[tid] = my_nch;
+              continue;
+            }
+          }
+        }
+      }
       for (;;) {
         // No `if (lane == 0)` around the atomics of this loop: with one at the end of an iteration (the atomicMin) and one
         // at the start of the next (the ticket) the compiler threads the two branches, and lanes 1-63 go round the loop on
@@ -2083,6 +2179,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
 #endif
         const uint32_t g = uni_u32((uint32_t)(atomicAdd(&s_ticket, 1ull) >> 6));
         if (g >= (total + LONG_NCH - 1) / LONG_NCH) break;
+        if (nparts > 1 && uni_u32(__hip_atomic_load(&slot->bestpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < part) break;
         const uint32_t c0 = g * LONG_NCH;
         uint32_t lo = 0, hi = nb;  // the bin of listed chunk c0: the last b with chunk0[b] <= c0 (it has chunks: c0 < total)
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (uni_u32(s_bchunk0[mid]) <= c0) lo = mid; else hi = mid; }
@@ -2248,12 +2345,17 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         s_bdone[tid] = my_tgt;  // nothing stopped early: every listed chunk was compared
       } else if (ok) {
         // the best pass so far: the bins behind it are out, the bins ahead of it are complete up to their targets
-        if (tid == 0) s_valid = ((unsigned long long)c_hi << 32) | c_lo;
+        if (tid == 0) {
+          s_valid = ((unsigned long long)c_hi << 32) | c_lo;
+          if (nparts > 1) atomicMin(&slot->bestpart, part);  // (the parts behind this one can stop)
+        }
         s_bdone[tid] = (uint32_t)tid >= cb ? my_nch : my_tgt;
       } else {
         // outside the window: bin cb is left.  The chunks behind it may or may not have been compared (wavefronts stopped at
         // the key): their bins keep their lists and forget this turn's live entries
-        if (tid == 0) { s_capped = 1; s_minpass = s_valid; }
+        // (that the probe of bin cb stopped at the window -- the search's "capped" flag -- is said at the end, and only if the
+        // bin lies ahead of the winner: s_binlive[cb] >= MAX_SEARCH is what brought the check about)
+        if (tid == 0) s_minpass = s_valid;
         if ((uint32_t)tid < cb) s_bdone[tid] = my_tgt;
         else if ((uint32_t)tid == cb) s_bdone[tid] = my_nch;
         else s_binlive[tid] = live_prev;
@@ -2261,9 +2363,40 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     }
     // a bin ahead of the winner (any bin when nothing won) that held MAX_SEARCH live entries stopped its probe at the window
     {
+      const uint32_t v_hi = uni_u32(((const uint32_t *)&s_valid)[1]);
+      const uint32_t wb = v_hi != 0xffffffffu ? v_hi : b_hi;
+      if ((uint32_t)tid >= b_lo && (uint32_t)tid < wb && my_big && s_binlive[tid] >= (uint32_t)MAX_SEARCH) s_capped = 1;
+    }
+    if (nparts > 1) {
+      // a part of a split search: its result goes to the slot; the part that finishes last combines them -- the lowest part
+      // with a pass wins, the parts up to it say whether a bin stopped at the window
+      __syncthreads();
+      if (tid == 0) {
+        ag_st(&slot->res[part], aborted ? ~0ull : (unsigned long long)s_valid);
+        ag_st(&slot->capped[part], (uint32_t)s_capped);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ctl = atomicAdd(&slot->done, 1u) == nparts - 1;
+      }
+      __syncthreads();
+      if (!uni_u32(s_ctl)) { __syncthreads(); continue; }
+      if (tid == 0) {
+        unsigned long long key = ~0ull;
+        uint32_t cap = 0;
+        for (uint32_t pp = 0; pp < nparts && key == ~0ull; pp++) {
+          cap |= __hip_atomic_load(&slot->capped[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          key = __hip_atomic_load(&slot->res[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_valid = key; s_capped = cap;
+        s_best = __hip_atomic_load(&slot->best_single, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bestrid = __hip_atomic_load(&slot->bestrid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ag_st(&slot->nparts, 0u);  // the slot is free again
+      }
+      __syncthreads();
+      best_single = s_best;
+    }
+    {
       const uint32_t v_hi = uni_u32(((const uint32_t *)&s_valid)[1]), v_lo = uni_u32(((const uint32_t *)&s_valid)[0]);
-      const uint32_t wb = v_hi != 0xffffffffu ? v_hi : nb;
-      if ((uint32_t)tid < wb && my_big && s_binlive[tid] >= (uint32_t)MAX_SEARCH) s_capped = 1;
       if (tid == 0 && v_hi != 0xffffffffu) {
         typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
         g_u32_t *pids = (g_u32_t *)((s_bcode[v_hi] & 1) ? P.ids[1] : P.ids[0]);
@@ -2316,6 +2449,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
         }
         c->st_long++;  // (the chain is this block's alone)
+        if (P.lctl) atomicAdd(&P.lctl[2], 1u);  // one more search of the round finished
       }
     }
     __syncthreads();  // the LDS state belongs to the next chain of this block
@@ -2383,6 +2517,8 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
   if (cid == 0 && P.longq) { P.longq[0] = 0; P.longq[1] = 0; }  // this round's long searches are done (k_long ran before this kernel)
+  if (P.longq && cid < 3) P.lctl[cid] = 0;
+  if (P.longq && cid < P.ltask_cap) P.ltask[cid] = 0;  // (K entries: half a megabyte per round on the pools that have a queue)
   if (P.ord) {  // class lists of this block's chains (k_round_mc): class 0 first, no atomics
     static_assert(MARK_BLOCK == 256, "k_mg_mark runs 256 chains per block");
     __shared__ uint32_t s_wc[4][4];  // [wave][class]

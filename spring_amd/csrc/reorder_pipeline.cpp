@@ -1358,7 +1358,9 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.long_min = P.long_budget < 8 ? 0 : 2048;
   if (o.long_min > 0) P.long_min = o.long_min;
   if (o.long_blocks > 0) P.long_blocks = o.long_blocks;
+  P.long_split = o.long_split > 0 ? o.long_split : o.long_split < 0 ? 0 : 128;
   P.longq = nullptr;
+  P.lctl = nullptr; P.ltask = nullptr; P.lslot = nullptr; P.ltask_cap = 0;
   P.sig[0] = P.sig[1] = nullptr;
 }
 // Default chain count.  ~1000 reads per chain: the compressed size grows with the chain count on ordinary coverage
@@ -1445,6 +1447,13 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     if (P.deep_bins && P.long_budget > 0) {  // queue of the searches k_round hands to k_long
       DMALLOC(P.longq, ((size_t)K + 2) * 4);
       HIPCHK(hipMemsetAsync(P.longq, 0, 8, st));
+      P.ltask_cap = K;
+      DMALLOC(P.lctl, 4 * 4);
+      DMALLOC(P.ltask, (size_t)K * 4);
+      DMALLOC(P.lslot, (size_t)P.long_blocks * sizeof(LongSlot));
+      HIPCHK(hipMemsetAsync(P.lctl, 0, 4 * 4, st));
+      HIPCHK(hipMemsetAsync(P.ltask, 0, (size_t)K * 4, st));
+      HIPCHK(hipMemsetAsync(P.lslot, 0, (size_t)P.long_blocks * sizeof(LongSlot), st));
       for (int l = 0; l < 2; l++) {  // ... and the signatures k_long rejects most bin entries from (16 bytes per dictionary entry)
         ulonglong2 *sg = nullptr;
         const uint64_t m = ctx->dict[l].numreads;
@@ -1921,6 +1930,12 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   s.unmatched = htot[0]; s.probes = htot[1]; s.keyok = htot[2]; s.cands = htot[3]; s.iterations = htot[4];
   s.lost = htot[5]; s.hits = htot[6]; s.long_searches = htot[7];
   s.table_minz = ctx->minz; s.table_marked_lines = ctx->marked_lines;
+  s.long_splits = 0;
+  if (P.lctl) {
+    uint32_t ns = 0;
+    HIPCHK(hipMemcpy(&ns, P.lctl + 3, 4, hipMemcpyDeviceToHost));  // (k_mg_mark zeroes [0..2] every round, [3] counts the run's splits)
+    s.long_splits = ns;
+  }
 #ifdef SR_PHASE_TIMING  // experiment builds: per-phase shader clocks of k_round (tools/xbuild.sh, XPIPE=1)
   {
     unsigned long long pt[64] = {0};

@@ -241,6 +241,7 @@ def test_synth_host_equals_device():
 
 @pytest.mark.parametrize("K,T,kw", [(1, 1, dict(collect_stats=True)), (64, 3, dict(collect_stats=True)), (256, 2, dict(fused=3, deep_bins=-1)),
                                     (256, 2, dict(deep_bins=1)), (256, 2, dict(fused=3, table_mode=2, deep_bins=-1)),
+                                    (256, 2, dict(deep_bins=1, long_budget=1, long_split=1)), (300, 2, dict(deep_bins=1, long_budget=2, long_split=3, long_blocks=2)),
                                     (0, 2, dict())])
 def test_genome_like_pool_vs_oracle(K, T, kw):
     """A pool drawn from the genome-like generator (SYN_GENOMIC_FLAG: 64 Zipf-sized repeat families at 5-20 % divergence,
@@ -434,18 +435,20 @@ def test_resumed_search_with_bins_beyond_max_search(K):
     _same(_gpu("heavy", K, 1, deep_bins=1), po.reorder_rounds(read, ln, L, K, 1), ("heavy", K))
 
 
-@pytest.mark.parametrize("budget", [1, 3, 0])
+@pytest.mark.parametrize("budget,split,blocks", [(1, 0, 0), (3, 0, 0), (0, 0, 0), (1, 1, 0), (1, 2, 3), (1, 1, 1), (3, 16, 0)])
 @pytest.mark.parametrize("n,L,G,K", [(60_000, 100, 300, 256), (40_000, 150, 2_000, 500), (30_000, 150, 400, 37)])
-def test_long_searches_through_k_long(n, L, G, K, budget):
+def test_long_searches_through_k_long(n, L, G, K, budget, split, blocks):
     """Deep-bin pools: a search that has used up `long_budget` compare passes in k_round is finished by k_long (one
     block of 16 wavefronts per chain, same probes / priority order / MAX_SEARCH rule).  budget 1 sends nearly every
     search over a multi-read bin there, 3 a mixture, 0 is the default (8 passes, and only searches with thousands of
     bin entries still ahead of them); the streams equal the rounds oracle and
-    the run with k_long switched off."""
+    the run with k_long switched off.  split: chunks of 64 bin entries per part of a split search (long_split; 1 splits
+    every search with four chunks ahead of it into up to eight parts that other blocks -- with `blocks` = 1 the same block,
+    later -- take over); the default (128) never fires on pools of this size."""
     sa = _sa()
     outs = {}
     for b in (budget, -1):
-        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, deep_bins=1, long_budget=b)) as st:
+        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, deep_bins=1, long_budget=b, long_split=split, long_blocks=blocks)) as st:
             st.load_synth(n, L, G, 23, 10000)
             outs[b] = st.run().streams()
             dna = st.download_dna()
@@ -454,22 +457,26 @@ def test_long_searches_through_k_long(n, L, G, K, budget):
     _same(outs[budget], want, ("k_long", budget))
     _same(outs[-1], want, "k_long off")
     assert outs[-1]["stats"]["long_searches"] == 0
+    if split in (1, 2):
+        assert outs[budget]["stats"]["long_splits"] > 0
+    assert outs[-1]["stats"]["long_splits"] == 0
     if budget > 0:  # (the default budget only fires on searches longer than these pools have)
         assert outs[budget]["stats"]["long_searches"] > (n // 20 if budget == 1 else 0), outs[budget]["stats"]["long_searches"]
 
 
+@pytest.mark.parametrize("split", [0, 1, 4])
 @pytest.mark.parametrize("K", [16, 300])
-def test_long_searches_with_bins_beyond_max_search(K):
+def test_long_searches_with_bins_beyond_max_search(K, split):
     """k_long on the set whose bins hold more than MAX_SEARCH_REORDER reads (the live-entry limit is kept per bin across
     the 64-entry chunks the wavefronts of a block take), also over two virtual ranks (proposal words instead of resv[])."""
     from spring_amd.pool import VirtualPool
     dna, n, L = named_set("heavy")
     read, ln = po.load_dna(dna, n, L)
     want = po.reorder_rounds(read, ln, L, K, 1)
-    got = _gpu("heavy", K, 1, deep_bins=1, long_budget=1)
+    got = _gpu("heavy", K, 1, deep_bins=1, long_budget=1, long_split=split)
     _same(got, want, ("heavy k_long", K))
     assert got["stats"]["long_searches"] > 0
-    vp = VirtualPool(2, K, 1, deep_bins=1, long_budget=1)
+    vp = VirtualPool(2, K, 1, deep_bins=1, long_budget=1, long_split=split)
     try:
         got2 = vp.run(lambda s: s.load_dna(dna, n, L))
     finally:

@@ -20,8 +20,8 @@ def run(n, L, K, stats=False, timed=False, rps=0, err=10000, repeats=False, cov=
     t1 = time.perf_counter()
     st = s.stats()
     s.close()
-    print("n=%d L=%d K=%d wall=%.3fs  unpack=%.1f dict=%.1f chains=%.1f final=%.1f ms rounds=%d unmatched=%d single=%d Mreads/s=%.2f search_ms=%.1f launches=%d lost=%d long=%d dev=%.1fGB" % (
-        n, L, K, t1-t0, st["ms_unpack"], st["ms_dict"], st["ms_chains"], st["ms_finalize"], st["rounds"], st["unmatched"], st["n_single"], n/(t1-t0)/1e6, st["ms_search_kernel"], st["search_launches"], st["lost"], st["long_searches"], st["device_bytes"]/1e9), flush=True)
+    print("n=%d L=%d K=%d wall=%.3fs  unpack=%.1f dict=%.1f chains=%.1f final=%.1f ms rounds=%d unmatched=%d single=%d Mreads/s=%.2f search_ms=%.1f launches=%d lost=%d long=%d splits=%d dev=%.1fGB" % (
+        n, L, K, t1-t0, st["ms_unpack"], st["ms_dict"], st["ms_chains"], st["ms_finalize"], st["rounds"], st["unmatched"], st["n_single"], n/(t1-t0)/1e6, st["ms_search_kernel"], st["search_launches"], st["lost"], st["long_searches"], st["long_splits"], st["device_bytes"]/1e9), flush=True)
     return st
 for a in sys.argv[1:]:
     f = a.split(",")
