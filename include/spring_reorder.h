@@ -82,6 +82,8 @@ typedef struct {
   int32_t debug;          /* 1: stage / phase timings on stderr */
   int32_t long_split;     /* k_long: a search with at least 4 x this many 64-entry chunks of bin entries ahead of it is split
                              into parts that idle blocks take over (0 = default 128, -1 = never) */
+  int32_t entry_flags;    /* deep-bin pools: -1 = the bin entries do not carry their read's taken bit (the scans ask the bitmap, as
+                             before round 4); 0 = they do.  Same results either way */
 } spring_reorder_opts;
 
 typedef struct {

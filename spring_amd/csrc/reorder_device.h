@@ -133,6 +133,12 @@ struct DevParams {
   TabView tab;                // ONE table for both dictionaries (tab_find)
   const ulonglong2 *urec[2];  // {key, start | count<<32} per unique key (multi-read bins)
   const uint32_t *ids[2];
+  // Liveness inside the bins (deep-bin pools, fused rounds; else null / 0xffffffff): epos[l][read] = index of the read's entry
+  // in ids[l] (0xffffffff: none), and bit 31 of that entry is set when the read is taken (k_mg_mark, k_init_seeds) -- a bin
+  // scan then knows a dead entry from the id it has loaded anyway instead of asking the bitmap (one random request per
+  // entry: two thirds of k_long's requests on a bin of more than MAX_SEARCH entries).  idmask strips the bit (n < 2^31).
+  uint32_t *epos[2];
+  uint32_t idmask;
   const ulonglong2 *sig[2];   // k_long only (else null): {first limb, last limb} of the read of every entry of ids[l] (k_build_sig)
   // shared mutable state
   uint64_t *taken;    // bitmap, bit r set <=> read r claimed (== !remainingreads[r], reorder.h:343)
@@ -208,8 +214,10 @@ hipError_t sort_pairs_u32_u64(hipStream_t st, void *tmp, size_t &tmp_bytes, cons
 hipError_t merge_by_hash(hipStream_t st, void *tmp, size_t &tmp_bytes, const uint64_t *k0, const uint64_t *k1,
                          const uint64_t *v0, const uint64_t *v1, uint64_t *kout, uint64_t *vout, size_t n0, size_t n1);
 void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag);
+void launch_build_epos(hipStream_t st, const uint32_t *ids, uint64_t m, uint32_t *epos);
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
-                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken, ulonglong2 *sig /* or null: moved with the ids */);
+                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken, ulonglong2 *sig /* or null: moved with the ids */,
+                      uint32_t *epos = nullptr /* or null: follows the ids, and bit 31 of an id says "taken" */);
 void launch_build_sig(hipStream_t st, const uint32_t *ids, uint64_t m, const uint64_t *reads, int S, int W, ulonglong2 *sig);
 void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,

@@ -406,7 +406,8 @@ __global__ void k_iota_tag(uint64_t *v, uint64_t n, uint64_t tag) {
 // TRIM kernel variants only cuts the dead tail.)
 __global__ __launch_bounds__(256) void k_trim_bins(const uint32_t *__restrict__ deep, const uint32_t *__restrict__ ndeep,
                                                    ulonglong2 *__restrict__ urec, uint32_t *__restrict__ ids,
-                                                   const uint64_t *__restrict__ taken, ulonglong2 *__restrict__ sig /* or null */) {
+                                                   const uint64_t *__restrict__ taken, ulonglong2 *__restrict__ sig /* or null */,
+                                                   uint32_t *__restrict__ epos /* or null */) {
   const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= *ndeep) return;
@@ -417,12 +418,17 @@ __global__ __launch_bounds__(256) void k_trim_bins(const uint32_t *__restrict__ 
   for (uint32_t base = 0; base < count; base += 64) {
     const uint32_t j = base + lane;
     const uint32_t r = j < count ? ids[start + j] : 0u;
-    const bool live = j < count && !is_taken(taken, r);
+    // (with epos: bit 31 of the id is the read's taken bit -- a live entry's id has it clear)
+    const bool live = j < count && (epos ? !(r >> 31) : !is_taken(taken, r));
     ulonglong2 sg = make_ulonglong2(0, 0);
     if (sig && live) sg = sig[start + j];
     const uint64_t m = __ballot(live);
     const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-    if (live && pos != j) { ids[start + pos] = r; if (sig) sig[start + pos] = sg; }  // (every lane has read its entry before any lane writes)
+    if (live && pos != j) {  // (every lane has read its entry before any lane writes)
+      ids[start + pos] = r;
+      if (sig) sig[start + pos] = sg;
+      if (epos) epos[r] = start + pos;
+    }
     w += (uint32_t)__popcll(m);
   }
   if (lane == 0 && w != count) urec[u].y = (uint64_t)start | ((uint64_t)w << 32);
@@ -805,6 +811,22 @@ __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
     if (P.prop) P.prop[cid] = (unsigned long long)PK_NONE << 32;
   }
 }
+// a read has been taken: its bin entries say so (DevParams::epos)
+__device__ __forceinline__ void mark_dead(const DevParams &P, uint32_t rid) {
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (!P.epos[l]) continue;
+    const uint32_t e = P.epos[l][rid];
+    if (e != 0xffffffffu) atomicOr(const_cast<uint32_t *>(P.ids[l]) + e, 0x80000000u);
+  }
+}
+__global__ void k_build_epos(const uint32_t *__restrict__ ids, uint64_t m, uint32_t *__restrict__ epos) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) epos[ids[i]] = (uint32_t)i;
+}
+void launch_build_epos(hipStream_t st, const uint32_t *ids, uint64_t m, uint32_t *epos) {
+  if (m) hipLaunchKernelGGL(k_build_epos, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, ids, m, epos);
+}
 // every rank marks the initial seeds of ALL chains (taken[] is replicated)
 __global__ void k_init_seeds(DevParams P) {
   const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -814,6 +836,7 @@ __global__ void k_init_seeds(DevParams P) {
   const uint32_t seed = cid * step;
   atomicOr((unsigned long long *)&P.taken[seed >> 6], 1ull << (seed & 63));
   atomicSub(&P.ublk[seed >> UBLK_SHIFT], 1u);
+  mark_dead(P, seed);
 }
 
 // (rank+1)-th highest untaken read at or below the cursor, rank = number of seed-needing chains
@@ -1098,7 +1121,12 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
         *walk_left = j;
       }
       const uint32_t r = single ? pay : ids[start + j];
-      if (!SPEC && is_taken(P.taken, r)) continue;
+      bool known_live = false;
+      if (TRIM && !single && P.idmask != 0xffffffffu) {  // (the entry itself says whether its read is taken)
+        if (r >> 31) continue;
+        known_live = true;
+      }
+      if (!SPEC && !known_live && is_taken(P.taken, r)) continue;
       if (TRIM && top_live < 0) top_live = j;
       const int wt = within_thresh(r, single);
       if (SPEC && wt == -2) continue;  // taken
@@ -1215,7 +1243,10 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
         const int pl = ow & 1, prev = (ow >> 1) & 1, psh = sh_base + (ow >> 2);
         g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
         r = pids[pst + (uint32_t)j];
-        if (!is_taken(P.taken, r)) {
+        bool dead;
+        if (P.idmask != 0xffffffffu) { dead = (r >> 31) != 0; r &= 0x7fffffffu; }
+        else dead = is_taken(P.taken, r);
+        if (!dead) {
           lv = true;
           const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
           ps = cmp_candidate<true>(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
@@ -2195,7 +2226,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         const long long lq1 = clock64();
 #endif
         // A: id and signature of every entry of the chunks
-        uint32_t kb[LONG_NCH], kq[LONG_NCH], rk[LONG_NCH];
+        uint32_t kb[LONG_NCH], kq[LONG_NCH], rk[LONG_NCH], kdead[LONG_NCH];
         bool kbig[LONG_NCH], has[LONG_NCH];
         int kcode[LONG_NCH];
         ulonglong2 sgk[LONG_NCH];
@@ -2213,13 +2244,15 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
             kbig[k] = cnt > (uint32_t)MAX_SEARCH;
             const long long j = (long long)cnt - 1 - ((long long)kq[k] * 64 + lane);
             has[k] = kv && j >= 0;
-            rk[k] = 0; sgk[k] = make_ulonglong2(0, 0);
+            rk[k] = 0; sgk[k] = make_ulonglong2(0, 0); kdead[k] = 0;
             if (has[k]) {
               const int pl = kcode[k] & 1;
               g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
               const ulonglong2 *psig = pl ? uni_ptr(P.sig[1]) : uni_ptr(P.sig[0]);
               rk[k] = pids[st0 + (uint32_t)j];
               sgk[k] = psig[st0 + (uint32_t)j];
+              kdead[k] = rk[k] >> 31;  // (meaningful with DevParams::epos only)
+              rk[k] &= P.idmask;
             }
           }
         }
@@ -2237,7 +2270,10 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           sp[k] = has[k] && sig_bound(P, prev ? srev : sref, prev ? -2 * psh : 2 * psh, prev ? psh : 0,
                                       prev ? ref_len + psh : ref_len - psh, rk[k], sgk[k]) <= THRESH;
           tw[k] = ~0ull;
-          if (has[k] && (kbig[k] || sp[k])) tw[k] = P.taken[rk[k] >> 6];
+          if (has[k] && (kbig[k] || sp[k])) {
+            if (P.idmask != 0xffffffffu) tw[k] = kdead[k] ? ~0ull : 0ull;  // (the entry said it: no request)
+            else tw[k] = P.taken[rk[k] >> 6];
+          }
         }
 #if SR_LONG_COUNT == 3
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2332,7 +2368,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           const unsigned long long ahead = (unsigned long long)cq * 64 + cfp;  // entries of the bin visited before the pass
           uint32_t mycnt = 0;
           for (unsigned long long pp = (unsigned long long)tid; pp < ahead; pp += 64 * LONG_WAVES)
-            mycnt += !is_taken(P.taken, pids[st0 + (cnt - 1 - (uint32_t)pp)]);
+            { const uint32_t rr = pids[st0 + (cnt - 1 - (uint32_t)pp)]; mycnt += P.idmask != 0xffffffffu ? !(rr >> 31) : !is_taken(P.taken, rr); }
           const uint32_t wsum = (uint32_t)wave_sum_i((int)mycnt);
           if (wsum) atomicAdd(&s_ctl, lane == 0 ? wsum : 0u);
           __syncthreads();
@@ -2401,7 +2437,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
         g_u32_t *pids = (g_u32_t *)((s_bcode[v_hi] & 1) ? P.ids[1] : P.ids[0]);
         s_win_code = s_bcode[v_hi];
-        s_win_rid = pids[s_bstart[v_hi] + (s_bcount[v_hi] - 1 - ((v_lo >> 6) * 64 + (v_lo & 63u)))];
+        s_win_rid = pids[s_bstart[v_hi] + (s_bcount[v_hi] - 1 - ((v_lo >> 6) * 64 + (v_lo & 63u)))] & P.idmask;
       }
     }
     __syncthreads();
@@ -2491,6 +2527,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
       const bool won = P.resv[rid] == cid;
       if (won) {
         atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+        mark_dead(P, rid);
         // (matches only: seeds all come from the top of the pool -- thousands of same-address atomics per round --
         // and find_seed counts the cursor's block from the bitmap)
         if (pk == PK_MATCH) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
@@ -2694,9 +2731,9 @@ void launch_iota_tag(hipStream_t st, uint64_t *v, uint64_t n, uint64_t tag) {
   hipLaunchKernelGGL(k_iota_tag, GRID1(n, 256), dim3(256), 0, st, v, n, tag);
 }
 void launch_trim_bins(hipStream_t st, const uint32_t *deep, const uint32_t *ndeep, uint32_t ndeep_host,
-                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken, ulonglong2 *sig) {
+                      ulonglong2 *urec, const uint32_t *ids, const uint64_t *taken, ulonglong2 *sig, uint32_t *epos) {
   if (!ndeep_host) return;
-  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 4), dim3(256), 0, st, deep, ndeep, urec, const_cast<uint32_t *>(ids), taken, sig);
+  hipLaunchKernelGGL(k_trim_bins, GRID1(ndeep_host, 4), dim3(256), 0, st, deep, ndeep, urec, const_cast<uint32_t *>(ids), taken, sig, epos);
 }
 void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int which,
                         const uint64_t *reads, int S, int dstart, int dend, const uint64_t *keys, uint32_t nkeys,

@@ -1318,7 +1318,9 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   for (int l = 0; l < 2; l++) {
     P.dstart[l] = ctx->dict[l].start; P.dend[l] = ctx->dict[l].end; P.numkeys[l] = ctx->dict[l].numkeys;
     P.urec[l] = ctx->dict[l].urec; P.ids[l] = ctx->dict[l].ids;
+    P.epos[l] = nullptr;
   }
+  P.idmask = 0xffffffffu;
   P.tab = tab_view(ctx);
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
@@ -1431,6 +1433,14 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   }
   P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
   ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
+  if (fused && P.deep_bins && ctx->o.entry_flags >= 0 && n < 0x80000000u) {  // liveness inside the bins (DevParams::epos)
+    for (int l = 0; l < 2; l++) {
+      DMALLOC(P.epos[l], (size_t)std::max<uint32_t>(n, 1) * 4);
+      HIPCHK(hipMemsetAsync(P.epos[l], 0xff, (size_t)std::max<uint32_t>(n, 1) * 4, st));
+      launch_build_epos(st, ctx->dict[l].ids, ctx->dict[l].numreads, P.epos[l]);
+    }
+    P.idmask = 0x7fffffffu;
+  }
   if (fused) {  // the rounds whose shared state k_mg_mark keeps: proposal words + double-buffered counters
     const size_t nblk = (size_t)Ktot / 2048 + 1;
     if (d_prop) P.prop = (unsigned long long *)d_prop;
@@ -1568,7 +1578,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
     }
     rounds += R;
     for (int l = 0; l < 2; l++)  // shrink deep bins whose tail has been consumed (exact; see k_trim_bins)
-      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]));
+      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]), P.epos[l]);
     // chains still running: the two-kernel round keeps the count, the fused round recounts it every round
     if (fused) {
       int ra = running_chains(ctx, alive_tmp, h_alive);
@@ -1655,7 +1665,7 @@ int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32
   ctx->stats.rounds++;
   if (ctx->stats.rounds % 16 == 0)
     for (int l = 0; l < 2; l++)
-      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, ctx->P.taken, const_cast<ulonglong2 *>(ctx->P.sig[l]));
+      launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, ctx->P.taken, const_cast<ulonglong2 *>(ctx->P.sig[l]), ctx->P.epos[l]);
   if (check_alive) {
     uint32_t a = 0;
     std::vector<uint32_t> tmp;
@@ -1836,7 +1846,7 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
       ctx->stats.rounds++;
       if (ctx->stats.rounds % 16 == 0)
         for (int l = 0; l < 2; l++)
-          launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]));
+          launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]), P.epos[l]);
     }
     if (ret) break;
     if (timed) {
@@ -1930,12 +1940,6 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   s.unmatched = htot[0]; s.probes = htot[1]; s.keyok = htot[2]; s.cands = htot[3]; s.iterations = htot[4];
   s.lost = htot[5]; s.hits = htot[6]; s.long_searches = htot[7];
   s.table_minz = ctx->minz; s.table_marked_lines = ctx->marked_lines;
-  s.long_splits = 0;
-  if (P.lctl) {
-    uint32_t ns = 0;
-    HIPCHK(hipMemcpy(&ns, P.lctl + 3, 4, hipMemcpyDeviceToHost));  // (k_mg_mark zeroes [0..2] every round, [3] counts the run's splits)
-    s.long_splits = ns;
-  }
 #ifdef SR_PHASE_TIMING  // experiment builds: per-phase shader clocks of k_round (tools/xbuild.sh, XPIPE=1)
   {
     unsigned long long pt[64] = {0};
@@ -1990,6 +1994,12 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   HIPCHK(hipStreamSynchronize(st));
+  s.long_splits = 0;
+  if (P.lctl) {
+    uint32_t ns = 0;  // (k_mg_mark zeroes [0..2] every round, [3] counts the run's splits)
+    HIPCHK(hipMemcpy(&ns, P.lctl + 3, 4, hipMemcpyDeviceToHost));
+    s.long_splits = ns;
+  }
   ctx->dfree(d_off_m); ctx->dfree(d_off_s);
   // the append-order buffers are no longer needed
   ctx->dfree(P.e_rec); ctx->dfree(P.e_chunk); ctx->dfree(P.s_rec); ctx->dfree(P.s_chunk);

@@ -45,6 +45,7 @@ class ReorderOpts:
     plan1: tuple = ()
     long_min: int = 0
     long_blocks: int = 0
+    entry_flags: int = 0      # -1: deep-bin scans ask the taken bitmap instead of reading the flag in the bin entry (A/B)
     long_split: int = 0       # k_long: chunks of 64 bin entries per part of a split search (0 = default 128, -1 = never split)
     debug: bool = False       # stage timings on stderr
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
@@ -67,7 +68,7 @@ class ReorderOpts:
         for i, v in enumerate(tuple(self.plan1)[:6]):
             o.plan1[i] = int(v)
         o.long_min, o.long_blocks, o.debug = self.long_min, self.long_blocks, int(self.debug)
-        o.long_split = self.long_split
+        o.long_split, o.entry_flags = self.long_split, self.entry_flags
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d

@@ -242,6 +242,7 @@ def test_synth_host_equals_device():
 @pytest.mark.parametrize("K,T,kw", [(1, 1, dict(collect_stats=True)), (64, 3, dict(collect_stats=True)), (256, 2, dict(fused=3, deep_bins=-1)),
                                     (256, 2, dict(deep_bins=1)), (256, 2, dict(fused=3, table_mode=2, deep_bins=-1)),
                                     (256, 2, dict(deep_bins=1, long_budget=1, long_split=1)), (300, 2, dict(deep_bins=1, long_budget=2, long_split=3, long_blocks=2)),
+                                    (256, 2, dict(deep_bins=1, long_budget=1, long_split=1, entry_flags=-1)), (0, 3, dict(entry_flags=-1)),
                                     (0, 2, dict())])
 def test_genome_like_pool_vs_oracle(K, T, kw):
     """A pool drawn from the genome-like generator (SYN_GENOMIC_FLAG: 64 Zipf-sized repeat families at 5-20 % divergence,
@@ -387,7 +388,8 @@ def test_single_pool_1M_4_virtual_ranks():
                                 dict(dbg_search_lds=20000), dict(dbg_apply_lds=20000, fused=-1), dict(fused=-1),
                                 dict(first_shifts=3, seed_wide=-1, tab_scale=1, search_wpb=4, fused=-1),
                                 dict(table_mode=1, tab_scale=4), dict(plan0=(4, 4, 8, 16)), dict(plan0=(16,), plan1=(2, 2, 4), fused=3),
-                                dict(plan0=(1, 1, 2, 4, 8, 16), deep_bins=1), dict(long_min=64, long_blocks=7, long_budget=2, deep_bins=1)])
+                                dict(plan0=(1, 1, 2, 4, 8, 16), deep_bins=1), dict(long_min=64, long_blocks=7, long_budget=2, deep_bins=1),
+                                dict(deep_bins=1, entry_flags=-1)])
 @pytest.mark.parametrize("name,K,T", [("syn5k_150", 64, 3), ("var2k", 7, 2), ("heavy", 16, 1), ("tandem", 32, 2)])
 def test_tuning_opts_do_not_change_results(name, K, T, kw):
     """Every tuning / experiment field of spring_reorder_opts at a non-default value: same streams, same per-tid
