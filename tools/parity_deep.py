@@ -1,7 +1,8 @@
 """Parity on deep-coverage pools (the regime of bin compaction, the balanced bin scan and resumed searches):
 GPU reorder in the PRODUCTION build (no work counting: that is the build with those mechanisms) == rounds oracle,
 and the counting build == rounds oracle including the reference-equivalent work counters.
-usage: parity_deep.py reads,readlen,genome,chains ..."""
+usage: parity_deep.py reads,readlen,genome,chains[,gen] ...   (gen: a genome-like pool -- repeat families, tandem repeats,
+low-complexity runs; chains = 0 then means the library's own choice, and the oracle runs with that count)"""
 import os
 import sys
 import time
@@ -15,9 +16,12 @@ from helpers import KEYS  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 for a in sys.argv[1:]:
-    n, L, G, K = [int(x) for x in a.split(",")]
-    K = K or max(1, min(65536, n >> 10))
-    dna = spring_amd.synth_dna_host(n, L, G, 21)
+    f = a.split(",")
+    n, L, G, K = [int(x) for x in f[:4]]
+    gen = len(f) > 4 and f[4] == "gen"
+    if not gen:
+        K = K or max(1, min(65536, n >> 10))
+    dna = spring_amd.synth_dna_host(n, L, G, 21, 10000 | spring_amd.SYNTH_GENOMIC) if gen else spring_amd.synth_dna_host(n, L, G, 21)
     read, ln = po.load_dna(dna, n, L)
     outs = []
     for stats in (False, True):
@@ -25,6 +29,8 @@ for a in sys.argv[1:]:
             st.load_dna(dna, n, L)
             st.run()
             outs.append((st.streams(), st.stats()))
+    K = outs[0][1]["chains"]
+    assert outs[1][1]["chains"] == K
     t0 = time.time()
     want = po.reorder_rounds(read, ln, L, K, 8)
     for (got, gst), what in zip(outs, ("production build", "counting build")):
@@ -34,6 +40,6 @@ for a in sys.argv[1:]:
     for k in ("probes", "keyok", "cands", "hits", "unmatched"):
         assert outs[1][1][k] == want["stats"][k], (k, outs[1][1][k], want["stats"][k])
     print("n=%d L=%d genome=%d (%.0fx) K=%d: production and counting builds identical to the rounds oracle (%.0f s of oracle); "
-          "rounds %d, lost proposals %d, %.1f candidate comparisons per read, %d searches finished by k_long, production chains stage %.1f ms"
+          "rounds %d, lost proposals %d, %.1f candidate comparisons per read, %d searches finished by k_long (%d split), production chains stage %.1f ms"
           % (n, L, G, n * L / G, K, time.time() - t0, outs[0][1]["rounds"], outs[0][1]["lost"],
-             want["stats"]["cands"] / n, outs[0][1]["long_searches"], outs[0][1]["ms_chains"]), flush=True)
+             want["stats"]["cands"] / n, outs[0][1]["long_searches"], outs[0][1]["long_splits"], outs[0][1]["ms_chains"]), flush=True)
