@@ -103,7 +103,7 @@ constexpr int MINZ_K = 16;                  // minimizer length in bases
 constexpr int MINZ_WL = 32;                 // ... of windows of this length only (MINZ_WL - MINZ_K + 1 = 17 k-mers per window)
 
 constexpr int LONG_MAX_BINS = 1024;  // one bin per probe code of a search (k_long: one thread per probe)
-constexpr int LONG_MAX_PARTS = 8;
+constexpr int LONG_MAX_PARTS = 64;
 // A long search whose bins hold far more entries than the average one is split into parts (ranges of its bins in priority
 // order) that blocks without a search of their own take over: the block that ran the probes publishes the bin list here.
 struct LongSlot {
@@ -164,7 +164,7 @@ struct DevParams {
   uint32_t *longq;
   int long_budget, long_min, long_blocks, long_split;
   // split long searches (k_long): lctl[0] = next help ticket, [1] = help tasks pushed, [2] = searches finished this round;
-  // ltask[i] = (slot + 1) << 4 | part of help task i (0: not pushed yet), ltask_cap entries; lslot[block] = what the parts of
+  // ltask[i] = (slot + 1) << 8 | part of help task i (0: not pushed yet), ltask_cap entries; lslot[block] = what the parts of
   // a split search share.  k_mg_mark zeroes lctl and ltask with the queue.
   uint32_t *lctl, *ltask;
   uint32_t ltask_cap;

@@ -2003,6 +2003,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
   uint32_t my_help_ticket = 0xffffffffu;  // (thread 0) a help ticket taken and not yet served
   bool main_empty = false;                // (thread 0) the queue of searches has run out
   for (;;) {
+#ifdef SR_LONG_COUNT
+    const long long lc_top = clock64();
+#endif
     if (tid == 0) {
       uint32_t mode = 0, val = 0;
       if (!main_empty) { val = atomicAdd(&P.longq[1], 1u); main_empty = val >= npend; }
@@ -2023,9 +2026,13 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     }
     __syncthreads();
     const uint32_t mode = uni_u32(s_mode), qv = uni_u32(s_qi);
+#ifdef SR_LONG_COUNT
+    const long long lc_take = clock64();
+    if (tid == 0) atomicAdd((unsigned long long *)(P.lctl + 4), (unsigned long long)(lc_take - lc_top));
+#endif
     if (mode == 2) break;
-    LongSlot *const slot = mode == 1 ? P.lslot + ((qv >> 4) - 1) : myslot;
-    const uint32_t part = mode == 1 ? (qv & 15u) : 0u;
+    LongSlot *const slot = mode == 1 ? P.lslot + ((qv >> 8) - 1) : myslot;
+    const uint32_t part = mode == 1 ? (qv & 255u) : 0u;
     uint32_t nparts = 1;
     // (the slot was written by another block: every access to it is an agent-scope one)
     const uint32_t li = mode == 1 ? uni_u32(ag_ld(&slot->li)) : uni_u32(P.longq[2 + qv]);
@@ -2102,9 +2109,10 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     // bin).  Big bins count their live entries (s_binlive) and are listed LONG_FIRST chunks at first; a pass found in one is
     // checked after the turn's barrier against the live entries ahead of it (exact recount) -- outside the window the bin is
     // left, as the reference leaves it, and the scan goes on behind it.  A big bin ahead of the best pass that has neither
-    // been listed to its end nor reached the limit is listed four times as far in the next turn: the result is the first
+    // been listed to its end nor reached the limit is listed further in the next turn (as far as its share of live entries says
+    // the window reaches, at most four times as far): the result is the first
     // pass inside its bin's window in key order, whatever the number of turns.
-    constexpr uint32_t LONG_FIRST = (MAX_SEARCH + 63) / 64;
+    constexpr uint32_t LONG_FIRST = MAX_SEARCH / 64;  // (whole chunks inside the window whatever is live)
     __syncthreads();  // (s_wcnt is about to be reused; s_b* of every wavefront written)
     nb = uni_u32(nb);
     const uint32_t my_cnt = (uint32_t)tid < nb ? s_bcount[tid] : 0u;
@@ -2115,7 +2123,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     if (tid == 0) { s_minpass = ~0ull; s_valid = ~0ull; }
     bool split_tried = mode == 1 || P.lslot == nullptr || P.long_split == 0, aborted = false;
 #ifdef SR_LONG_COUNT
-    unsigned long long lc_chunks = 0, lc_live = 0, lc_cmp = 0, lc_busy = 0, lc_turns = 0;
+    unsigned long long lc_chunks = 0, lc_live = 0, lc_cmp = 0, lc_busy = 0, lc_turns = 0, lc_listed = 0, lc_notok = 0, lc_okp = 0;
     long long lc_q[5] = {0, 0, 0, 0, 0};
 #endif
     for (;;) {
@@ -2129,7 +2137,27 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       uint32_t my_tgt = my_nch;
       if (my_big) {
         if (live_prev >= (uint32_t)MAX_SEARCH) my_tgt = my_done;
-        else { const uint32_t far = my_done * 4u > LONG_FIRST ? my_done * 4u : LONG_FIRST; my_tgt = far < my_nch ? far : my_nch; }
+        else {
+          // How far a big bin is listed.  The reads that pass but lie beyond the window are never taken through this bin, so
+          // they pile up right behind it while the window itself is emptied: a chunk that straddles or overshoots the window's
+          // end nearly always holds a pass, and a pass outside the window costs a turn of its own (the bin is left, everything
+          // behind it is listed again -- 30 to 90 such turns in the longest searches when a bin was simply listed four times
+          // as far, r04_genomic.txt).  So: (1) the chunks that cannot reach past the window even if every entry is live
+          // ((MAX - live) / 64 of them; at first floor(1000 / 64) = 15), whose passes need no check; (2) when that is none,
+          // ONE chunk, which the wavefront that compares it clips at the window exactly (it knows the live entries ahead:
+          // live so far + its own lanes); (3) only where the share of live entries says the window is still far, a jump
+          // of 7/8 of the estimated distance (at most three times what is done) -- the one case left for the check below.
+          uint32_t far = LONG_FIRST;
+          if (my_done) {
+            const uint32_t room = (uint32_t)MAX_SEARCH - live_prev;
+            uint32_t ext = room / 64u ? room / 64u : 1u;
+            unsigned long long est = live_prev ? ((unsigned long long)room * my_done + live_prev - 1) / live_prev : 3ull * my_done;
+            if (est > 3ull * my_done) est = 3ull * my_done;
+            if (est >= 2ull * ext + 4ull) { const uint32_t jump = (uint32_t)(est - est / 8 - 1); if (jump > ext) ext = jump; }
+            far = my_done + ext;
+          }
+          my_tgt = far < my_nch ? far : my_nch;
+        }
       }
       if (my_tgt < my_done) my_tgt = my_done;
       const uint32_t nch = my_tgt - my_done;
@@ -2145,6 +2173,9 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       if (tid == 0) s_ticket = 0;
       __syncthreads();
       if (total == 0) break;
+#ifdef SR_LONG_COUNT
+      lc_listed += total;
+#endif
       if (nparts > 1 && uni_u32(__hip_atomic_load(&slot->bestpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < part) {
         aborted = true;  // a part ahead of this one has a pass inside its window: nothing here can win
         break;
@@ -2153,15 +2184,21 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         split_tried = true;
         if (total >= LONG_SPLIT_MIN) {
           if (tid == 0) s_ctl = __hip_atomic_load(&myslot->nparts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;  // (the last split of this block is over)
-          if (tid <= LONG_MAX_PARTS) s_blo[tid] = tid == 0 ? 0u : nb;
           __syncthreads();
           if (uni_u32(s_ctl)) {
             uint32_t np = total / LONG_SPLIT_PART;
             if (np > (uint32_t)LONG_MAX_PARTS) np = LONG_MAX_PARTS;
-            // part p starts at the first bin with p / np of the listed chunks ahead of it
-            if ((uint32_t)tid < nb)
-              for (uint32_t pp = 1; pp < np; pp++)
-                if (s_bchunk0[tid] >= (uint32_t)((unsigned long long)pp * total / np)) atomicMin(&s_blo[pp], (uint32_t)tid);
+            // part p starts at the first bin with p / np of the listed chunks ahead of it (thread p looks it up)
+            if ((uint32_t)tid <= np) {
+              uint32_t first = (uint32_t)tid == np ? nb : 0u;
+              if (tid > 0 && (uint32_t)tid < np) {
+                const uint32_t thr = (uint32_t)((unsigned long long)tid * total / np);
+                uint32_t lo2 = 0, hi2 = nb;  // first b in [0, nb] with chunk0[b] >= thr (chunk0 does not decrease)
+                while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (s_bchunk0[mid] >= thr) hi2 = mid; else lo2 = mid + 1; }
+                first = lo2;
+              }
+              s_blo[tid] = first;
+            }
             if ((uint32_t)tid < nb) { ag_st(&myslot->bstart[tid], s_bstart[tid]); ag_st(&myslot->bcount[tid], s_bcount[tid]); ag_st(&myslot->bcode[tid], s_bcode[tid]); }
             __syncthreads();
             if ((uint32_t)tid <= np) ag_st(&myslot->blo[tid], (uint32_t)tid == np ? nb : s_blo[tid]);
@@ -2178,7 +2215,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
                 ag_st(&myslot->nparts, np);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (uint32_t pp = 1; pp < np; pp++)
-                  __hip_atomic_store(&P.ltask[base + pp - 1], ((blockIdx.x + 1u) << 4) | pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(&P.ltask[base + pp - 1], ((blockIdx.x + 1u) << 8) | pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 okp = np;
                 atomicAdd(&P.lctl[3], 1u);
               }
@@ -2228,6 +2265,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         // A: id and signature of every entry of the chunks
         uint32_t kb[LONG_NCH], kq[LONG_NCH], rk[LONG_NCH], kdead[LONG_NCH];
         bool kbig[LONG_NCH], has[LONG_NCH];
+        uint32_t kclip[LONG_NCH];  // live entries of the bin ahead of this chunk when it is to be clipped at the window, else ~0
         int kcode[LONG_NCH];
         ulonglong2 sgk[LONG_NCH];
         {
@@ -2242,6 +2280,10 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
             kcode[k] = uni_i32((int)s_bcode[bb]);
             const uint32_t cnt = uni_u32(s_bcount[bb]), st0 = uni_u32(s_bstart[bb]);
             kbig[k] = cnt > (uint32_t)MAX_SEARCH;
+            // a big bin listed with a single chunk: the chunk is clipped at the window (the live entries so far are exact,
+            // nobody else adds to them in this turn)
+            kclip[k] = 0xffffffffu;
+            if (kv && kbig[k] && (bb + 1 < nb ? uni_u32(s_bchunk0[bb + 1]) : total) - uni_u32(s_bchunk0[bb]) == 1u) kclip[k] = uni_u32(s_binlive[bb]);
             const long long j = (long long)cnt - 1 - ((long long)kq[k] * 64 + lane);
             has[k] = kv && j >= 0;
             rk[k] = 0; sgk[k] = make_ulonglong2(0, 0); kdead[k] = 0;
@@ -2284,8 +2326,10 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
 #pragma unroll
         for (int k = 0; k < LONG_NCH; k++) {
           const bool lv = !((tw[k] >> (rk[k] & 63)) & 1ull);
-          const bool sv = lv && sp[k];
-          const uint64_t Lm = __ballot(lv), Sm = __ballot(sv);
+          const uint64_t Lm = __ballot(lv);
+          bool sv = lv && sp[k];
+          if (kclip[k] != 0xffffffffu && kclip[k] + (uint32_t)__popcll(Lm & ((1ull << lane) - 1)) >= (uint32_t)MAX_SEARCH) sv = false;  // outside the window
+          const uint64_t Sm = __ballot(sv);
 #ifdef SR_LONG_COUNT
           lc_chunks += has[k] ? 1 : 0; lc_live += __popcll(Lm);
 #endif
@@ -2373,10 +2417,20 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           if (wsum) atomicAdd(&s_ctl, lane == 0 ? wsum : 0u);
           __syncthreads();
           ok = uni_u32(s_ctl) < (uint32_t)MAX_SEARCH;
+#ifdef SR_LONG_COUNT
+          if (!ok && tid == 0) {  // what a pass outside the window looks like: live entries ahead, chunk, bin size, chunks done before this turn
+            unsigned long long *nk = (unsigned long long *)(P.lctl + 8) + 120;
+            atomicAdd(nk, 1ull); atomicAdd(nk + 1, (unsigned long long)s_ctl); atomicAdd(nk + 2, (unsigned long long)cq); atomicAdd(nk + 3, (unsigned long long)cnt);
+            atomicAdd(nk + 4, (unsigned long long)s_bdone[cb]); atomicAdd(nk + 5, (unsigned long long)s_binlive[cb]);
+          }
+#endif
         }
       }
       __syncthreads();
       // the lists of the next turn
+#ifdef SR_LONG_COUNT
+      if (fresh) { if (ok) lc_okp++; else lc_notok++; }
+#endif
       if (!fresh) {
         s_bdone[tid] = my_tgt;  // nothing stopped early: every listed chunk was compared
       } else if (ok) {
@@ -2414,7 +2468,19 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         s_ctl = atomicAdd(&slot->done, 1u) == nparts - 1;
       }
       __syncthreads();
-      if (!uni_u32(s_ctl)) { __syncthreads(); continue; }
+      if (!uni_u32(s_ctl)) {
+#ifdef SR_LONG_COUNT
+        if (tid == 0) {
+          const unsigned long long dt = (unsigned long long)(clock64() - lc_take);
+          atomicAdd((unsigned long long *)(P.lctl + 6), dt);
+          int b = 63 - __clzll(dt | 1ull) - 10; b = b < 0 ? 0 : b > 15 ? 15 : b;
+          unsigned long long *hsp = (unsigned long long *)(P.lctl + 8) + 8 * b;
+          atomicAdd(hsp, 1ull); atomicAdd(hsp + 1, lc_turns); atomicAdd(hsp + 2, lc_listed); atomicAdd(hsp + 3, dt); atomicAdd(hsp + 4, lc_notok); atomicAdd(hsp + 5, lc_okp);
+        }
+#endif
+        __syncthreads();
+        continue;
+      }
       if (tid == 0) {
         unsigned long long key = ~0ull;
         uint32_t cap = 0;
@@ -2488,6 +2554,15 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         if (P.lctl) atomicAdd(&P.lctl[2], 1u);  // one more search of the round finished
       }
     }
+#ifdef SR_LONG_COUNT
+    if (tid == 0) {
+      const unsigned long long dt = (unsigned long long)(clock64() - lc_take);
+      atomicAdd((unsigned long long *)(P.lctl + 6), dt);
+      int b = 63 - __clzll(dt | 1ull) - 10; b = b < 0 ? 0 : b > 15 ? 15 : b;
+      unsigned long long *hsp = (unsigned long long *)(P.lctl + 8) + 8 * b;
+      atomicAdd(hsp, 1ull); atomicAdd(hsp + 1, lc_turns); atomicAdd(hsp + 2, lc_listed); atomicAdd(hsp + 3, dt); atomicAdd(hsp + 4, lc_notok); atomicAdd(hsp + 5, lc_okp);
+    }
+#endif
     __syncthreads();  // the LDS state belongs to the next chain of this block
   }
 }

@@ -1458,10 +1458,10 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
       DMALLOC(P.longq, ((size_t)K + 2) * 4);
       HIPCHK(hipMemsetAsync(P.longq, 0, 8, st));
       P.ltask_cap = K;
-      DMALLOC(P.lctl, 4 * 4);
+      DMALLOC(P.lctl, 264 * 4);  // ([4..135]: instrumentation builds)
       DMALLOC(P.ltask, (size_t)K * 4);
       DMALLOC(P.lslot, (size_t)P.long_blocks * sizeof(LongSlot));
-      HIPCHK(hipMemsetAsync(P.lctl, 0, 4 * 4, st));
+      HIPCHK(hipMemsetAsync(P.lctl, 0, 264 * 4, st));
       HIPCHK(hipMemsetAsync(P.ltask, 0, (size_t)K * 4, st));
       HIPCHK(hipMemsetAsync(P.lslot, 0, (size_t)P.long_blocks * sizeof(LongSlot), st));
       for (int l = 0; l < 2; l++) {  // ... and the signatures k_long rejects most bin entries from (16 bytes per dictionary entry)
@@ -1999,6 +1999,20 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
     uint32_t ns = 0;  // (k_mg_mark zeroes [0..2] every round, [3] counts the run's splits)
     HIPCHK(hipMemcpy(&ns, P.lctl + 3, 4, hipMemcpyDeviceToHost));
     s.long_splits = ns;
+#ifdef SR_LONG_COUNT
+    {  // clocks the blocks of k_long spent waiting for help tasks / between taking a search and finishing it
+      unsigned long long w[2] = {0, 0};
+      HIPCHK(hipMemcpy(w, P.lctl + 4, 16, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[k_long] idle clocks %llu, search clocks (take to proposal, all blocks) %llu\n", w[0], w[1]);
+      unsigned long long hs[128];  // per log2(clocks) bucket: searches or parts, turns, chunks listed, clocks, passes outside the window, passes inside
+      HIPCHK(hipMemcpy(hs, P.lctl + 8, sizeof(hs), hipMemcpyDeviceToHost));
+      if (hs[120]) fprintf(stderr, "[k_long] passes outside the window: %llu; on average %.0f live entries ahead, chunk %.1f, bin of %.0f entries, %.1f chunks done before the turn, %.0f live counted\n",
+                           hs[120], (double)hs[121] / hs[120], (double)hs[122] / hs[120], (double)hs[123] / hs[120], (double)hs[124] / hs[120], (double)hs[125] / hs[120]);
+      for (int b = 0; b < 15; b++)
+        if (hs[8 * b]) fprintf(stderr, "[k_long] clocks 2^%d..: %llu scans, %.1f turns (%.2f left a bin at the window, %.2f took a pass), %.0f chunks, %.0f clocks each\n", 10 + b, hs[8 * b],
+                               (double)hs[8 * b + 1] / hs[8 * b], (double)hs[8 * b + 4] / hs[8 * b], (double)hs[8 * b + 5] / hs[8 * b], (double)hs[8 * b + 2] / hs[8 * b], (double)hs[8 * b + 3] / hs[8 * b]);
+    }
+#endif
   }
   ctx->dfree(d_off_m); ctx->dfree(d_off_s);
   // the append-order buffers are no longer needed
