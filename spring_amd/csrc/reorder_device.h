@@ -106,6 +106,10 @@ constexpr int LONG_MAX_BINS = 1024;  // one bin per probe code of a search (k_lo
 constexpr int LONG_MAX_PARTS = 64;
 // A long search whose bins hold far more entries than the average one is split into parts (ranges of its bins in priority
 // order) that blocks without a search of their own take over: the block that ran the probes publishes the bin list here.
+// EXPERIMENT, off by default (opts.long_split): bit-exact on every test pool and on the 20 M genome-like pool, but at 100 M
+// reads -- a quarter of a million splits per run -- one run in a few came back with a few reads placed differently (and
+// once did not come back within its time limit).  Neither agent-scope accesses nor uncached memory for these structures
+// removed it; with the passes outside the window gone (k_long, "how far a big bin is listed") it buys 2-4 % there.
 struct LongSlot {
   uint32_t li, nb, nparts, done, best_single, bestrid, bestpart, pad;
   uint32_t blo[LONG_MAX_PARTS + 1];          // part p scans bins [blo[p], blo[p + 1])

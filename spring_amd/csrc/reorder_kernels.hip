@@ -2015,6 +2015,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         for (;;) {
           if (my_help_ticket < P.ltask_cap) {
             const uint32_t t = __hip_atomic_load(&P.ltask[my_help_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0xffffffffu) { my_help_ticket = atomicAdd(&P.lctl[0], 1u); continue; }  // (a reserved task that was not pushed)
             if (t) { mode = 1; val = t; my_help_ticket = 0xffffffffu; break; }
           }
           // (every search finished: all help tasks have been served, none will come for this ticket)
@@ -2218,6 +2219,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
                   __hip_atomic_store(&P.ltask[base + pp - 1], ((blockIdx.x + 1u) << 8) | pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 okp = np;
                 atomicAdd(&P.lctl[3], 1u);
+              } else {
+                // no room for the tasks: the indices that were reserved must not stay empty -- a block that holds the ticket of
+                // an empty task waits for it until the round's searches are done, and with every block waiting nothing is
+                // (opts.long_split = 64 at 100 M reads: 160 000 tasks per round, K = 131 072 of them fit)
+                for (uint32_t i = base; i < base + np - 1 && i < P.ltask_cap; i++)
+                  __hip_atomic_store(&P.ltask[i], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
               s_ctl = okp;
             }
@@ -2630,7 +2637,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
   if (cid == 0 && P.longq) { P.longq[0] = 0; P.longq[1] = 0; }  // this round's long searches are done (k_long ran before this kernel)
   if (P.longq && cid < 3) P.lctl[cid] = 0;
-  if (P.longq && cid < P.ltask_cap) P.ltask[cid] = 0;  // (K entries: half a megabyte per round on the pools that have a queue)
+  if (P.longq && P.long_split && cid < P.ltask_cap) P.ltask[cid] = 0;  // (K entries: half a megabyte per round on the pools that have a queue)
   if (P.ord) {  // class lists of this block's chains (k_round_mc): class 0 first, no atomics
     static_assert(MARK_BLOCK == 256, "k_mg_mark runs 256 chains per block");
     __shared__ uint32_t s_wc[4][4];  // [wave][class]

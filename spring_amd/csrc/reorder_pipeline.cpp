@@ -127,6 +127,8 @@ struct spring_reorder_ctx {
   hipStream_t st = nullptr;
   int stage = ST_CREATED;
   std::vector<void *> allocs;
+  void *uc_mem = nullptr;   // uncached device memory (k_long's queues and slots: what blocks of one launch tell each other)
+  size_t uc_bytes = 0;
   uint64_t dev_bytes = 0, peak_bytes = 0;
   // input
   uint8_t *d_dna = nullptr;  // record stream (owned unless borrowed)
@@ -378,6 +380,7 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
   for (void *p : ctx->allocs) pool_free(ctx->dev, p);
+  if (ctx->uc_mem) (void)hipFree(ctx->uc_mem);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
@@ -1360,7 +1363,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   P.long_min = P.long_budget < 8 ? 0 : 2048;
   if (o.long_min > 0) P.long_min = o.long_min;
   if (o.long_blocks > 0) P.long_blocks = o.long_blocks;
-  P.long_split = o.long_split > 0 ? o.long_split : o.long_split < 0 ? 0 : 128;
+  P.long_split = o.long_split > 0 ? o.long_split : 0;  // (off by default: see the note at LongSlot)
   P.longq = nullptr;
   P.lctl = nullptr; P.ltask = nullptr; P.lslot = nullptr; P.ltask_cap = 0;
   P.sig[0] = P.sig[1] = nullptr;
@@ -1458,12 +1461,24 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
       DMALLOC(P.longq, ((size_t)K + 2) * 4);
       HIPCHK(hipMemsetAsync(P.longq, 0, 8, st));
       P.ltask_cap = K;
-      DMALLOC(P.lctl, 264 * 4);  // ([4..135]: instrumentation builds)
-      DMALLOC(P.ltask, (size_t)K * 4);
-      DMALLOC(P.lslot, (size_t)P.long_blocks * sizeof(LongSlot));
-      HIPCHK(hipMemsetAsync(P.lctl, 0, 264 * 4, st));
-      HIPCHK(hipMemsetAsync(P.ltask, 0, (size_t)K * 4, st));
-      HIPCHK(hipMemsetAsync(P.lslot, 0, (size_t)P.long_blocks * sizeof(LongSlot), st));
+      // The blocks of one k_long launch hand each other work through these (help tasks, the bin list of a split search, the
+      // parts' results).  The XCDs have an L2 each and ordinary device memory is cached there: a block on another XCD may be
+      // served a stale line whatever the writer's stores said (agent-scope stores and loads alone gave a wrong result once
+      // in a few runs at 250 000 splits per run, and fences write back / invalidate a whole L2 each time).  So this
+      // memory is allocated UNCACHED: every access goes to the memory side, coherent by construction.
+      const size_t b_ctl = 264 * 4 /* ([4..]: instrumentation builds) */, b_task = ((size_t)K * 4 + 255) & ~(size_t)255;
+      const size_t b_need = 2048 + b_task + (size_t)P.long_blocks * sizeof(LongSlot);
+      if (ctx->uc_bytes < b_need) {
+        if (ctx->uc_mem) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(ctx->uc_mem); ctx->uc_mem = nullptr; ctx->uc_bytes = 0; }
+        HIPCHK(hipExtMallocWithFlags(&ctx->uc_mem, b_need, hipDeviceMallocUncached));
+        ctx->uc_bytes = b_need;
+      }
+      static_assert(264 * 4 <= 2048 && alignof(LongSlot) <= 256, "layout of the uncached block");
+      (void)b_ctl;
+      P.lctl = (uint32_t *)ctx->uc_mem;
+      P.ltask = (uint32_t *)((char *)ctx->uc_mem + 2048);
+      P.lslot = (LongSlot *)((char *)ctx->uc_mem + 2048 + b_task);
+      HIPCHK(hipMemsetAsync(ctx->uc_mem, 0, b_need, st));
       for (int l = 0; l < 2; l++) {  // ... and the signatures k_long rejects most bin entries from (16 bytes per dictionary entry)
         ulonglong2 *sg = nullptr;
         const uint64_t m = ctx->dict[l].numreads;

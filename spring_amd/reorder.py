@@ -46,7 +46,7 @@ class ReorderOpts:
     long_min: int = 0
     long_blocks: int = 0
     entry_flags: int = 0      # -1: deep-bin scans ask the taken bitmap instead of reading the flag in the bin entry (A/B)
-    long_split: int = 0       # k_long: chunks of 64 bin entries per part of a split search (0 = default 128, -1 = never split)
+    long_split: int = 0       # k_long, experiment (0 = off): chunks of 64 bin entries per part of a split search
     debug: bool = False       # stage timings on stderr
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
 
