@@ -1990,9 +1990,8 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
   const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
   // the blocks take the queued searches as they become free (a ticket counter, longq[1]): searches differ in length by two
   // orders of magnitude and a launch lasts as long as its most loaded block
-  // A search far longer than the average one would keep its block busy long after the others have run out of work (100 M
-  // genome-like reads: 2 600 searches of 80 us on average per launch, the longest > 1 ms; the launch lasted 2.1 ms on 256
-  // blocks).  Such a search is SPLIT: the block that ran its probes publishes the bin list (LongSlot) and pushes help tasks,
+  // EXPERIMENT (opts.long_split, off by default -- see LongSlot in reorder_device.h for why).  A search far longer than the
+  // average one keeps its block busy after the others have run out of work.  Such a search can be SPLIT: the block that ran its probes publishes the bin list (LongSlot) and pushes help tasks,
   // one per part = range of bins in priority order; a block that finds the queue empty takes help tickets (ltask[], served in
   // order) until every search of the round is finished (lctl[2]).  A part is an ordinary scan of its bins; the part that
   // finishes last combines: the lowest part with a pass wins.
@@ -2110,9 +2109,8 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     // bin).  Big bins count their live entries (s_binlive) and are listed LONG_FIRST chunks at first; a pass found in one is
     // checked after the turn's barrier against the live entries ahead of it (exact recount) -- outside the window the bin is
     // left, as the reference leaves it, and the scan goes on behind it.  A big bin ahead of the best pass that has neither
-    // been listed to its end nor reached the limit is listed further in the next turn (as far as its share of live entries says
-    // the window reaches, at most four times as far): the result is the first
-    // pass inside its bin's window in key order, whatever the number of turns.
+    // been listed to its end nor reached the limit is listed further in the next turn (how far: at the targets below): the
+    // result is the first pass inside its bin's window in key order, whatever the number of turns.
     constexpr uint32_t LONG_FIRST = MAX_SEARCH / 64;  // (whole chunks inside the window whatever is live)
     __syncthreads();  // (s_wcnt is about to be reused; s_b* of every wavefront written)
     nb = uni_u32(nb);
