@@ -86,6 +86,8 @@ typedef struct {
                              legal, but not the specified -- result: an unresolved race, hence not the default */
   int32_t entry_flags;    /* deep-bin pools: -1 = the bin entries do not carry their read's taken bit (the scans ask the bitmap, as
                              before round 4); 0 = they do.  Same results either way */
+  int32_t out_writers;    /* spring_reorder_run: threads that write the output files (each file belongs to one of them);
+                             0 = a quarter of the host's hardware threads, at least 4, at most 24 */
 } spring_reorder_opts;
 
 typedef struct {

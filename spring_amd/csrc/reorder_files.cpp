@@ -5,6 +5,7 @@
 // encoder_main<>, encoder.h:580-593) so the rest of the SPRING pipeline
 // consumes the GPU stage's output unchanged.  Also the C++ mirror of the
 // reference's operator interface (call_reorder.h).
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 #include <atomic>
@@ -23,6 +24,7 @@
 
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -171,27 +173,35 @@ struct FilePair {
   }
 };
 
-// ---- output: the streams go device -> pinned chunk -> file, one writer thread per tid (at most 16), so that the
-// copies of the next stream run while the previous ones are still being framed, checksummed and written
-// (the "copy done" event of a chunk is made per copy, under the device whose stream records it -- an event belongs to the
-// device that was current when it was created, and the chunks of this ring serve every rank of a multi-GPU call -- and
+// ---- output: the streams go device -> pinned slot -> file.  Every output file belongs to one writer thread (its
+// slots are written in order, straight from the pinned memory with write / writev: no stdio copy); the files are dealt
+// out over the writers largest first, and the submitting thread hands out the slots ROUND ROBIN over the writers, so
+// that all of them work from the first copy on (round 4 submitted tid by tid: the first writer's backlog held most of
+// the ring while the others waited -- 8.3 GB/s for 5.45 GB; profiles/r05_files.txt).
+// (the "copy done" event of a slot is made per copy, under the device whose stream records it -- an event belongs to the
+// device that was current when it was created, and the slots of this ring serve every rank of a multi-GPU call -- and
 // is destroyed by the writer thread once it has waited for it)
+constexpr size_t OUT_SLOT = (size_t)8 << 20;                 // bytes per slot
+constexpr int SLOTS_PER_CHUNK = (int)(sr::PIN_CHUNK / OUT_SLOT);
 struct Slot { void *pin = nullptr; hipEvent_t ev = nullptr; };
-class Ring {  // a bounded set of pinned chunks
+class Ring {  // a bounded set of pinned slots, cut from the library's cached pinned chunks
  public:
-  explicit Ring(int n) : cap_(n) {}
-  ~Ring() { for (auto &s : all_) sr::pinned_put(s.pin); }
+  explicit Ring(int nchunks) : cap_(nchunks) {}
+  ~Ring() { for (void *c : chunks_) sr::pinned_put(c); }
   bool acquire(Slot *out) {
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
       if (!free_.empty()) { *out = free_.back(); free_.pop_back(); return true; }
-      if ((int)all_.size() < cap_) {
-        Slot s;
-        s.pin = sr::pinned_get();
-        if (!s.pin) return false;
-        all_.push_back(s);
-        *out = s;
-        return true;
+      if ((int)chunks_.size() < cap_) {
+        void *c = sr::pinned_get();
+        if (!c) return false;
+        chunks_.push_back(c);
+        for (int i = SLOTS_PER_CHUNK - 1; i >= 0; i--) {
+          Slot s;
+          s.pin = (uint8_t *)c + (size_t)i * OUT_SLOT;
+          free_.push_back(s);
+        }
+        continue;
       }
       cv_.wait(lk);
     }
@@ -205,7 +215,8 @@ class Ring {  // a bounded set of pinned chunks
   int cap_;
   std::mutex mu_;
   std::condition_variable cv_;
-  std::vector<Slot> all_, free_;
+  std::vector<void *> chunks_;
+  std::vector<Slot> free_;
 };
 
 struct Msg {
@@ -237,16 +248,40 @@ class Writer {
   void bad(const char *what, const std::string &path) {
     if (!rc) { rc = SPRING_REORDER_E_IO; err = std::string(what) + " " + path + ": " + strerror(errno); }
   }
+  void put_iov(struct iovec *iov, int cnt) {  // all of it, whatever the kernel takes per call
+    while (cnt > 0) {
+      const ssize_t w = writev(fd_, iov, cnt);
+      if (w < 0 && errno == EINTR) continue;
+      if (w < 0) { bad("short write to", path_); return; }
+      size_t left = (size_t)w;
+      while (cnt > 0 && left >= iov->iov_len) { left -= iov->iov_len; iov++; cnt--; }
+      if (cnt > 0) { iov->iov_base = (uint8_t *)iov->iov_base + left; iov->iov_len -= left; }
+    }
+  }
   void put(const uint8_t *p, size_t n) {
-    if (!f_ || rc) return;
-    if (!gz_) { if (n && fwrite(p, 1, n, f_) != n) bad("short write to", path_); return; }
+    if (fd_ < 0 || rc || !n) return;
+    if (!gz_) {
+      struct iovec v = {(void *)p, n};
+      put_iov(&v, 1);
+      return;
+    }
     crc_ = crc32_update(crc_, p, n);
     isize_ += n;
-    while (n) {  // stored deflate blocks, none of them final: the final (empty) one is written when the stream closes
-      const size_t blk = n > 65535 ? 65535 : n;
-      const uint8_t bh[5] = {0, (uint8_t)(blk & 0xff), (uint8_t)(blk >> 8), (uint8_t)(~blk & 0xff), (uint8_t)((~blk >> 8) & 0xff)};
-      if (fwrite(bh, 1, 5, f_) != 5 || fwrite(p, 1, blk, f_) != blk) { bad("short write to", path_); return; }
-      p += blk; n -= blk;
+    // stored deflate blocks, none of them final: the final (empty) one is written when the stream closes
+    constexpr int MAXB = 256;
+    uint8_t bh[MAXB][5];
+    struct iovec iov[2 * MAXB];
+    while (n && !rc) {
+      int nb = 0;
+      while (n && nb < MAXB) {
+        const size_t blk = n > 65535 ? 65535 : n;
+        bh[nb][0] = 0; bh[nb][1] = (uint8_t)(blk & 0xff); bh[nb][2] = (uint8_t)(blk >> 8);
+        bh[nb][3] = (uint8_t)(~blk & 0xff); bh[nb][4] = (uint8_t)((~blk >> 8) & 0xff);
+        iov[2 * nb] = {bh[nb], 5};
+        iov[2 * nb + 1] = {(void *)p, blk};
+        p += blk; n -= blk; nb++;
+      }
+      put_iov(iov, 2 * nb);
     }
   }
   void run() {
@@ -259,15 +294,15 @@ class Writer {
         q_.pop_front();
       }
       switch (m.kind) {
-        case Msg::STOP: if (f_) fclose(f_); return;
+        case Msg::STOP: if (fd_ >= 0) close(fd_); return;
         case Msg::OPEN_RAW: case Msg::OPEN_GZ: {
           path_ = m.path; gz_ = m.kind == Msg::OPEN_GZ; crc_ = 0xFFFFFFFFu; isize_ = 0;
-          f_ = rc ? nullptr : fopen(path_.c_str(), "wb");
-          if (!f_ && !rc) bad("cannot open for writing", path_);
-          if (f_) setvbuf(f_, nullptr, _IOFBF, 1 << 20);
-          if (f_ && gz_) {
-            const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255};
-            if (fwrite(hdr, 1, 10, f_) != 10) bad("short write to", path_);
+          fd_ = rc ? -1 : open(path_.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+          if (fd_ < 0 && !rc) bad("cannot open for writing", path_);
+          if (fd_ >= 0 && gz_) {
+            uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 255};
+            struct iovec v = {hdr, 10};
+            put_iov(&v, 1);
           }
           break;
         }
@@ -279,15 +314,15 @@ class Writer {
           break;
         case Msg::BYTES: put(m.bytes.data(), m.bytes.size()); break;
         case Msg::CLOSE:
-          if (f_ && gz_ && !rc) {
-            const uint8_t fin[5] = {1, 0, 0, 0xff, 0xff};  // final stored block, empty
+          if (fd_ >= 0 && gz_ && !rc) {
+            uint8_t fin[13] = {1, 0, 0, 0xff, 0xff};  // final stored block, empty; then CRC-32 and ISIZE
             const uint32_t crc = crc_ ^ 0xFFFFFFFFu, isz = (uint32_t)isize_;
-            uint8_t tr[8];
-            memcpy(tr, &crc, 4); memcpy(tr + 4, &isz, 4);
-            if (fwrite(fin, 1, 5, f_) != 5 || fwrite(tr, 1, 8, f_) != 8) bad("short write to", path_);
+            memcpy(fin + 5, &crc, 4); memcpy(fin + 9, &isz, 4);
+            struct iovec v = {fin, 13};
+            put_iov(&v, 1);
           }
-          if (f_ && fclose(f_) != 0) bad("close failed for", path_);
-          f_ = nullptr;
+          if (fd_ >= 0 && close(fd_) != 0) bad("close failed for", path_);
+          fd_ = -1;
           break;
       }
     }
@@ -297,47 +332,106 @@ class Writer {
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<Msg> q_;
-  FILE *f_ = nullptr;
+  int fd_ = -1;
   bool gz_ = false;
   uint32_t crc_ = 0;
   uint64_t isize_ = 0;
   std::string path_;
 };
 
-void w_open(Writer &w, const std::string &path, bool gz) {
+// One output file: bytes of one or more device ranges (rank by rank), or a few host bytes
+struct OutSeg { int dev; hipStream_t st; const uint8_t *d; size_t n; };
+struct OutFile {
+  std::string path;
+  bool gz = false;
+  std::vector<OutSeg> segs;
+  std::vector<uint8_t> bytes;
+  size_t total() const { size_t t = bytes.size(); for (const OutSeg &s : segs) t += s.n; return t; }
+};
+// the next slot of device bytes of file f (cursor: segment si, offset so) -> writer w.  0, or a failure code
+int w_next_slot(Writer &w, Ring &ring, const OutFile &f, size_t &si, size_t &so) {
+  while (si < f.segs.size() && so >= f.segs[si].n) { si++; so = 0; }
+  if (si >= f.segs.size()) return 0;
+  const OutSeg &s = f.segs[si];
+  const size_t len = std::min(OUT_SLOT, s.n - so);
+  if (hipSetDevice(s.dev) != hipSuccess) return fail(SPRING_REORDER_E_HIP, "hipSetDevice(%d) failed", s.dev);
   Msg m;
-  m.kind = gz ? Msg::OPEN_GZ : Msg::OPEN_RAW;
-  m.path = path;
-  w.push(std::move(m));
-}
-void w_close(Writer &w) {
-  Msg m;
-  m.kind = Msg::CLOSE;
-  w.push(std::move(m));
-}
-// bytes [d, d + n) of device `dev` (ordered on stream st) -> the writer's open file
-int w_device(Writer &w, Ring &ring, int dev, hipStream_t st, const void *d, size_t n) {
-  if (!n) return 0;
-  if (hipSetDevice(dev) != hipSuccess) return fail(SPRING_REORDER_E_HIP, "hipSetDevice(%d) failed", dev);
-  for (size_t off = 0; off < n; off += sr::PIN_CHUNK) {
-    const size_t len = std::min(sr::PIN_CHUNK, n - off);
-    Msg m;
-    m.kind = Msg::DATA;
-    m.len = len;
-    if (!ring.acquire(&m.slot)) return fail(SPRING_REORDER_E_HIP, "cannot pin a staging chunk for the output streams");
-    if (hipEventCreateWithFlags(&m.slot.ev, hipEventDisableTiming) != hipSuccess) {  // (device `dev` is current)
-      ring.release(m.slot);
-      return fail(SPRING_REORDER_E_HIP, "cannot create an event on device %d", dev);
-    }
-    if (hipMemcpyAsync(m.slot.pin, (const uint8_t *)d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipEventRecord(m.slot.ev, st) != hipSuccess) {
-      (void)hipStreamSynchronize(st);  // (a copy that did start must not land in a chunk handed to someone else)
-      (void)hipEventDestroy(m.slot.ev);
-      ring.release(m.slot);
-      return fail(SPRING_REORDER_E_HIP, "device to host copy of an output stream failed");
-    }
-    w.push(std::move(m));
+  m.kind = Msg::DATA;
+  m.len = len;
+  if (!ring.acquire(&m.slot)) return fail(SPRING_REORDER_E_HIP, "cannot pin a staging chunk for the output streams");
+  if (hipEventCreateWithFlags(&m.slot.ev, hipEventDisableTiming) != hipSuccess) {  // (device s.dev is current)
+    ring.release(m.slot);
+    return fail(SPRING_REORDER_E_HIP, "cannot create an event on device %d", s.dev);
   }
+  if (hipMemcpyAsync(m.slot.pin, s.d + so, len, hipMemcpyDeviceToHost, s.st) != hipSuccess ||
+      hipEventRecord(m.slot.ev, s.st) != hipSuccess) {
+    (void)hipStreamSynchronize(s.st);  // (a copy that did start must not land in a slot handed to someone else)
+    (void)hipEventDestroy(m.slot.ev);
+    ring.release(m.slot);
+    return fail(SPRING_REORDER_E_HIP, "device to host copy of an output stream failed");
+  }
+  w.push(std::move(m));
+  so += len;
+  return 0;
+}
+// every file of `files` written by `nw` writer threads
+int write_out_files(const std::vector<OutFile> &files, int nw) {
+  if (!crc_ready) crc_init();
+  nw = std::max(1, std::min(nw, (int)files.size()));
+  // files -> writers: largest first, each to the writer with the least bytes so far
+  std::vector<size_t> idx(files.size()), load((size_t)nw, 0);
+  for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return files[a].total() > files[b].total(); });
+  std::vector<std::vector<size_t>> mine((size_t)nw);
+  for (size_t i : idx) {
+    const size_t w = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+    mine[w].push_back(i);
+    load[w] += files[i].total() + 4096;
+  }
+  Ring ring(16);  // 16 x 32 MiB = 64 slots in flight at most
+  std::vector<std::unique_ptr<Writer>> W;
+  for (int i = 0; i < nw; i++) W.emplace_back(new Writer(&ring));
+  try {
+    for (auto &w : W) w->start();
+  } catch (const std::system_error &) {
+    return fail(SPRING_REORDER_E_IO, "cannot start the writer threads");
+  }
+  struct Cur { size_t fi = 0, si = 0, so = 0; bool open = false; };
+  std::vector<Cur> cur((size_t)nw);
+  int ret = 0;
+  for (bool any = true; any && !ret;) {
+    any = false;
+    for (int w = 0; w < nw && !ret; w++) {
+      Cur &c = cur[(size_t)w];
+      if (c.fi >= mine[(size_t)w].size()) continue;
+      any = true;
+      const OutFile &f = files[mine[(size_t)w][c.fi]];
+      if (!c.open) {
+        Msg m;
+        m.kind = f.gz ? Msg::OPEN_GZ : Msg::OPEN_RAW;
+        m.path = f.path;
+        W[(size_t)w]->push(std::move(m));
+        if (!f.bytes.empty()) {
+          Msg b;
+          b.kind = Msg::BYTES;
+          b.bytes = f.bytes;
+          W[(size_t)w]->push(std::move(b));
+        }
+        c.open = true; c.si = 0; c.so = 0;
+      }
+      ret = w_next_slot(*W[(size_t)w], ring, f, c.si, c.so);
+      while (c.si < f.segs.size() && c.so >= f.segs[c.si].n) { c.si++; c.so = 0; }
+      if (c.si >= f.segs.size()) {
+        Msg m;
+        m.kind = Msg::CLOSE;
+        W[(size_t)w]->push(std::move(m));
+        c.fi++; c.open = false;
+      }
+    }
+  }
+  for (auto &w : W) w->finish();
+  if (ret) return ret;
+  for (auto &w : W) if (w->rc) return fail(w->rc, "%s", w->err.c_str());
   return 0;
 }
 
@@ -492,7 +586,6 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
       for (int k = 0; k < world; k++) if (rcs[(size_t)k]) return fail(rcs[(size_t)k], "%s", errs[(size_t)k].c_str());
     }
     lap("dict + chains + final");
-    in.close_all();
 
     // ---- output: tid t of the job = every rank's tid-t segment, ranks ascending (chain c -> tid c % num_thr)
     std::vector<sr::ReorderView> v((size_t)world);
@@ -504,84 +597,86 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
       unmatched += st.unmatched;
       nsing_total += v[(size_t)k].nsing;
     }
-    if (!crc_ready) crc_init();
-    const int nw = std::min(num_thr, 16);
-    Ring ring(24);  // 24 x 32 MiB in flight at most
-    std::vector<std::unique_ptr<Writer>> W;
-    for (int i = 0; i < nw; i++) W.emplace_back(new Writer(&ring));
-    try {
-      for (auto &w : W) w->start();
-    } catch (const std::system_error &) {
-      return fail(SPRING_REORDER_E_IO, "cannot start the writer threads");
-    }
-    int ret = 0;
+    // temp.dna.<tid> / temp.dna.singleton are built on the device (reverse complement + repack), rank by rank; all
+    // of them first, so that the copies of every file can be in flight together (40 bytes per read of device memory)
+    struct EmitBufs {
+      std::vector<std::pair<spring_reorder_ctx *, uint8_t *>> v;
+      ~EmitBufs() { for (auto &e : v) sr::emit_dna_free(e.first, e.second); }  // (waits for the stream: the copies have left the buffer)
+    } emitted;
+    std::vector<OutFile> files;
     auto stream_of = [&](int t, const char *name, bool gz, size_t elem, auto ptr_of) {
-      Writer &w = *W[(size_t)(t % nw)];
-      w_open(w, base + "/" + name + "." + std::to_string(t), gz);
-      for (int k = 0; k < world && !ret; k++) {
+      OutFile f;
+      f.path = base + "/" + name + "." + std::to_string(t);
+      f.gz = gz;
+      for (int k = 0; k < world; k++) {
         const sr::ReorderView &vk = v[(size_t)k];
         const uint64_t a = vk.tid_off[t], c = vk.tid_off[t + 1] - a;
-        ret = w_device(w, ring, vk.dev, vk.st, (const uint8_t *)ptr_of(vk) + a * elem, c * elem);
+        if (c) f.segs.push_back({vk.dev, vk.st, (const uint8_t *)ptr_of(vk) + a * elem, (size_t)(c * elem)});
       }
-      w_close(w);
+      files.push_back(std::move(f));
     };
-    for (int t = 0; t < num_thr && !ret; t++) {  // all six files must exist for every tid (encoder.h:147-175)
+    for (int t = 0; t < num_thr; t++) {  // all six files must exist for every tid (encoder.h:147-175)
       stream_of(t, "read_order.bin", false, 4, [](const sr::ReorderView &x) { return (const void *)x.f_order; });
       stream_of(t, "read_rev.txt", true, 1, [](const sr::ReorderView &x) { return (const void *)x.f_rc; });
       stream_of(t, "tempflag.txt", true, 1, [](const sr::ReorderView &x) { return (const void *)x.f_flag; });
       stream_of(t, "temppos.txt", true, 8, [](const sr::ReorderView &x) { return (const void *)x.f_pos; });
       stream_of(t, "read_lengths.bin", true, 2, [](const sr::ReorderView &x) { return (const void *)x.f_len; });
-      // temp.dna.<tid>: built on the device (reverse complement + repack), rank by rank
-      Writer &w = *W[(size_t)(t % nw)];
-      w_open(w, base + "/temp.dna." + std::to_string(t), false);
-      for (int k = 0; k < world && !ret; k++) {
+      OutFile f;
+      f.path = base + "/temp.dna." + std::to_string(t);
+      for (int k = 0; k < world; k++) {
         uint8_t *d = nullptr;
         size_t nb = 0;
-        if ((ret = sr::emit_dna_device(g[(size_t)k].c, t, &d, &nb))) break;
-        ret = w_device(w, ring, v[(size_t)k].dev, v[(size_t)k].st, d, nb);
-        sr::emit_dna_free(g[(size_t)k].c, d);  // (waits for the stream: the copies above have left the buffer)
+        if ((r = sr::emit_dna_device(g[(size_t)k].c, t, &d, &nb))) return r;
+        if (d) emitted.v.push_back({g[(size_t)k].c, d});
+        if (nb) f.segs.push_back({v[(size_t)k].dev, v[(size_t)k].st, d, nb});
       }
-      w_close(w);
+      files.push_back(std::move(f));
     }
-    if (!ret) {  // reorder.h:699-728; the singleton streams are in tid order too (rank by rank inside a tid)
-      Writer &w = *W[0];
-      w_open(w, base + "/temp.dna.singleton", false);
-      for (int t = 0; t < num_thr && !ret; t++)
-        for (int k = 0; k < world && !ret; k++) {
+    {  // reorder.h:699-728; the singleton streams are in tid order too (rank by rank inside a tid)
+      OutFile fd, fo, fc;
+      fd.path = base + "/temp.dna.singleton";
+      fo.path = base + "/read_order.bin.singleton";
+      fc.path = base + "/temp.dna.singleton.count";
+      for (int t = 0; t < num_thr; t++)
+        for (int k = 0; k < world; k++) {
           const sr::ReorderView &vk = v[(size_t)k];
           const uint64_t a = vk.tid_off_s[t], c = vk.tid_off_s[t + 1] - a;
           if (!c) continue;
           uint8_t *d = nullptr;
           size_t nb = 0;
-          if ((ret = sr::emit_dna_device(g[(size_t)k].c, -1, &d, &nb, a, c))) break;
-          ret = w_device(w, ring, vk.dev, vk.st, d, nb);
-          sr::emit_dna_free(g[(size_t)k].c, d);
+          if ((r = sr::emit_dna_device(g[(size_t)k].c, -1, &d, &nb, a, c))) return r;
+          if (d) emitted.v.push_back({g[(size_t)k].c, d});
+          if (nb) fd.segs.push_back({vk.dev, vk.st, d, nb});
+          fo.segs.push_back({vk.dev, vk.st, (const uint8_t *)(vk.f_order_s + a), (size_t)c * 4});
         }
-      w_close(w);
-      Writer &w1 = *W[(size_t)(1 % nw)];
-      w_open(w1, base + "/read_order.bin.singleton", false);
-      for (int t = 0; t < num_thr && !ret; t++)
-        for (int k = 0; k < world && !ret; k++) {
-          const sr::ReorderView &vk = v[(size_t)k];
-          const uint64_t a = vk.tid_off_s[t], c = vk.tid_off_s[t + 1] - a;
-          ret = w_device(w1, ring, vk.dev, vk.st, vk.f_order_s + a, (size_t)c * 4);
-        }
-      w_close(w1);
-      w_open(w1, base + "/temp.dna.singleton.count", false);
-      Msg m;
-      m.kind = Msg::BYTES;
       const uint32_t numreads_s = (uint32_t)nsing_total;
-      m.bytes.assign((const uint8_t *)&numreads_s, (const uint8_t *)&numreads_s + 4);
-      w1.push(std::move(m));
-      w_close(w1);
+      fc.bytes.assign((const uint8_t *)&numreads_s, (const uint8_t *)&numreads_s + 4);
+      files.push_back(std::move(fd));
+      files.push_back(std::move(fo));
+      files.push_back(std::move(fc));
     }
-    for (auto &w : W) w->finish();
-    if (ret) return ret;
-    for (auto &w : W) if (w->rc) return fail(w->rc, "%s", w->err.c_str());
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nw = o.out_writers > 0 ? o.out_writers : (int)std::max(4u, std::min(24u, hw ? hw / 4 : 8u));
+    lap("emit temp.dna");
+    if ((r = write_out_files(files, nw))) return r;
+    lap("D2H + write files");
     // the stage consumes its inputs (reorder.h:232,241) -- once its outputs exist: a failed call leaves them in place
+    // Unlinking a file whose pages sit in the page cache frees them page by page (0.3 s for the 4 GB of 100 M reads on
+    // the GPU box, tools/pagecache_write_bench.c) -- at the LAST reference to the inode.  The names go now; the
+    // descriptors this call still holds are closed by a detached thread, which is where the pages are freed.
     remove((base + "/input_clean_1.dna").c_str());
     if (paired_end) remove((base + "/input_clean_2.dna").c_str());
-    lap("D2H + write files");
+    {
+      const int fd0 = in.fd[0], fd1 = in.fd[1];
+      in.fd[0] = in.fd[1] = -1;
+      try {
+        std::thread([fd0, fd1] { if (fd0 >= 0) close(fd0); if (fd1 >= 0) close(fd1); }).detach();
+      } catch (const std::system_error &) {
+        if (fd0 >= 0) close(fd0);
+        if (fd1 >= 0) close(fd1);
+      }
+    }
+    lap("unlink inputs");
     printf("Reordering done, %llu were unmatched\n", (unsigned long long)unmatched);  // reorder.h:633-635
     return 0;
   } catch (const std::bad_alloc &) {

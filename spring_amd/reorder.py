@@ -48,6 +48,7 @@ class ReorderOpts:
     entry_flags: int = 0      # -1: deep-bin scans ask the taken bitmap instead of reading the flag in the bin entry (A/B)
     long_split: int = 0       # k_long, experiment (0 = off): chunks of 64 bin entries per part of a split search
     debug: bool = False       # stage timings on stderr
+    out_writers: int = 0      # call_reorder: threads writing the output files (0 = from the host's thread count)
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
 
     def to_c(self):
@@ -69,6 +70,7 @@ class ReorderOpts:
             o.plan1[i] = int(v)
         o.long_min, o.long_blocks, o.debug = self.long_min, self.long_blocks, int(self.debug)
         o.long_split, o.entry_flags = self.long_split, self.entry_flags
+        o.out_writers = self.out_writers
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d
