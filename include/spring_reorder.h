@@ -80,10 +80,9 @@ typedef struct {
   int32_t long_min;       /* k_long: bin entries that must still be ahead of a search for it to be handed over (0 = default 2048) */
   int32_t long_blocks;    /* k_long: grid size (0 = default 512) */
   int32_t debug;          /* 1: stage / phase timings on stderr */
-  int32_t long_split;     /* k_long, EXPERIMENT (0 = off): a search with at least 4 x this many 64-entry chunks of bin entries
-                             ahead of it is split into parts that idle blocks take over.  Exact on every test pool, but at
-                             100 M genome-like reads (250 000 splits per run) one run in a few ended with a different --
-                             legal, but not the specified -- result: an unresolved race, hence not the default */
+  int32_t long_split;     /* long searches (k_long_list / k_long_scan / k_long_fin): a search whose bins hold more than this many
+                             chunks of 64 entries within reach of the first turn is cut into parts (ranges of its bins, up to 64)
+                             that are scanned by a block each; 0 = default (256), -1 = never cut.  Same results for every value */
   int32_t entry_flags;    /* deep-bin pools: -1 = the bin entries do not carry their read's taken bit (the scans ask the bitmap, as
                              before round 4); 0 = they do.  Same results either way */
   int32_t out_writers;    /* spring_reorder_run: threads that write the output files (each file belongs to one of them);

@@ -104,19 +104,16 @@ constexpr int MINZ_WL = 32;                 // ... of windows of this length onl
 
 constexpr int LONG_MAX_BINS = 1024;  // one bin per probe code of a search (k_long: one thread per probe)
 constexpr int LONG_MAX_PARTS = 64;
-// A long search whose bins hold far more entries than the average one is split into parts (ranges of its bins in priority
-// order) that blocks without a search of their own take over: the block that ran the probes publishes the bin list here.
-// EXPERIMENT, off by default (opts.long_split): bit-exact on every test pool and on the 20 M genome-like pool, but at 100 M
-// reads -- a quarter of a million splits per run -- one run in a few came back with a few reads placed differently (and
-// once did not come back within its time limit).  Neither agent-scope accesses nor uncached memory for these structures
-// removed it; with the passes outside the window gone (k_long, "how far a big bin is listed") it buys 2-4 % there.
-struct LongSlot {
-  uint32_t li, nb, nparts, done, best_single, bestrid, bestpart, pad;
-  uint32_t blo[LONG_MAX_PARTS + 1];          // part p scans bins [blo[p], blo[p + 1])
-  uint32_t capped[LONG_MAX_PARTS];
-  unsigned long long res[LONG_MAX_PARTS];    // part p's first pass inside its bin's window (key), ~0: none
-  uint32_t bstart[LONG_MAX_BINS], bcount[LONG_MAX_BINS];
-  uint16_t bcode[LONG_MAX_BINS];
+// What the three kernels of a round's long searches hand each other (k_long_list -> k_long_scan -> k_long_fin,
+// reorder_kernels.hip): one head per search of the round (index = its place in longq), its verified multi-read bins in
+// lbin / lbcode (lbin_stride entries per search), one word per part in lparts.  A search whose first turn lists more than
+// long_part chunks of 64 bin entries is cut into up to LONG_MAX_PARTS parts = ranges of its bins in priority order.
+struct LongHead {
+  uint32_t nb, nparts, best_single, bestrid;  // bins listed, parts, lowest code of a single-read bin that hit (+ its read)
+  uint32_t bestpart, pad[3];                  // lowest part with a pass so far: a hint that lets the parts behind it stop
+  uint32_t blo[LONG_MAX_PARTS + 4];           // part p scans bins [blo[p], blo[p + 1])
+  uint32_t rescode[LONG_MAX_PARTS], resrid[LONG_MAX_PARTS];  // part p's first pass inside its bin's window: probe code (0x7fffffff: none), read
+  uint32_t capped[LONG_MAX_PARTS];            // part p: a bin ahead of its pass (any bin, without one) stopped at the window
 };
 struct DevParams {
   // reads
@@ -166,13 +163,14 @@ struct DevParams {
   // one lane (tail) a wavefront of k_round spends on a search before it hands it over; 0 = never.
   // long_min: bin entries that must still be ahead of the search at that point (else the wavefront carries on).
   uint32_t *longq;
-  int long_budget, long_min, long_blocks, long_split;
-  // split long searches (k_long): lctl[0] = next help ticket, [1] = help tasks pushed, [2] = searches finished this round;
-  // ltask[i] = (slot + 1) << 8 | part of help task i (0: not pushed yet), ltask_cap entries; lslot[block] = what the parts of
-  // a split search share.  k_mg_mark zeroes lctl and ltask with the queue.
-  uint32_t *lctl, *ltask;
-  uint32_t ltask_cap;
-  struct LongSlot *lslot;
+  int long_budget, long_min, long_blocks, long_part;
+  // lctl[0] = parts listed this round, [1] = k_long_scan's ticket counter (k_mg_mark zeroes both with the queue), [3] = split
+  // searches of the run; lparts[i] = search << 6 | part
+  uint32_t *lctl, *lparts;
+  struct LongHead *lhead;
+  uint2 *lbin;          // {start, count} of a listed bin
+  uint16_t *lbcode;     // its probe code
+  uint32_t lbin_stride;
 #ifdef SR_PHASE_TIMING
   unsigned long long *dbg;  // [0..63] phase clocks / visits summed over the wavefronts that ran > 1M clocks, [64] how many
 #endif

@@ -1960,84 +1960,58 @@ __device__ __forceinline__ int sig_bound(const DevParams &P, const uint64_t *sx,
 }
 
 constexpr int LONG_WAVES = 16;
-// what the blocks of k_long tell each other goes past the caches (agent scope: the XCDs have an L2 each); no fence is
-// needed beside it -- a fence here writes back / invalidates a whole L2
+// (the abort hint of a split search, below: an agent-scope load -- the XCDs have an L2 each; a stale value only costs work)
 template <typename T> __device__ __forceinline__ T ag_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void ag_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #ifndef SR_LONG_NCH
 #define SR_LONG_NCH 2
 #endif
 constexpr int LONG_NCH = SR_LONG_NCH;  // chunks of 64 bin entries per ticket
 static_assert(2 * 64 * LONG_NCH <= STAGE_WORDS, "the packed survivors of a ticket fit the staging rows");
-__global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direct) {
+constexpr uint32_t LONG_NONE = 0x7fffffffu;
+// a part is scanned by a block of SCAN_WAVES wavefronts, one thread per bin: at most LONG_PART_BINS bins per part.  Small
+// blocks, several per CU: a part's serial phases (its header, the barriers and prefix sums of a turn) run while the
+// wavefronts of other parts stream chunks -- with one block of 16 wavefronts per CU those phases left the CU idle, and a
+// search cut into parts of 128 chunks took 2.5 s instead of 1.7 (100 M genome-like reads, profiles/r05_k_long.txt)
+constexpr int SCAN_WAVES = 4;
+constexpr int LONG_PART_BINS = 64 * SCAN_WAVES;
+
+// Round 5: three kernels instead of one.  Round 4's k_long was one launch in which a block ran a whole search -- probes,
+// then every chunk of every bin -- and a launch lasted as long as its longest search: 62 % of the blocks' time was idle on
+// genome-like pools (a few searches per launch scan 2 000-3 500 chunks, ~1 ms, while the average one takes 40 us;
+// profiles/r05_k_long.txt), and the split searches that were meant to cure it handed parts from block to block INSIDE the
+// launch through agent-scope memory: a protocol that never became reliable.  Now the hand-over IS a kernel boundary:
+//   k_long_list  one block per search: the probes (step 1 above), the verified bins written to the search's slot, the
+//                search cut into parts = ranges of bins with about P.long_part listed chunks each, one entry per part
+//                appended to the round's part list;
+//   k_long_scan  one block per part (a ticket counter over the part list): step 2 above on the part's bins -- the first
+//                pass inside its bin's window in the reference's order, or none;
+//   k_long_fin   one wavefront per search: the lowest part with a pass wins (against the best single-read bin), the
+//                proposal is written exactly as search_step writes it.
+// Everything a later kernel reads was written by an earlier one; the only thing blocks of one launch tell each other is a
+// hint -- bestpart, the lowest part of the search that has a pass so far: parts behind it stop (no result depends on it).
+
+// ---- kernel 1: probes -> bin list -> parts
+__global__ __launch_bounds__(64 * LONG_WAVES) void k_long_list(DevParams P) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[LONG_WAVES][STAGE_WORDS];
-  __shared__ uint32_t s_bstart[64 * LONG_WAVES], s_bcount[64 * LONG_WAVES];
+  __shared__ uint32_t s_bstart[64 * LONG_WAVES], s_bcount[64 * LONG_WAVES], s_bchunk0[64 * LONG_WAVES];
   __shared__ uint16_t s_bcode[64 * LONG_WAVES];
   __shared__ uint32_t s_wcnt[LONG_WAVES];
-  __shared__ uint32_t s_best, s_bestrid, s_ctl, s_win_code, s_win_rid, s_capped;
-  __shared__ uint32_t s_bchunk0[64 * LONG_WAVES];   // listed chunks ahead of bin b in this turn
-  __shared__ uint32_t s_binlive[64 * LONG_WAVES];   // live entries seen in bin b (bins of more than MAX_SEARCH entries only)
-  __shared__ uint32_t s_bdone[64 * LONG_WAVES];     // chunks of bin b that have been compared (all of them: the bin is out)
-  __shared__ unsigned long long s_ticket;           // 64 * the next listed chunk of the turn
-  __shared__ unsigned long long s_minpass;          // lowest key (bin << 32 | chunk << 6 | lane) of a passing entry ...
-  __shared__ unsigned long long s_valid;            // ... and the lowest one that has been checked against its bin's window
+  __shared__ uint32_t s_best, s_bestrid, s_qi, s_base, s_bstart_part[LONG_MAX_PARTS + 2];
+  static_assert(LONG_MAX_BINS == 64 * LONG_WAVES, "one bin per thread");
   const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
   const uint32_t npend = P.longq[0];
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   lds_u32_t *stage = (lds_u32_t *)s_stage[wave];
   const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
-  // the blocks take the queued searches as they become free (a ticket counter, longq[1]): searches differ in length by two
-  // orders of magnitude and a launch lasts as long as its most loaded block
-  // EXPERIMENT (opts.long_split, off by default -- see LongSlot in reorder_device.h for why).  A search far longer than the
-  // average one keeps its block busy after the others have run out of work.  Such a search can be SPLIT: the block that ran its probes publishes the bin list (LongSlot) and pushes help tasks,
-  // one per part = range of bins in priority order; a block that finds the queue empty takes help tickets (ltask[], served in
-  // order) until every search of the round is finished (lctl[2]).  A part is an ordinary scan of its bins; the part that
-  // finishes last combines: the lowest part with a pass wins.
-  __shared__ uint32_t s_qi, s_mode, s_blo[LONG_MAX_PARTS + 1];
-  static_assert(LONG_MAX_BINS == 64 * LONG_WAVES, "one bin per thread");
-  const uint32_t LONG_SPLIT_PART = (uint32_t)P.long_split, LONG_SPLIT_MIN = 4 * LONG_SPLIT_PART;  // listed chunks per part / to split at all
-  LongSlot *const myslot = P.lslot + blockIdx.x;
-  uint32_t my_help_ticket = 0xffffffffu;  // (thread 0) a help ticket taken and not yet served
-  bool main_empty = false;                // (thread 0) the queue of searches has run out
+  constexpr uint32_t LONG_FIRST = MAX_SEARCH / 64;  // (whole chunks inside the window whatever is live)
   for (;;) {
-#ifdef SR_LONG_COUNT
-    const long long lc_top = clock64();
-#endif
-    if (tid == 0) {
-      uint32_t mode = 0, val = 0;
-      if (!main_empty) { val = atomicAdd(&P.longq[1], 1u); main_empty = val >= npend; }
-      if (main_empty) {
-        mode = 2;
-        if (my_help_ticket == 0xffffffffu) my_help_ticket = atomicAdd(&P.lctl[0], 1u);
-        for (;;) {
-          if (my_help_ticket < P.ltask_cap) {
-            const uint32_t t = __hip_atomic_load(&P.ltask[my_help_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == 0xffffffffu) { my_help_ticket = atomicAdd(&P.lctl[0], 1u); continue; }  // (a reserved task that was not pushed)
-            if (t) { mode = 1; val = t; my_help_ticket = 0xffffffffu; break; }
-          }
-          // (every search finished: all help tasks have been served, none will come for this ticket)
-          if (__hip_atomic_load(&P.lctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= npend) break;
-          __builtin_amdgcn_s_sleep(32);
-        }
-      }
-      s_mode = mode; s_qi = val;
-    }
+    if (tid == 0) s_qi = atomicAdd(&P.longq[1], 1u);  // the searches differ in length: taken as the blocks become free
     __syncthreads();
-    const uint32_t mode = uni_u32(s_mode), qv = uni_u32(s_qi);
-#ifdef SR_LONG_COUNT
-    const long long lc_take = clock64();
-    if (tid == 0) atomicAdd((unsigned long long *)(P.lctl + 4), (unsigned long long)(lc_take - lc_top));
-#endif
-    if (mode == 2) break;
-    LongSlot *const slot = mode == 1 ? P.lslot + ((qv >> 8) - 1) : myslot;
-    const uint32_t part = mode == 1 ? (qv & 255u) : 0u;
-    uint32_t nparts = 1;
-    // (the slot was written by another block: every access to it is an agent-scope one)
-    const uint32_t li = mode == 1 ? uni_u32(ag_ld(&slot->li)) : uni_u32(P.longq[2 + qv]);
-    if (mode == 1) nparts = uni_u32(ag_ld(&slot->nparts));
-    const uint32_t cid = P.c0 + li;
+    const uint32_t qi = uni_u32(s_qi);
+    if (qi >= npend) break;
+    const uint32_t li = uni_u32(P.longq[2 + qi]);
     Chain *c = &P.chains[li];
     if (tid < LDS_LIMBS) {
       const int i = tid - LDS_PAD;
@@ -2047,7 +2021,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     }
     ChainHot h;
     load_hot(c, h);
-    if (tid == 0) { s_best = 0x7fffffffu; s_bestrid = 0; s_win_code = 0x7fffffffu; s_win_rid = 0; s_capped = 0; }
+    if (tid == 0) { s_best = LONG_NONE; s_bestrid = 0; }
     __syncthreads();
     const int ref_len = h.ref_len;
     int min_code = 0;
@@ -2055,16 +2029,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       const int pr = (int)h.prop_rev;
       if (pr & 4) min_code = ((int)h.prop_shift << 2) | ((pr & 1) << 1) | ((pr >> 1) & 1);
     }
-#ifdef SR_LONG_COUNT
-    const long long lc_t0 = clock64();
-#endif
-    uint32_t best_single = 0x7fffffffu, nb = 0, b_lo = 0, b_hi = 0;
-    if (mode == 1) {  // a part of a split search: the bins come from the slot
-      nb = uni_u32(ag_ld(&slot->nb));
-      b_lo = uni_u32(ag_ld(&slot->blo[part])); b_hi = uni_u32(ag_ld(&slot->blo[part + 1]));
-      if ((uint32_t)tid < nb) { s_bstart[tid] = ag_ld(&slot->bstart[tid]); s_bcount[tid] = ag_ld(&slot->bcount[tid]); s_bcode[tid] = ag_ld(&slot->bcode[tid]); }
-    } else {
-    // ---- 1. one thread per probe
+    // ---- one thread per probe
     const int code = tid, l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
     const bool valid = probe_valid(P, l, rev, shift, ref_len) && code >= min_code;
     bool hit = false, keyok = false, other = false;
@@ -2079,12 +2044,13 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
     }
     __syncthreads();
     if (hit && s_best == (uint32_t)code) s_bestrid = rid;  // (eval_probe left the lowest hitting code in s_best)
-    best_single = s_best;
+    const uint32_t best_single = s_best;
     // (a bin behind a single-read bin that hit can never win: it is not listed)
     const bool mine = pend.on && pend.count > 0 && (uint32_t)code < best_single;
     const uint64_t pb = __ballot(mine);
     if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(pb);
     __syncthreads();
+    uint32_t nb = 0;
     {
       uint32_t base = 0;
       for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; nb += v; }
@@ -2094,43 +2060,129 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       }
     }
     nb = uni_u32(nb);
-    b_hi = nb;
-    }
-#ifdef SR_LONG_COUNT
-    const long long lc_t1 = clock64();
-#endif
-    // ---- 2. the bins in chunks of 64 entries, in the reference's order (bins by priority code, a bin from its tail).
-    // No step-by-step hand-out any more (round 4: thread 0 folding 16 results and dealing the next 16 chunks between two
-    // block barriers was 70 % of a search's clocks).  A TURN lists a range of chunks [done, target) per bin; chunk0[b] = listed
-    // chunks ahead of bin b; a wavefront takes the next listed chunk from a ticket counter, finds its bin, compares, and
-    // publishes a passing entry with a 64-bit atomicMin on the key bin << 32 | chunk << 6 | lane; wavefronts stop taking
-    // tickets beyond the lowest key.  Keys order the entries as the reference visits them.
-    // The MAX_SEARCH_REORDER window (reorder.h:287-288) can only matter in a bin of more than that many entries (a "big"
-    // bin).  Big bins count their live entries (s_binlive) and are listed LONG_FIRST chunks at first; a pass found in one is
-    // checked after the turn's barrier against the live entries ahead of it (exact recount) -- outside the window the bin is
-    // left, as the reference leaves it, and the scan goes on behind it.  A big bin ahead of the best pass that has neither
-    // been listed to its end nor reached the limit is listed further in the next turn (how far: at the targets below): the
-    // result is the first pass inside its bin's window in key order, whatever the number of turns.
-    constexpr uint32_t LONG_FIRST = MAX_SEARCH / 64;  // (whole chunks inside the window whatever is live)
     __syncthreads();  // (s_wcnt is about to be reused; s_b* of every wavefront written)
-    nb = uni_u32(nb);
+    // ---- the chunks the first turn of a scan lists (a bin of more than MAX_SEARCH entries: LONG_FIRST of them) -> parts
+    const uint32_t my_cnt = (uint32_t)tid < nb ? s_bcount[tid] : 0u;
+    const uint32_t my_nch = (my_cnt + 63u) / 64u;
+    const uint32_t nch1 = my_cnt > (uint32_t)MAX_SEARCH ? (my_nch < LONG_FIRST ? my_nch : LONG_FIRST) : my_nch;
+    const uint32_t incl = (uint32_t)wave_incl_scan_i((int)nch1, lane);
+    if (lane == 63) s_wcnt[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; total += v; }
+    total = uni_u32(total);
+    s_bchunk0[tid] = base + incl - nch1;
+    // parts: ranges of bins of about P.long_part listed chunks and at most LONG_PART_BINS bins -- cut at equal shares of the
+    // weight chunks * LONG_PART_BINS + bins * part (a part full of either weighs part * LONG_PART_BINS); should a part still
+    // come out with too many bins (many one-chunk bins beside a few long ones), the search is cut by bin count alone
+    const uint32_t part_ch = P.long_part > 0 ? (uint32_t)P.long_part : 0x100000u;
+    const unsigned long long wtot = (unsigned long long)total * LONG_PART_BINS + (unsigned long long)nb * part_ch;
+    const unsigned long long wfull = (unsigned long long)part_ch * LONG_PART_BINS;
+    uint32_t np = nb ? (uint32_t)((wtot + wfull - 1) / wfull) : 0u;
+    if (np > (uint32_t)LONG_MAX_PARTS) np = LONG_MAX_PARTS;
+    if (nb > np * (uint32_t)LONG_PART_BINS) np = (nb + LONG_PART_BINS - 1) / LONG_PART_BINS;  // (<= 4: nb <= 1024)
+    if (tid == 0) { s_base = np ? atomicAdd(&P.lctl[0], np) : 0u; s_best = 0; }  // (s_best: "a part has too many bins")
+    __syncthreads();
+    LongHead *hd = P.lhead + qi;
+    uint32_t first = 0;
+    if ((uint32_t)tid <= np && np) {
+      // part p starts at the first bin with p / np of the weight ahead of it
+      first = (uint32_t)tid == np ? nb : 0u;
+      if (tid > 0 && (uint32_t)tid < np) {
+        const unsigned long long thr = (unsigned long long)tid * wtot / np;
+        uint32_t lo2 = 0, hi2 = nb;  // first b in [0, nb] with weight ahead >= thr (it does not decrease)
+        while (lo2 < hi2) {
+          const uint32_t mid = (lo2 + hi2) >> 1;
+          if ((unsigned long long)s_bchunk0[mid] * LONG_PART_BINS + (unsigned long long)mid * part_ch >= thr) hi2 = mid; else lo2 = mid + 1;
+        }
+        first = lo2;
+      }
+      s_bstart_part[tid] = first;
+    }
+    __syncthreads();
+    if ((uint32_t)tid < np && s_bstart_part[tid + 1] - s_bstart_part[tid] > (uint32_t)LONG_PART_BINS) s_best = 1;
+    __syncthreads();
+    if ((uint32_t)tid <= np && np) {
+      if (uni_u32(s_best)) {  // by bin count alone
+        const uint32_t npb = (nb + LONG_PART_BINS - 1) / LONG_PART_BINS;
+        first = (uint32_t)tid >= npb ? nb : (uint32_t)tid * LONG_PART_BINS;  // (parts beyond npb are empty)
+      }
+      hd->blo[tid] = first;
+      if ((uint32_t)tid < np) P.lparts[uni_u32(s_base) + (uint32_t)tid] = (qi << 6) | (uint32_t)tid;
+    }
+    if ((uint32_t)tid < nb) {
+      P.lbin[(size_t)qi * P.lbin_stride + tid] = make_uint2(s_bstart[tid], s_bcount[tid]);
+      P.lbcode[(size_t)qi * P.lbin_stride + tid] = s_bcode[tid];
+    }
+    if (tid == 0) {
+      hd->nb = nb; hd->nparts = np; hd->best_single = best_single; hd->bestrid = s_bestrid; hd->bestpart = 0xffffffffu;
+      if (np > 1) atomicAdd(&P.lctl[3], 1u);  // (the run's split searches: stats.long_splits)
+    }
+    __syncthreads();  // the LDS state belongs to the next search of this block
+  }
+}
+
+// ---- kernel 2: one part of a search = a range of its bins, in chunks of 64 entries, in the reference's order (bins by
+// priority code, a bin from its tail).  A TURN lists a range of chunks [done, target) per bin; chunk0[b] = listed chunks
+// ahead of bin b; a wavefront takes the next listed chunks from a ticket counter, finds their bin, compares, and publishes
+// a passing entry with a 64-bit atomicMin on the key bin << 32 | chunk << 6 | lane; wavefronts stop taking tickets beyond
+// the lowest key.  Keys order the entries as the reference visits them.
+// The MAX_SEARCH_REORDER window (reorder.h:287-288) can only matter in a bin of more than that many entries (a "big"
+// bin).  Big bins count their live entries (s_binlive) and are listed LONG_FIRST chunks at first; a pass found in one is
+// checked after the turn's barrier against the live entries ahead of it (exact recount) -- outside the window the bin is
+// left, as the reference leaves it, and the scan goes on behind it.  A big bin ahead of the best pass that has neither
+// been listed to its end nor reached the limit is listed further in the next turn (how far: at the targets below): the
+// result is the first pass inside its bin's window in key order, whatever the number of turns.
+__global__ __launch_bounds__(64 * SCAN_WAVES) void k_long_scan(DevParams P) {
+  __shared__ uint64_t s_refs[2][LDS_LIMBS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[SCAN_WAVES][STAGE_WORDS];
+  __shared__ uint32_t s_bstart[64 * SCAN_WAVES], s_bcount[64 * SCAN_WAVES];
+  __shared__ uint16_t s_bcode[64 * SCAN_WAVES];
+  __shared__ uint32_t s_wcnt[SCAN_WAVES];
+  __shared__ uint32_t s_ctl, s_capped, s_qi, s_hint;
+  __shared__ uint32_t s_bchunk0[64 * SCAN_WAVES];   // listed chunks ahead of bin b in this turn
+  __shared__ uint32_t s_binlive[64 * SCAN_WAVES];   // live entries seen in bin b (bins of more than MAX_SEARCH entries only)
+  __shared__ uint32_t s_bdone[64 * SCAN_WAVES];     // chunks of bin b that have been compared (all of them: the bin is out)
+  __shared__ unsigned long long s_ticket;           // 64 * the next listed chunk of the turn
+  __shared__ unsigned long long s_minpass;          // lowest key (bin << 32 | chunk << 6 | lane) of a passing entry ...
+  __shared__ unsigned long long s_valid;            // ... and the lowest one that has been checked against its bin's window
+  const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
+  const uint32_t nparts_all = P.lctl[0];
+  const int klen2 = 2 * P.wl;
+  lds_u32_t *stage = (lds_u32_t *)s_stage[wave];
+  const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
+  constexpr uint32_t LONG_FIRST = MAX_SEARCH / 64;
+  for (;;) {
+    if (tid == 0) s_qi = atomicAdd(&P.lctl[1], 1u);
+    __syncthreads();
+    const uint32_t ti = uni_u32(s_qi);
+    if (ti >= nparts_all) break;
+    const uint32_t pd = uni_u32(P.lparts[ti]), qi = pd >> 6, part = pd & 63u;
+    LongHead *hd = P.lhead + qi;
+    const uint32_t nparts = uni_u32(hd->nparts);
+    const uint32_t b_lo = uni_u32(hd->blo[part]), nb = uni_u32(hd->blo[part + 1]) - b_lo;  // this part's bins, numbered from 0
+    const uint32_t li = uni_u32(P.longq[2 + qi]);
+    const Chain *c = &P.chains[li];
+    if (tid < LDS_LIMBS) {
+      const int i = tid - LDS_PAD;
+      uint64_t r0 = 0, r1 = 0;
+      if (i >= 0 && i < P.W) { r0 = c->ref[i]; r1 = c->revref[i]; }
+      s_refs[0][tid] = r0; s_refs[1][tid] = r1;
+    }
+    const int ref_len = uni_i32(c->h.ref_len);
+    if ((uint32_t)tid < nb) {
+      const uint2 b = P.lbin[(size_t)qi * P.lbin_stride + b_lo + tid];
+      s_bstart[tid] = b.x; s_bcount[tid] = b.y; s_bcode[tid] = P.lbcode[(size_t)qi * P.lbin_stride + b_lo + tid];
+    }
+    if (tid == 0) { s_capped = 0; s_minpass = ~0ull; s_valid = ~0ull; }
+    __syncthreads();
     const uint32_t my_cnt = (uint32_t)tid < nb ? s_bcount[tid] : 0u;
     const uint32_t my_nch = (my_cnt + 63u) / 64u;
     const bool my_big = my_cnt > (uint32_t)MAX_SEARCH;
     s_binlive[tid] = 0;
-    s_bdone[tid] = ((uint32_t)tid >= b_lo && (uint32_t)tid < b_hi) ? 0u : my_nch;  // (all chunks done = the bin is out)
-    if (tid == 0) { s_minpass = ~0ull; s_valid = ~0ull; }
-    bool split_tried = mode == 1 || P.lslot == nullptr || P.long_split == 0, aborted = false;
-#ifdef SR_LONG_COUNT
-    unsigned long long lc_chunks = 0, lc_live = 0, lc_cmp = 0, lc_busy = 0, lc_turns = 0, lc_listed = 0, lc_notok = 0, lc_okp = 0;
-    long long lc_q[5] = {0, 0, 0, 0, 0};
-#endif
+    s_bdone[tid] = 0;
     for (;;) {
       __syncthreads();
-#ifdef SR_LONG_COUNT
-      lc_turns++;
-      const long long lc_w0 = clock64();
-#endif
       // the range of thread tid's bin in this turn
       const uint32_t my_done = s_bdone[tid], live_prev = s_binlive[tid];
       uint32_t my_tgt = my_nch;
@@ -2164,79 +2216,19 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       if (lane == 63) s_wcnt[wave] = incl;
       __syncthreads();
       uint32_t base = 0, total = 0;
-      for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; total += v; }
+      for (int w = 0; w < SCAN_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; total += v; }
       // (everything a barrier depends on is made a scalar: a branch the compiler takes for divergent is run through with an
       // empty EXEC mask, and an s_barrier inside it still counts)
       total = uni_u32(total);
       s_bchunk0[tid] = base + incl - nch;
-      if (tid == 0) s_ticket = 0;
+      // (the hint is read by ONE thread and handed round through LDS: leaving the turn loop is a decision of the block -- every
+      // wavefront loading it for itself, as round 4's split searches did, lets some leave and some stay, and from then on
+      // the barriers pair threads at different places: the "unresolved race" of round 4, and its hangs)
+      if (tid == 0) { s_ticket = 0; s_hint = nparts > 1 ? ag_ld(&hd->bestpart) : 0xffffffffu; }
       __syncthreads();
       if (total == 0) break;
-#ifdef SR_LONG_COUNT
-      lc_listed += total;
-#endif
-      if (nparts > 1 && uni_u32(__hip_atomic_load(&slot->bestpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < part) {
-        aborted = true;  // a part ahead of this one has a pass inside its window: nothing here can win
-        break;
-      }
-      if (!split_tried) {
-        split_tried = true;
-        if (total >= LONG_SPLIT_MIN) {
-          if (tid == 0) s_ctl = __hip_atomic_load(&myslot->nparts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;  // (the last split of this block is over)
-          __syncthreads();
-          if (uni_u32(s_ctl)) {
-            uint32_t np = total / LONG_SPLIT_PART;
-            if (np > (uint32_t)LONG_MAX_PARTS) np = LONG_MAX_PARTS;
-            // part p starts at the first bin with p / np of the listed chunks ahead of it (thread p looks it up)
-            if ((uint32_t)tid <= np) {
-              uint32_t first = (uint32_t)tid == np ? nb : 0u;
-              if (tid > 0 && (uint32_t)tid < np) {
-                const uint32_t thr = (uint32_t)((unsigned long long)tid * total / np);
-                uint32_t lo2 = 0, hi2 = nb;  // first b in [0, nb] with chunk0[b] >= thr (chunk0 does not decrease)
-                while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (s_bchunk0[mid] >= thr) hi2 = mid; else lo2 = mid + 1; }
-                first = lo2;
-              }
-              s_blo[tid] = first;
-            }
-            if ((uint32_t)tid < nb) { ag_st(&myslot->bstart[tid], s_bstart[tid]); ag_st(&myslot->bcount[tid], s_bcount[tid]); ag_st(&myslot->bcode[tid], s_bcode[tid]); }
-            __syncthreads();
-            if ((uint32_t)tid <= np) ag_st(&myslot->blo[tid], (uint32_t)tid == np ? nb : s_blo[tid]);
-            if (tid == 0) {
-              ag_st(&myslot->li, li); ag_st(&myslot->nb, nb); ag_st(&myslot->done, 0u); ag_st(&myslot->best_single, best_single);
-              ag_st(&myslot->bestrid, (uint32_t)s_bestrid); ag_st(&myslot->bestpart, 0xffffffffu);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every store of this wavefront has been acknowledged ...
-            __syncthreads();                                   // ... and so have the other wavefronts')
-            if (tid == 0) {
-              const uint32_t base = atomicAdd(&P.lctl[1], np - 1);
-              uint32_t okp = 0;
-              if (base + np - 1 <= P.ltask_cap) {
-                ag_st(&myslot->nparts, np);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (uint32_t pp = 1; pp < np; pp++)
-                  __hip_atomic_store(&P.ltask[base + pp - 1], ((blockIdx.x + 1u) << 8) | pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                okp = np;
-                atomicAdd(&P.lctl[3], 1u);
-              } else {
-                // no room for the tasks: the indices that were reserved must not stay empty -- a block that holds the ticket of
-                // an empty task waits for it until the round's searches are done, and with every block waiting nothing is
-                // (opts.long_split = 64 at 100 M reads: 160 000 tasks per round, K = 131 072 of them fit)
-                for (uint32_t i = base; i < base + np - 1 && i < P.ltask_cap; i++)
-                  __hip_atomic_store(&P.ltask[i], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              s_ctl = okp;
-            }
-            __syncthreads();
-            const uint32_t okp = uni_u32(s_ctl);
-            if (okp) {  // this block keeps part 0
-              nparts = okp;
-              b_hi = uni_u32(s_blo[1]);
-              if ((uint32_t)tid >= b_hi) s_bdone[tid] = my_nch;
-              continue;
-            }
-          }
-        }
-      }
+      // a part ahead of this one has a pass inside its window: nothing here can win (a hint: see the header comment)
+      if (uni_u32(s_hint) < part) break;
       for (;;) {
         // No `if (lane == 0)` around the atomics of this loop: with one at the end of an iteration (the atomicMin) and one
         // at the start of the next (the ticket) the compiler threads the two branches, and lanes 1-63 go round the loop on
@@ -2244,15 +2236,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
         // in the atomic instead: the 64 lanes add 1 each (the backend folds that into one LDS add of 64), so s_ticket counts
         // in units of 64.
         // A ticket is LONG_NCH consecutive listed chunks: a chunk is three dependent memory round trips (id + signature,
-        // bitmap word, the survivors' reads) and a wavefront has nothing else to do meanwhile -- 9.6 k clocks per chunk one
-        // at a time; with four in flight the round trips are shared, and the survivors of all four (one entry in twelve
-        // passes the signature bound on genome-like pools) are packed into one compare pass.
-#if SR_LONG_COUNT == 3
-        const long long lq0 = clock64();
-#endif
+        // bitmap word, the survivors' reads) and a wavefront has nothing else to do meanwhile; with several in flight the
+        // round trips are shared, and the survivors of all of them (one entry in twelve passes the signature bound on
+        // genome-like pools) are packed into one compare pass.
         const uint32_t g = uni_u32((uint32_t)(atomicAdd(&s_ticket, 1ull) >> 6));
         if (g >= (total + LONG_NCH - 1) / LONG_NCH) break;
-        if (nparts > 1 && uni_u32(__hip_atomic_load(&slot->bestpart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < part) break;
+        if (nparts > 1 && uni_u32(ag_ld(&hd->bestpart)) < part) break;
         const uint32_t c0 = g * LONG_NCH;
         uint32_t lo = 0, hi = nb;  // the bin of listed chunk c0: the last b with chunk0[b] <= c0 (it has chunks: c0 < total)
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (uni_u32(s_bchunk0[mid]) <= c0) lo = mid; else hi = mid; }
@@ -2264,9 +2253,6 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           if (mp_hi < lo || (mp_hi == lo && (mp_lo >> 6) < q0)) break;
         }
         typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
-#if SR_LONG_COUNT == 3
-        const long long lq1 = clock64();
-#endif
         // A: id and signature of every entry of the chunks
         uint32_t kb[LONG_NCH], kq[LONG_NCH], rk[LONG_NCH], kdead[LONG_NCH];
         bool kbig[LONG_NCH], has[LONG_NCH];
@@ -2303,10 +2289,6 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
             }
           }
         }
-#if SR_LONG_COUNT == 3
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const long long lq2 = clock64();
-#endif
         // B: signature bound; the bitmap word (one random request per entry) only where it matters -- the number of live
         // entries counts in a big bin only, elsewhere the entries that pass the bound are asked
         bool sp[LONG_NCH];
@@ -2322,10 +2304,6 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
             else tw[k] = P.taken[rk[k] >> 6];
           }
         }
-#if SR_LONG_COUNT == 3
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const long long lq3 = clock64();
-#endif
         // C: the entries that are free and pass the bound, packed in key order (chunk, then lane) into the staging rows
         uint32_t nsrv = 0;
 #pragma unroll
@@ -2335,9 +2313,6 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           bool sv = lv && sp[k];
           if (kclip[k] != 0xffffffffu && kclip[k] + (uint32_t)__popcll(Lm & ((1ull << lane) - 1)) >= (uint32_t)MAX_SEARCH) sv = false;  // outside the window
           const uint64_t Sm = __ballot(sv);
-#ifdef SR_LONG_COUNT
-          lc_chunks += has[k] ? 1 : 0; lc_live += __popcll(Lm);
-#endif
           if (kbig[k] && Lm) atomicAdd(&s_binlive[kb[k]], lv ? 1u : 0u);
           if (sv) {
             const uint32_t at = nsrv + (uint32_t)__popcll(Sm & ((1ull << lane) - 1));
@@ -2347,15 +2322,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           nsrv += (uint32_t)__popcll(Sm);
         }
         nsrv = uni_u32(nsrv);
-#if SR_LONG_COUNT == 3
-        lc_q[0] += lq1 - lq0; lc_q[1] += lq2 - lq1; lc_q[2] += lq3 - lq2; lc_q[3] -= clock64(); lc_q[4] += nsrv;
-#endif
-        if (nsrv == 0) {
-#if SR_LONG_COUNT == 3
-          lc_q[3] += clock64();
-#endif
-          continue;
-        }
+        if (nsrv == 0) continue;
         // (the compare stages reads through the same rows: everything is taken out first)
         uint32_t pr[LONG_NCH], po[LONG_NCH];
 #pragma unroll
@@ -2389,13 +2356,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
             break;  // (the packed order is the key order: nothing behind the first pass matters)
           }
         }
-#if SR_LONG_COUNT == 3
-        lc_q[3] += clock64();
-#endif
       }
-#ifdef SR_LONG_COUNT
-      lc_busy += (unsigned long long)(clock64() - lc_w0);
-#endif
       __syncthreads();
       // Every listed chunk with a key below the final s_minpass has been compared (tickets go out in key order and a
       // wavefront only stops on a key lower than its chunk's), so the final s_minpass is the first pass of this turn's list.
@@ -2416,33 +2377,23 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
           __syncthreads();
           const unsigned long long ahead = (unsigned long long)cq * 64 + cfp;  // entries of the bin visited before the pass
           uint32_t mycnt = 0;
-          for (unsigned long long pp = (unsigned long long)tid; pp < ahead; pp += 64 * LONG_WAVES)
+          for (unsigned long long pp = (unsigned long long)tid; pp < ahead; pp += 64 * SCAN_WAVES)
             { const uint32_t rr = pids[st0 + (cnt - 1 - (uint32_t)pp)]; mycnt += P.idmask != 0xffffffffu ? !(rr >> 31) : !is_taken(P.taken, rr); }
           const uint32_t wsum = (uint32_t)wave_sum_i((int)mycnt);
           if (wsum) atomicAdd(&s_ctl, lane == 0 ? wsum : 0u);
           __syncthreads();
           ok = uni_u32(s_ctl) < (uint32_t)MAX_SEARCH;
-#ifdef SR_LONG_COUNT
-          if (!ok && tid == 0) {  // what a pass outside the window looks like: live entries ahead, chunk, bin size, chunks done before this turn
-            unsigned long long *nk = (unsigned long long *)(P.lctl + 8) + 120;
-            atomicAdd(nk, 1ull); atomicAdd(nk + 1, (unsigned long long)s_ctl); atomicAdd(nk + 2, (unsigned long long)cq); atomicAdd(nk + 3, (unsigned long long)cnt);
-            atomicAdd(nk + 4, (unsigned long long)s_bdone[cb]); atomicAdd(nk + 5, (unsigned long long)s_binlive[cb]);
-          }
-#endif
         }
       }
       __syncthreads();
       // the lists of the next turn
-#ifdef SR_LONG_COUNT
-      if (fresh) { if (ok) lc_okp++; else lc_notok++; }
-#endif
       if (!fresh) {
         s_bdone[tid] = my_tgt;  // nothing stopped early: every listed chunk was compared
       } else if (ok) {
         // the best pass so far: the bins behind it are out, the bins ahead of it are complete up to their targets
         if (tid == 0) {
           s_valid = ((unsigned long long)c_hi << 32) | c_lo;
-          if (nparts > 1) atomicMin(&slot->bestpart, part);  // (the parts behind this one can stop)
+          if (nparts > 1) atomicMin(&hd->bestpart, part);  // (the parts behind this one can stop)
         }
         s_bdone[tid] = (uint32_t)tid >= cb ? my_nch : my_tgt;
       } else {
@@ -2457,118 +2408,69 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long(DevParams P, int direc
       }
     }
     // a bin ahead of the winner (any bin when nothing won) that held MAX_SEARCH live entries stopped its probe at the window
+    // (a part that stopped on the hint has no pass and lies behind the winning part: k_long_fin does not look at it)
     {
       const uint32_t v_hi = uni_u32(((const uint32_t *)&s_valid)[1]);
-      const uint32_t wb = v_hi != 0xffffffffu ? v_hi : b_hi;
-      if ((uint32_t)tid >= b_lo && (uint32_t)tid < wb && my_big && s_binlive[tid] >= (uint32_t)MAX_SEARCH) s_capped = 1;
-    }
-    if (nparts > 1) {
-      // a part of a split search: its result goes to the slot; the part that finishes last combines them -- the lowest part
-      // with a pass wins, the parts up to it say whether a bin stopped at the window
-      __syncthreads();
-      if (tid == 0) {
-        ag_st(&slot->res[part], aborted ? ~0ull : (unsigned long long)s_valid);
-        ag_st(&slot->capped[part], (uint32_t)s_capped);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_ctl = atomicAdd(&slot->done, 1u) == nparts - 1;
-      }
-      __syncthreads();
-      if (!uni_u32(s_ctl)) {
-#ifdef SR_LONG_COUNT
-        if (tid == 0) {
-          const unsigned long long dt = (unsigned long long)(clock64() - lc_take);
-          atomicAdd((unsigned long long *)(P.lctl + 6), dt);
-          int b = 63 - __clzll(dt | 1ull) - 10; b = b < 0 ? 0 : b > 15 ? 15 : b;
-          unsigned long long *hsp = (unsigned long long *)(P.lctl + 8) + 8 * b;
-          atomicAdd(hsp, 1ull); atomicAdd(hsp + 1, lc_turns); atomicAdd(hsp + 2, lc_listed); atomicAdd(hsp + 3, dt); atomicAdd(hsp + 4, lc_notok); atomicAdd(hsp + 5, lc_okp);
-        }
-#endif
-        __syncthreads();
-        continue;
-      }
-      if (tid == 0) {
-        unsigned long long key = ~0ull;
-        uint32_t cap = 0;
-        for (uint32_t pp = 0; pp < nparts && key == ~0ull; pp++) {
-          cap |= __hip_atomic_load(&slot->capped[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          key = __hip_atomic_load(&slot->res[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_valid = key; s_capped = cap;
-        s_best = __hip_atomic_load(&slot->best_single, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_bestrid = __hip_atomic_load(&slot->bestrid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ag_st(&slot->nparts, 0u);  // the slot is free again
-      }
-      __syncthreads();
-      best_single = s_best;
-    }
-    {
-      const uint32_t v_hi = uni_u32(((const uint32_t *)&s_valid)[1]), v_lo = uni_u32(((const uint32_t *)&s_valid)[0]);
-      if (tid == 0 && v_hi != 0xffffffffu) {
-        typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
-        g_u32_t *pids = (g_u32_t *)((s_bcode[v_hi] & 1) ? P.ids[1] : P.ids[0]);
-        s_win_code = s_bcode[v_hi];
-        s_win_rid = pids[s_bstart[v_hi] + (s_bcount[v_hi] - 1 - ((v_lo >> 6) * 64 + (v_lo & 63u)))] & P.idmask;
-      }
+      const uint32_t wb = v_hi != 0xffffffffu ? v_hi : nb;
+      if ((uint32_t)tid < wb && my_big && s_binlive[tid] >= (uint32_t)MAX_SEARCH) s_capped = 1;
     }
     __syncthreads();
-#ifdef SR_LONG_COUNT
-#if SR_LONG_COUNT != 3
-    if (tid == 0) { c->st_iter += (unsigned long long)(lc_t1 - lc_t0); c->st_hits += (unsigned long long)(clock64() - lc_t1); c->st_lost += lc_turns; }
-#endif
-    if (lane == 0) {
-      atomicAdd((unsigned long long *)&c->st_probes, lc_chunks);
-#if SR_LONG_COUNT == 3
-      // per wavefront clocks: st_iter ticket + bin lookup, st_hits id/signature round trip, st_keyok bound + bitmap round trip,
-      // st_cands packing + compare; st_lost survivors
-      atomicAdd((unsigned long long *)&c->st_iter, (unsigned long long)lc_q[0]);
-      atomicAdd((unsigned long long *)&c->st_hits, (unsigned long long)lc_q[1]);
-      atomicAdd((unsigned long long *)&c->st_keyok, (unsigned long long)lc_q[2]);
-      atomicAdd((unsigned long long *)&c->st_cands, (unsigned long long)lc_q[3]);
-      atomicAdd((unsigned long long *)&c->st_lost, (unsigned long long)lc_q[4]);
-#else
-      atomicAdd((unsigned long long *)&c->st_cands, lc_live);
-      atomicAdd((unsigned long long *)&c->st_keyok, lc_busy);
-#endif
-    }
-#endif
-    // ---- the proposal (as the end of search_step)
-    if (wave == 0) {
-      const uint32_t wm = s_win_code, ws = best_single;
-      const bool found = wm != 0x7fffffffu || ws != 0x7fffffffu;
-      const uint32_t wcode = wm < ws ? wm : ws;
-      const uint32_t wrid = wm < ws ? s_win_rid : s_bestrid;
-      const bool cap_u = s_capped != 0;
-      if (found) {
-        h.prop_rid = uni_u32(wrid);
-        h.prop_shift = uni_u32(wcode >> 2);
-        h.prop_rev = uni_u32(((wcode >> 1) & 1) | ((wcode & 1) << 1) | (cap_u ? 0u : 4u));
-        h.prop_kind = PROP_MATCH;
-      } else {
-        h.prop_kind = PROP_NONE;
-      }
-      store_hot(c, h, lane, 2, 4);
-      if (lane == 0) {
-        if (found) {
-          P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid;
-          if (direct) atomicMin(&P.resv[wrid], cid);
-        } else {
-          P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
-        }
-        c->st_long++;  // (the chain is this block's alone)
-        if (P.lctl) atomicAdd(&P.lctl[2], 1u);  // one more search of the round finished
-      }
-    }
-#ifdef SR_LONG_COUNT
     if (tid == 0) {
-      const unsigned long long dt = (unsigned long long)(clock64() - lc_take);
-      atomicAdd((unsigned long long *)(P.lctl + 6), dt);
-      int b = 63 - __clzll(dt | 1ull) - 10; b = b < 0 ? 0 : b > 15 ? 15 : b;
-      unsigned long long *hsp = (unsigned long long *)(P.lctl + 8) + 8 * b;
-      atomicAdd(hsp, 1ull); atomicAdd(hsp + 1, lc_turns); atomicAdd(hsp + 2, lc_listed); atomicAdd(hsp + 3, dt); atomicAdd(hsp + 4, lc_notok); atomicAdd(hsp + 5, lc_okp);
+      const uint32_t v_hi = ((const uint32_t *)&s_valid)[1], v_lo = ((const uint32_t *)&s_valid)[0];
+      uint32_t wcode = LONG_NONE, wrid = 0;
+      if (v_hi != 0xffffffffu) {
+        typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+        g_u32_t *pids = (g_u32_t *)((s_bcode[v_hi] & 1) ? P.ids[1] : P.ids[0]);
+        wcode = s_bcode[v_hi];
+        wrid = pids[s_bstart[v_hi] + (s_bcount[v_hi] - 1 - ((v_lo >> 6) * 64 + (v_lo & 63u)))] & P.idmask;
+      }
+      hd->rescode[part] = wcode; hd->resrid[part] = wrid; hd->capped[part] = s_capped;
     }
-#endif
-    __syncthreads();  // the LDS state belongs to the next chain of this block
+    __syncthreads();  // the LDS state belongs to the next part of this block
+  }
+}
+
+// ---- kernel 3: one wavefront per search -- the lowest part with a pass against the best single-read bin; the proposal
+// (as the end of search_step)
+__global__ __launch_bounds__(256) void k_long_fin(DevParams P, int direct) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t npend = P.longq[0];
+  for (uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6); qi < npend; qi += gridDim.x * 4) {
+  const uint32_t li = uni_u32(P.longq[2 + qi]), cid = P.c0 + li;
+  Chain *c = &P.chains[li];
+  const LongHead *hd = P.lhead + qi;
+  ChainHot h;
+  load_hot(c, h);
+  const uint32_t np = uni_u32(hd->nparts);
+  const uint32_t rc_ = (uint32_t)lane < np ? hd->rescode[lane] : LONG_NONE;
+  const uint32_t cp_ = (uint32_t)lane < np ? hd->capped[lane] : 0u;
+  const uint64_t fm = __ballot(rc_ != LONG_NONE);
+  const int wp = fm ? __ffsll((unsigned long long)fm) - 1 : 63;  // the winning part (none: every part counts for the flag)
+  const bool cap_u = __ballot(cp_ != 0 && lane <= wp) != 0;
+  const uint32_t wm = fm ? (uint32_t)__shfl((int)rc_, wp, 64) : LONG_NONE;
+  const uint32_t wmr = fm ? uni_u32(hd->resrid[wp]) : 0u;
+  const uint32_t ws = uni_u32(hd->best_single);
+  const bool found = wm != LONG_NONE || ws != LONG_NONE;
+  const uint32_t wcode = wm < ws ? wm : ws;
+  const uint32_t wrid = wm < ws ? wmr : uni_u32(hd->bestrid);
+  if (found) {
+    h.prop_rid = wrid;
+    h.prop_shift = wcode >> 2;
+    h.prop_rev = ((wcode >> 1) & 1) | ((wcode & 1) << 1) | (cap_u ? 0u : 4u);  // rev | dict << 1 | resumable << 2
+    h.prop_kind = PROP_MATCH;
+  } else {
+    h.prop_kind = PROP_NONE;
+  }
+  store_hot(c, h, lane, 2, 4);
+  if (lane == 0) {
+    if (found) {
+      P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid;
+      if (direct) atomicMin(&P.resv[wrid], cid);
+    } else {
+      P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
+    }
+    c->st_long++;  // (the chain is this wavefront's alone)
+  }
   }
 }
 
@@ -2634,8 +2536,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   // the counters the NEXT round's k_mg_mark accumulates into (nobody reads them before that)
   if (cid < (P.Ktot + 2047) / 2048) P.needy_cnt[cid] = 0;
   if (cid == 0 && P.longq) { P.longq[0] = 0; P.longq[1] = 0; }  // this round's long searches are done (k_long ran before this kernel)
-  if (P.longq && cid < 3) P.lctl[cid] = 0;
-  if (P.longq && P.long_split && cid < P.ltask_cap) P.ltask[cid] = 0;  // (K entries: half a megabyte per round on the pools that have a queue)
+  if (P.longq && cid < 2) P.lctl[cid] = 0;
   if (P.ord) {  // class lists of this block's chains (k_round_mc): class 0 first, no atomics
     static_assert(MARK_BLOCK == 256, "k_mg_mark runs 256 chains per block");
     __shared__ uint32_t s_wc[4][4];  // [wave][class]
@@ -2940,7 +2841,12 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
                       else hipLaunchKernelGGL((k_round_tl<N, false>), g, b, dyn, st, P); } while (0)
     if (P.Lpad <= 192) LCALL(3); else LCALL(8);
 #undef LCALL
-    hipLaunchKernelGGL(k_long, dim3(std::min<uint32_t>(P.K, (uint32_t)P.long_blocks)), dim3(64 * LONG_WAVES), 0, st, P, 1);
+    // the queued searches: probes and bin lists, then every part of every search, then the proposals (fixed grids: how many
+    // searches a round hands over is known on the device only; the blocks take queue entries / parts in turn)
+    const uint32_t lb = std::min<uint32_t>(P.K, (uint32_t)P.long_blocks);
+    hipLaunchKernelGGL(k_long_list, dim3(lb), dim3(64 * LONG_WAVES), 0, st, P);
+    hipLaunchKernelGGL(k_long_scan, dim3(std::min<uint32_t>(P.K * 4, (uint32_t)P.long_blocks * 5)), dim3(64 * SCAN_WAVES), 0, st, P);
+    hipLaunchKernelGGL(k_long_fin, dim3(std::min<uint32_t>((P.K + 3) / 4, 256u)), dim3(256), 0, st, P, 1);
   } else if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL

@@ -127,8 +127,6 @@ struct spring_reorder_ctx {
   hipStream_t st = nullptr;
   int stage = ST_CREATED;
   std::vector<void *> allocs;
-  void *uc_mem = nullptr;   // uncached device memory (k_long's queues and slots: what blocks of one launch tell each other)
-  size_t uc_bytes = 0;
   uint64_t dev_bytes = 0, peak_bytes = 0;
   // input
   uint8_t *d_dna = nullptr;  // record stream (owned unless borrowed)
@@ -380,7 +378,6 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   (void)hipSetDevice(ctx->dev);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
   for (void *p : ctx->allocs) pool_free(ctx->dev, p);
-  if (ctx->uc_mem) (void)hipFree(ctx->uc_mem);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
   delete ctx;
@@ -1357,15 +1354,18 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   const bool very_deep = P.deep_bins && (dict_is_very_deep(ctx) || (dict_has_heavy_tail(ctx) && !dict_is_deep(ctx)));
   P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : (very_deep ? 8 : 0));
   P.long_blocks = 512;
-  // ... and only when at least this many bin entries are still ahead of it (32 compare passes of one wavefront, two
-  // steps of k_long); budgets below 8 hand over unconditionally (tests).  PhiX-like pool, chains stage, same box: off
-  // 300 ms; budget 8 with 2 048 / 4 096 / 8 192 entries 219 / 225 / 228; 24 unconditionally 218; 8 unconditionally 238
-  P.long_min = P.long_budget < 8 ? 0 : 2048;
+  // ... and only when at least this many bin entries are still ahead of it; budgets below 8 hand over unconditionally
+  // (tests).  Round 5 (the long searches in three kernels, parts scanned by small blocks: what is handed over no longer
+  // waits for the round's longest search): 512 -- genome-like pools, chains stage with 2 048 / 1 024 / 512 / 256 entries:
+  // 20 M reads 221 / 210 / 210 / 220 ms, 100 M reads 1 589 / - / 1 516 / 1 558; PhiX-like pool 214 / 208 / 207 (off: 225).
+  // (round 3, one block of 16 wavefronts per search: 2 048 / 4 096 / 8 192 entries 219 / 225 / 228 ms on the PhiX-like pool)
+  P.long_min = P.long_budget < 8 ? 0 : 512;
   if (o.long_min > 0) P.long_min = o.long_min;
   if (o.long_blocks > 0) P.long_blocks = o.long_blocks;
-  P.long_split = o.long_split > 0 ? o.long_split : 0;  // (off by default: see the note at LongSlot)
+  // a search whose first turn lists more than this many chunks of 64 bin entries is cut into parts (k_long_list)
+  P.long_part = o.long_split > 0 ? o.long_split : (o.long_split < 0 ? 0 : 192);
   P.longq = nullptr;
-  P.lctl = nullptr; P.ltask = nullptr; P.lslot = nullptr; P.ltask_cap = 0;
+  P.lctl = nullptr; P.lparts = nullptr; P.lhead = nullptr; P.lbin = nullptr; P.lbcode = nullptr; P.lbin_stride = 0;
   P.sig[0] = P.sig[1] = nullptr;
 }
 // Default chain count.  ~1000 reads per chain: the compressed size grows with the chain count on ordinary coverage
@@ -1460,25 +1460,15 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     if (P.deep_bins && P.long_budget > 0) {  // queue of the searches k_round hands to k_long
       DMALLOC(P.longq, ((size_t)K + 2) * 4);
       HIPCHK(hipMemsetAsync(P.longq, 0, 8, st));
-      P.ltask_cap = K;
-      // The blocks of one k_long launch hand each other work through these (help tasks, the bin list of a split search, the
-      // parts' results).  The XCDs have an L2 each and ordinary device memory is cached there: a block on another XCD may be
-      // served a stale line whatever the writer's stores said (agent-scope stores and loads alone gave a wrong result once
-      // in a few runs at 250 000 splits per run, and fences write back / invalidate a whole L2 each time).  So this
-      // memory is allocated UNCACHED: every access goes to the memory side, coherent by construction.
-      const size_t b_ctl = 264 * 4 /* ([4..]: instrumentation builds) */, b_task = ((size_t)K * 4 + 255) & ~(size_t)255;
-      const size_t b_need = 2048 + b_task + (size_t)P.long_blocks * sizeof(LongSlot);
-      if (ctx->uc_bytes < b_need) {
-        if (ctx->uc_mem) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(ctx->uc_mem); ctx->uc_mem = nullptr; ctx->uc_bytes = 0; }
-        HIPCHK(hipExtMallocWithFlags(&ctx->uc_mem, b_need, hipDeviceMallocUncached));
-        ctx->uc_bytes = b_need;
-      }
-      static_assert(264 * 4 <= 2048 && alignof(LongSlot) <= 256, "layout of the uncached block");
-      (void)b_ctl;
-      P.lctl = (uint32_t *)ctx->uc_mem;
-      P.ltask = (uint32_t *)((char *)ctx->uc_mem + 2048);
-      P.lslot = (LongSlot *)((char *)ctx->uc_mem + 2048 + b_task);
-      HIPCHK(hipMemsetAsync(ctx->uc_mem, 0, b_need, st));
+      // what the three kernels of the long searches hand each other (LongHead, reorder_device.h): a head and a bin list per
+      // chain (any chain may hand its search over in a round), one word per part
+      P.lbin_stride = (uint32_t)std::min<int>(LONG_MAX_BINS, (4 * P.maxshift + 15) & ~15);
+      DMALLOC(P.lctl, 64);
+      HIPCHK(hipMemsetAsync(P.lctl, 0, 64, st));
+      DMALLOC(P.lparts, (size_t)K * LONG_MAX_PARTS * 4);
+      DMALLOC(P.lhead, (size_t)K * sizeof(LongHead));
+      DMALLOC(P.lbin, (size_t)K * P.lbin_stride * sizeof(uint2));
+      DMALLOC(P.lbcode, (size_t)K * P.lbin_stride * sizeof(uint16_t));
       for (int l = 0; l < 2; l++) {  // ... and the signatures k_long rejects most bin entries from (16 bytes per dictionary entry)
         ulonglong2 *sg = nullptr;
         const uint64_t m = ctx->dict[l].numreads;
@@ -2011,23 +2001,9 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(st));
   s.long_splits = 0;
   if (P.lctl) {
-    uint32_t ns = 0;  // (k_mg_mark zeroes [0..2] every round, [3] counts the run's splits)
+    uint32_t ns = 0;  // (k_mg_mark zeroes [0..1] every round, [3] counts the run's split searches)
     HIPCHK(hipMemcpy(&ns, P.lctl + 3, 4, hipMemcpyDeviceToHost));
     s.long_splits = ns;
-#ifdef SR_LONG_COUNT
-    {  // clocks the blocks of k_long spent waiting for help tasks / between taking a search and finishing it
-      unsigned long long w[2] = {0, 0};
-      HIPCHK(hipMemcpy(w, P.lctl + 4, 16, hipMemcpyDeviceToHost));
-      fprintf(stderr, "[k_long] idle clocks %llu, search clocks (take to proposal, all blocks) %llu\n", w[0], w[1]);
-      unsigned long long hs[128];  // per log2(clocks) bucket: searches or parts, turns, chunks listed, clocks, passes outside the window, passes inside
-      HIPCHK(hipMemcpy(hs, P.lctl + 8, sizeof(hs), hipMemcpyDeviceToHost));
-      if (hs[120]) fprintf(stderr, "[k_long] passes outside the window: %llu; on average %.0f live entries ahead, chunk %.1f, bin of %.0f entries, %.1f chunks done before the turn, %.0f live counted\n",
-                           hs[120], (double)hs[121] / hs[120], (double)hs[122] / hs[120], (double)hs[123] / hs[120], (double)hs[124] / hs[120], (double)hs[125] / hs[120]);
-      for (int b = 0; b < 15; b++)
-        if (hs[8 * b]) fprintf(stderr, "[k_long] clocks 2^%d..: %llu scans, %.1f turns (%.2f left a bin at the window, %.2f took a pass), %.0f chunks, %.0f clocks each\n", 10 + b, hs[8 * b],
-                               (double)hs[8 * b + 1] / hs[8 * b], (double)hs[8 * b + 4] / hs[8 * b], (double)hs[8 * b + 5] / hs[8 * b], (double)hs[8 * b + 2] / hs[8 * b], (double)hs[8 * b + 3] / hs[8 * b]);
-    }
-#endif
   }
   ctx->dfree(d_off_m); ctx->dfree(d_off_s);
   // the append-order buffers are no longer needed
