@@ -78,7 +78,7 @@ typedef struct {
                              has no match yet.  An empty plan = the library's choice (first_shifts, kernel, dictionary depth) */
   int32_t plan1[6];
   int32_t long_min;       /* k_long: bin entries that must still be ahead of a search for it to be handed over (0 = default 2048) */
-  int32_t long_blocks;    /* k_long: grid size (0 = default 512) */
+  int32_t long_blocks;    /* long searches: the grids of k_long_list / k_long_scan are 1-3 x / 5 x this many blocks (0 = default 256, the CUs) */
   int32_t debug;          /* 1: stage / phase timings on stderr */
   int32_t long_split;     /* long searches (k_long_list / k_long_scan / k_long_fin): a search whose bins hold more than this many
                              chunks of 64 entries within reach of the first turn is cut into parts (ranges of its bins, up to 64)

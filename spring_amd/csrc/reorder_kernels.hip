@@ -1991,16 +1991,21 @@ constexpr int LONG_PART_BINS = 64 * SCAN_WAVES;
 // hint -- bestpart, the lowest part of the search that has a pass so far: parts behind it stop (no result depends on it).
 
 // ---- kernel 1: probes -> bin list -> parts
-__global__ __launch_bounds__(64 * LONG_WAVES) void k_long_list(DevParams P) {
+// NW wavefronts per block = 64 NW probe codes: 8 for reads of up to 256 bases (three searches in flight per CU instead of one)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_long_list(DevParams P) {
   __shared__ uint64_t s_refs[2][LDS_LIMBS];
-  __shared__ __attribute__((aligned(16))) uint32_t s_stage[LONG_WAVES][STAGE_WORDS];
-  __shared__ uint32_t s_bstart[64 * LONG_WAVES], s_bcount[64 * LONG_WAVES], s_bchunk0[64 * LONG_WAVES];
-  __shared__ uint16_t s_bcode[64 * LONG_WAVES];
-  __shared__ uint32_t s_wcnt[LONG_WAVES];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[NW][STAGE_WORDS];
+  __shared__ uint32_t s_bstart[64 * NW], s_bcount[64 * NW], s_bchunk0[64 * NW];
+  __shared__ uint16_t s_bcode[64 * NW];
+  __shared__ uint32_t s_wcnt[NW];
   __shared__ uint32_t s_best, s_bestrid, s_qi, s_base, s_bstart_part[LONG_MAX_PARTS + 2];
-  static_assert(LONG_MAX_BINS == 64 * LONG_WAVES, "one bin per thread");
+  static_assert(LONG_MAX_BINS >= 64 * NW, "one bin per thread");
   const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
   const uint32_t npend = P.longq[0];
+  // (a fixed grid whatever the round handed over: a block that will find no search must cost nothing -- most rounds of the
+  // PhiX-like pool queue a few dozen searches, and 4 000 blocks that each took a ticket first cost 50 us per round)
+  if (blockIdx.x >= npend) return;
   const int klen2 = 2 * P.wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   lds_u32_t *stage = (lds_u32_t *)s_stage[wave];
@@ -2053,7 +2058,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long_list(DevParams P) {
     uint32_t nb = 0;
     {
       uint32_t base = 0;
-      for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; nb += v; }
+      for (int w = 0; w < NW; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; nb += v; }
       if (mine) {
         const uint32_t at = base + (uint32_t)__popcll(pb & ((1ull << lane) - 1));
         s_bstart[at] = pend.start; s_bcount[at] = pend.count; s_bcode[at] = (uint16_t)code;
@@ -2069,7 +2074,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_long_list(DevParams P) {
     if (lane == 63) s_wcnt[wave] = incl;
     __syncthreads();
     uint32_t base = 0, total = 0;
-    for (int w = 0; w < LONG_WAVES; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; total += v; }
+    for (int w = 0; w < NW; w++) { const uint32_t v = s_wcnt[w]; if (w < wave) base += v; total += v; }
     total = uni_u32(total);
     s_bchunk0[tid] = base + incl - nch1;
     // parts: ranges of bins of about P.long_part listed chunks and at most LONG_PART_BINS bins -- cut at equal shares of the
@@ -2148,6 +2153,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_long_scan(DevParams P) {
   __shared__ unsigned long long s_valid;            // ... and the lowest one that has been checked against its bin's window
   const int tid = threadIdx.x, wave = uni_i32(tid >> 6), lane = tid & 63;
   const uint32_t nparts_all = P.lctl[0];
+  if (blockIdx.x >= nparts_all) return;
   const int klen2 = 2 * P.wl;
   lds_u32_t *stage = (lds_u32_t *)s_stage[wave];
   const uint64_t *sref = &s_refs[0][0] + LDS_PAD, *srev = &s_refs[1][0] + LDS_PAD;
@@ -2843,10 +2849,12 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
 #undef LCALL
     // the queued searches: probes and bin lists, then every part of every search, then the proposals (fixed grids: how many
     // searches a round hands over is known on the device only; the blocks take queue entries / parts in turn)
-    const uint32_t lb = std::min<uint32_t>(P.K, (uint32_t)P.long_blocks);
-    hipLaunchKernelGGL(k_long_list, dim3(lb), dim3(64 * LONG_WAVES), 0, st, P);
-    hipLaunchKernelGGL(k_long_scan, dim3(std::min<uint32_t>(P.K * 4, (uint32_t)P.long_blocks * 5)), dim3(64 * SCAN_WAVES), 0, st, P);
-    hipLaunchKernelGGL(k_long_fin, dim3(std::min<uint32_t>((P.K + 3) / 4, 256u)), dim3(256), 0, st, P, 1);
+    // (long_blocks = 256 = the CUs: what is resident of each kernel -- 3 / 1 list blocks, 5 scan blocks per CU -- is its grid)
+    const uint32_t lb = (uint32_t)P.long_blocks;
+    if (4 * P.maxshift <= 512) hipLaunchKernelGGL(k_long_list<8>, dim3(std::min<uint32_t>(P.K, 3 * lb)), dim3(512), 0, st, P);
+    else hipLaunchKernelGGL(k_long_list<LONG_WAVES>, dim3(std::min<uint32_t>(P.K, lb)), dim3(64 * LONG_WAVES), 0, st, P);
+    hipLaunchKernelGGL(k_long_scan, dim3(std::min<uint32_t>(P.K * 4, 5 * lb)), dim3(64 * SCAN_WAVES), 0, st, P);
+    hipLaunchKernelGGL(k_long_fin, dim3(std::min<uint32_t>((P.K + 3) / 4, 64u)), dim3(256), 0, st, P, 1);
   } else if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL

@@ -1353,7 +1353,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // deep on average keep their own rule -- 25 600x: 178 ms without the hand-over, 195 with)
   const bool very_deep = P.deep_bins && (dict_is_very_deep(ctx) || (dict_has_heavy_tail(ctx) && !dict_is_deep(ctx)));
   P.long_budget = o.long_budget < 0 ? 0 : (o.long_budget ? o.long_budget : (very_deep ? 8 : 0));
-  P.long_blocks = 512;
+  P.long_blocks = 256;
   // ... and only when at least this many bin entries are still ahead of it; budgets below 8 hand over unconditionally
   // (tests).  Round 5 (the long searches in three kernels, parts scanned by small blocks: what is handed over no longer
   // waits for the round's longest search): 512 -- genome-like pools, chains stage with 2 048 / 1 024 / 512 / 256 entries:
