@@ -1566,7 +1566,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   uint64_t launches = 0;
   HIPCHK(hipMemcpyAsync(h_alive, &P.glob->alive, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  while (*h_alive) {
+  auto enqueue_batch = [&]() -> int {
     for (int r = 0; r < R; r++) {
       if (timed) HIPCHK(hipEventRecord(tev[2 * r], st));
       if (fused) {
@@ -1584,6 +1584,43 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
     rounds += R;
     for (int l = 0; l < 2; l++)  // shrink deep bins whose tail has been consumed (exact; see k_trim_bins)
       launch_trim_bins(st, ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]), P.epos[l]);
+    return 0;
+  };
+  if (fused && !timed && *h_alive) {
+    // The host looks at the chains still running one batch LATE: batch b + 1 is in the queue before the count of batch b is
+    // waited for, so the GPU never drains while the host synchronises and launches (a bubble of some tens of microseconds
+    // every R rounds).  The price: up to 2 R - 1 rounds over finished chains at the end instead of R - 1 (a round in which
+    // every chain is done changes nothing and costs its launches).
+    const size_t nw = ((size_t)P.Ktot + 63) / 64;
+    uint32_t *h_aw = nullptr;
+    HIPCHK(hipHostMalloc((void **)&h_aw, 2 * nw * sizeof(uint32_t), hipHostMallocDefault));
+    HostFree h_aw_guard{h_aw};
+    hipEvent_t bev[2] = {nullptr, nullptr};
+    struct EvFree { hipEvent_t *e; ~EvFree() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } bev_guard{bev};
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&bev[i], hipEventDisableTiming));
+    auto count_batch = [&](int slot) -> int {  // (queued behind the batch: the per-64-chain counts k_mg_mark keeps)
+      HIPCHK(hipMemcpyAsync(h_aw + (size_t)slot * nw, P.alive_wave, nw * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipEventRecord(bev[slot], st));
+      return 0;
+    };
+    int rr;
+    if ((rr = enqueue_batch())) return rr;
+    if ((rr = count_batch(0))) return rr;
+    for (int b = 0;; b ^= 1) {
+      if ((rr = enqueue_batch())) return rr;
+      if ((rr = count_batch(b ^ 1))) return rr;
+      HIPCHK(hipEventSynchronize(bev[b]));
+      uint64_t a = 0;
+      for (size_t i = 0; i < nw; i++) a += h_aw[(size_t)b * nw + i];
+      HIPCHK(hipGetLastError());
+      if (ctx->o.debug) fprintf(stderr, "[chains] rounds %llu running %llu\n", (unsigned long long)(rounds - R), (unsigned long long)a);
+      if (!a) break;
+    }
+    *h_alive = 0;
+  }
+  while (*h_alive) {
+    int rr = enqueue_batch();
+    if (rr) return rr;
     // chains still running: the two-kernel round keeps the count, the fused round recounts it every round
     if (fused) {
       int ra = running_chains(ctx, alive_tmp, h_alive);
