@@ -87,6 +87,17 @@ typedef struct {
                              before round 4); 0 = they do.  Same results either way */
   int32_t out_writers;    /* spring_reorder_run: threads that write the output files (each file belongs to one of them);
                              0 = a quarter of the host's hardware threads, at least 4, at most 24 */
+  int32_t alternatives;   /* candidates per match proposal (specification: orc_reorder_rounds_alt).  1: a chain that
+                             loses its proposed read to a lower chain id searches again next round.  2: the search also records the
+                             next passing read of the winning bin -- what the reference's thread tries next after losing the
+                             read_lock race (reorder.h:303-311) -- and a second resolution pass hands it to the loser: fewer lost
+                             proposals, fewer rounds on contended (deep-coverage) pools.  The OUTPUT DEPENDS on it for
+                             num_chains > 1 (both are legal `-t K` interleavings; num_chains = 1 is the `-t 1` order either way).
+                             0 (or negative) = the library's choice, reported in stats.alternatives: 2 on contended pools -- a
+                             quarter of the dictionary's reads in bins of >= 64 entries (coverage of tens of thousands x,
+                             PhiX-like pools: -10 ... -14 % of the chain stage) --, else 1 (a second candidate costs every
+                             successful search another look at its bin).  Needs fused rounds and fewer than 2^27 - 1 reads; 2
+                             on a shallower pool runs the deep-bin kernel variant */
 } spring_reorder_opts;
 
 typedef struct {
@@ -111,6 +122,7 @@ typedef struct {
   uint64_t table_minz;     /* 1: the dictionary table is addressed by minimizers (opts.table_mode) */
   uint64_t table_marked_lines; /* ... and this many of its lines were over-subscribed: their keys live at the redirect address */
   uint64_t long_splits;    /* long searches that were split into parts over several blocks (k_long) */
+  uint64_t alternatives;   /* candidates per match proposal the chain phase ran with (opts.alternatives, or the library's choice) */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);

@@ -25,10 +25,18 @@ constexpr int LDS_LIMBS = 16 + 2 * LDS_PAD;
 enum { MODE_SEARCH = 0, MODE_NEED_SEED = 1 };
 enum { PROP_NONE = 0, PROP_MATCH = 1, PROP_SEED = 2, PROP_FRESH = 3 /* fused rounds: nothing proposed yet */ };
 // per-chain proposal word exchanged between ranks in single-pool multi-GPU mode:
-// kind << 32 | rid, bit 40 = "this seed is the lowest of the round" (moves the cursor), bit 41 below
+// kind << 32 | rid, bit 35 = "this seed is the lowest of the round" (moves the cursor), bit 36 below; with the alternatives
+// schedule (DevParams::alts = 2) a PK_MATCH word also carries the chain's SECOND candidate, alt + 1 in bits 37..63 (0: none;
+// pools of fewer than 2^27 - 1 reads) -- so every consumer of the words, the multi-GPU exchange included, moves 8 bytes as before
 enum { PK_NONE = 0, PK_MATCH = 1, PK_SEED = 2, PK_NOSEED = 4, PK_DONE = 5 };
-constexpr unsigned long long PK_CURSOR_BIT = 1ull << 40;
-constexpr unsigned long long PK_WILLNEED_BIT = 1ull << 41;  // PK_NONE after a failed left search: the chain needs a seed next
+constexpr unsigned long long PK_CURSOR_BIT = 1ull << 35;
+constexpr unsigned long long PK_WILLNEED_BIT = 1ull << 36;  // PK_NONE after a failed left search: the chain needs a seed next
+constexpr int PK_ALT_SHIFT = 37;
+constexpr uint32_t ALT_MAX_READS = (1u << 27) - 1;
+// resv[] with alternatives: pass 0 (every first candidate, seeds) writes the chain id, pass 1 (k_alt_resolve: the second
+// candidate of a chain that lost pass 0) writes ALT_KEY | chain id -- an earlier pass beats a later one, inside a pass the
+// lowest chain id wins (specification: orc_reorder_rounds_alt); chain ids stay below 2^28
+constexpr uint32_t ALT_KEY = 1u << 28;
 
 // Per-chain state (one greedy chain == one reference OpenMP thread, reorder.h:351-431).
 // The 64-byte header is wave-uniform: the chain kernels fetch it with ONE scalar load into 16 SGPRs (no VGPRs, no
@@ -55,7 +63,8 @@ struct __attribute__((aligned(16))) ChainHot {
     };
     uint32_t flags;
   };
-  uint32_t pad[3];
+  uint32_t alt1;   // alternatives schedule: second candidate of the proposed match + 1 (0: none)
+  uint32_t pad[2];
 };
 static_assert(sizeof(ChainHot) == 64, "ChainHot must be one 64-byte line");
 
@@ -150,6 +159,7 @@ struct DevParams {
   uint32_t *needy_cnt;       // set bits per 64 words of needy (2048 chains) as k_mg_mark of the LAST round left them
   uint32_t *needy_cnt_next;  // the buffer k_mg_mark of THIS round fills (zeroed by the previous k_mg_mark)
   int fused;                 // 1: k_round (apply + search in one kernel)
+  int alts;                  // candidates per match proposal: 1, or 2 (the alternatives schedule; deep-bin kernel variants, fused rounds)
   int mc;                    // 1: four chains per wavefront (k_round_mc) where it applies
   // k_round_mc runs chains of one class per wavefront (the four chains of a wavefront take the union of their
   // paths): k_mg_mark sorts the running local chains of every block of MARK_BLOCK consecutive chain ids by what the

@@ -756,14 +756,15 @@ __device__ __forceinline__ void load_hot(const Chain *c, ChainHot &h) {
   h.prev = v[4]; h.first_rid = v[5]; h.n_emit = v[6]; h.n_single = v[7];
   h.s_slot = v[8]; h.num_reads_thr = v[9]; h.num_unmatched_past = v[10]; h.prop_rid = v[11];
   h.flags = v[12];
-  h.pad[0] = h.pad[1] = h.pad[2] = 0;
+  h.alt1 = v[13];
+  h.pad[0] = h.pad[1] = 0;
 }
 __device__ __forceinline__ void store_hot(Chain *c, const ChainHot &h, int lane, int q_lo = 0, int q_hi = 4) {
   if (lane >= q_lo && lane < q_hi) {
     const uint32_t plo = (uint32_t)(unsigned long long)h.ref_pos, phi = (uint32_t)((unsigned long long)h.ref_pos >> 32);
     uint4 q;
     q.x = lane == 0 ? plo : lane == 1 ? h.prev : lane == 2 ? h.s_slot : h.flags;
-    q.y = lane == 0 ? phi : lane == 1 ? h.first_rid : lane == 2 ? h.num_reads_thr : 0u;
+    q.y = lane == 0 ? phi : lane == 1 ? h.first_rid : lane == 2 ? h.num_reads_thr : h.alt1;
     q.z = lane == 0 ? (uint32_t)h.ref_len : lane == 1 ? h.n_emit : lane == 2 ? h.num_unmatched_past : 0u;
     q.w = lane == 0 ? h.e_slot : lane == 1 ? h.n_single : lane == 2 ? h.prop_rid : 0u;
     reinterpret_cast<uint4 *>(&c->h)[lane] = q;
@@ -1147,6 +1148,83 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
       atomicMin((uint32_t *)(uint64_t)(&urec[pay]) + 3, (uint32_t)(top_live + 1));
     break;
   }
+}
+
+// ---- the alternatives schedule (DevParams::alts = 2; executable specification: orc_reorder_rounds_alt): the SECOND candidate of a search
+// whose winner is read `wrid` of the probe `code` -- the next entry of the winner's bin, in the order the reference scans
+// it (from the tail), that is free and within the Hamming threshold, inside the same MAX_SEARCH_REORDER window (the reads
+// the reference's thread would try next after losing the read_lock race, reorder.h:303-311).  0xffffffff: none (a
+// single-read bin, or nothing passes).  One routine for every way a winner is found (serial walk, balanced scan, k_long):
+// it runs after the search, by the whole wavefront, on wave-uniform arguments: the bin is looked up again (its lines were
+// just touched), the entries ahead of the winner are only counted, the entries behind it are compared 64 at a time --
+// the first four live ones on their own first (on deep-coverage pools the next live entry nearly always passes).
+template <bool QUAD>
+__device__ __forceinline__ uint32_t find_alt(const DevParams &P, const uint64_t *sref, const uint64_t *srev, int ref_len,
+                                             int code, uint32_t wrid, lds_u32_t *stage, int lane) {
+  const int l = code & 1, rev = (code >> 1) & 1, shift = code >> 2;
+  const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+  const int klen2 = 2 * P.wl;
+  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
+  const uint64_t *sx = rev ? srev : sref;
+  const uint64_t key = lds_window(sx, rev ? 2 * (ds - shift) : 2 * (ds + shift)) & kmask;
+  const uint64_t hsh = mix64(key);
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) u64x2_t g_urec_t;
+  typedef const __attribute__((address_space(1))) uint32_t g_u32_t;
+  g_urec_t *urec = (g_urec_t *)(l ? uni_ptr(P.urec[1]) : uni_ptr(P.urec[0]));
+  g_u32_t *ids = (g_u32_t *)(l ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
+  uint32_t start = 0, count = 0;
+  for (int skip = 0;; skip++) {  // the key's bin (every lane walks the same slots: one request each)
+    uint32_t pay;
+    bool other = false;
+    const int kind = uni_i32(tab_find<false>(P.tab, hsh, 0u, l, skip, pay, other));
+    if (kind == 0) return 0xffffffffu;
+    if (kind == 2) { if (uni_u32(pay) == wrid) return 0xffffffffu; continue; }  // the winner's own single-read bin / a colliding slot
+    const u64x2_t rec = urec[uni_u32(pay)];
+    if (rec.x != key) continue;  // fingerprint collision
+    start = uni_u32((uint32_t)rec.y); count = uni_u32((uint32_t)(rec.y >> 32));
+    break;
+  }
+  const int bitshift = rev ? -2 * shift : 2 * shift;
+  const int lo = rev ? shift : 0;
+  const int mref = rev ? ref_len + shift : ref_len - shift;
+  int livec = 0;      // live entries of the chunks before this one
+  bool seen = false;  // the winner's entry has been passed
+  for (uint32_t base = 0; base < count; base += 64) {
+    const long long j = (long long)count - 1 - ((long long)base + lane);
+    uint32_t r = 0;
+    bool live = false;
+    if (j >= 0) {
+      r = ids[start + (uint32_t)j];
+      if (P.idmask != 0xffffffffu) { live = !(r >> 31); r &= 0x7fffffffu; }
+      else live = !is_taken(P.taken, r);
+    }
+    const uint64_t Lm = __ballot(live);
+    uint64_t cand = Lm;
+    if (!seen) {
+      const uint64_t Wm = __ballot(j >= 0 && r == wrid);
+      if (Wm) { seen = true; cand = Lm & ~((2ull << (__ffsll((unsigned long long)Wm) - 1)) - 1ull); }
+      else cand = 0;
+    }
+    // an entry is looked at while fewer than MAX_SEARCH live entries (the winner among them) lie ahead of it
+    const int before = livec + __popcll(Lm & ((1ull << lane) - 1ull));
+    const uint64_t Em = __ballot(((cand >> lane) & 1ull) && before < MAX_SEARCH);
+    if (Em) {
+      uint64_t first = Em;  // its four lowest bits
+      { uint64_t t = Em; t &= t - 1; t &= t - 1; t &= t - 1; t &= t - 1; first = Em & ~t; }
+      for (int stg = 0; stg < 2; stg++) {
+        const uint64_t m = stg ? (Em & ~first) : first;
+        if (!m) break;
+        bool ps = false;
+        if ((m >> lane) & 1ull) ps = cmp_candidate<QUAD>(P, sx, bitshift, lo, mref, ds, klen2, r, false, stage, lane) == 1;
+        const uint64_t Pm = __ballot(ps);
+        if (Pm) return (uint32_t)__shfl((int)r, __ffsll((unsigned long long)Pm) - 1, 64);
+      }
+    }
+    livec += __popcll(Lm);
+    if (livec >= MAX_SEARCH) break;
+  }
+  return 0xffffffffu;
 }
 
 // priority code of a probe: the reference tries shift ascending, forward before reverse, dictionary 0
@@ -1570,6 +1648,8 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
       h.prop_shift = (uint32_t)(wcode >> 2);
       h.prop_rev = (uint32_t)(((wcode >> 1) & 1) | ((wcode & 1) << 1) | ((TRIM && !cap_u) ? 4 : 0));  // rev | dict << 1 | resumable << 2
       h.prop_kind = PROP_MATCH;
+      // the alternatives schedule: the chain's second candidate travels with the proposal (deep-bin variants only)
+      if (TRIM && WORD) h.alt1 = P.alts == 2 ? uni_u32(find_alt<TRIM>(P, sref, srev, ref_len, wcode, wrid, s_stage, lane)) + 1u : 0u;
     } else {
       h.prop_kind = PROP_NONE;
     }
@@ -1577,7 +1657,7 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
   }
   if (lane == 0) {
     if (o.found) {
-      if (WORD) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid;
+      if (WORD) P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | o.rid | ((unsigned long long)(TRIM ? h.alt1 : 0u) << PK_ALT_SHIFT);
       if (DIRECT) atomicMin(&P.resv[o.rid], cid);
     } else {
       // a failed left search sends the chain for a new seed (apply step): k_mg_mark puts it on the needy bitmap
@@ -1690,7 +1770,13 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     return false;
   }
   // who holds the read we proposed (load in flight while the update is computed)
-  const uint32_t owner_v = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;
+  uint32_t owner_v = kind != PROP_NONE ? P.resv[h.prop_rid] : cid;
+  if (DEFER && P.alts == 2 && kind == PROP_MATCH && h.alt1 && uni_u32(owner_v) != cid) {
+    // the alternatives schedule: the first candidate went to another chain -- did pass 1 (k_alt_resolve) secure the second?
+    // Same probe, same alignment, the next read of the bin (orc_reorder_rounds_alt); the words of k_mg_mark say the same.
+    const uint32_t alt = h.alt1 - 1u;
+    if (uni_u32(P.resv[alt]) == (ALT_KEY | cid)) { h.prop_rid = alt; owner_v = cid; }
+  }
   const bool fail_path = kind == PROP_NONE && h.mode == MODE_SEARCH;
   bool do_upd = false, ureset = false, urev = false;
   uint32_t urid = 0;
@@ -2439,7 +2525,9 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_long_scan(DevParams P) {
 // ---- kernel 3: one wavefront per search -- the lowest part with a pass against the best single-read bin; the proposal
 // (as the end of search_step)
 __global__ __launch_bounds__(256) void k_long_fin(DevParams P, int direct) {
-  const int lane = threadIdx.x & 63;
+  __shared__ uint64_t s_refs[4][2][LDS_LIMBS];                                  // (the alternatives schedule: find_alt)
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][STAGE_WORDS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t npend = P.longq[0];
   for (uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6); qi < npend; qi += gridDim.x * 4) {
   const uint32_t li = uni_u32(P.longq[2 + qi]), cid = P.c0 + li;
@@ -2464,13 +2552,26 @@ __global__ __launch_bounds__(256) void k_long_fin(DevParams P, int direct) {
     h.prop_shift = wcode >> 2;
     h.prop_rev = ((wcode >> 1) & 1) | ((wcode & 1) << 1) | (cap_u ? 0u : 4u);  // rev | dict << 1 | resumable << 2
     h.prop_kind = PROP_MATCH;
+    h.alt1 = 0;
+    if (P.alts == 2) {  // the second candidate, as search_step finds it
+      if (lane < LDS_LIMBS) {
+        const int i = lane - LDS_PAD;
+        const bool in = i >= 0 && i < P.W;
+        s_refs[wv][0][lane] = in ? c->ref[i] : 0ull;
+        s_refs[wv][1][lane] = in ? c->revref[i] : 0ull;
+      }
+      wave_sync();
+      h.alt1 = uni_u32(find_alt<true>(P, &s_refs[wv][0][0] + LDS_PAD, &s_refs[wv][1][0] + LDS_PAD, h.ref_len, (int)wcode, wrid,
+                                      (lds_u32_t *)s_stage[wv], lane)) + 1u;
+      wave_sync();
+    }
   } else {
     h.prop_kind = PROP_NONE;
   }
   store_hot(c, h, lane, 2, 4);
   if (lane == 0) {
     if (found) {
-      P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid;
+      P.prop[cid] = ((unsigned long long)PK_MATCH << 32) | wrid | ((unsigned long long)h.alt1 << PK_ALT_SHIFT);
       if (direct) atomicMin(&P.resv[wrid], cid);
     } else {
       P.prop[cid] = ((unsigned long long)PK_NONE << 32) | (h.left_search ? PK_WILLNEED_BIT : 0ull);
@@ -2497,6 +2598,17 @@ __global__ void k_mg_resolve(DevParams P) {
   const int pk = (int)(pv >> 32) & 7;
   if (pk == PK_MATCH || pk == PK_SEED) atomicMin(&P.resv[(uint32_t)pv], cid);
 }
+// pass 1 of the alternatives schedule (after every pass-0 reservation of the round -- the round kernel's, k_long_fin's, and in
+// a multi-GPU pool k_mg_resolve's -- and before k_mg_mark): a chain whose first candidate went to another chain proposes
+// its second one; a read secured in pass 0 stays with its owner (ALT_KEY | chain > every chain id)
+__global__ void k_alt_resolve(DevParams P) {
+  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cid >= P.Ktot) return;
+  const unsigned long long pv = P.prop[cid];
+  if (((int)(pv >> 32) & 7) != PK_MATCH || !(pv >> PK_ALT_SHIFT)) return;
+  if (P.resv[(uint32_t)pv] == cid) return;
+  atomicMin(&P.resv[(uint32_t)(pv >> PK_ALT_SHIFT) - 1u], ALT_KEY | cid);
+}
 // winners claim their read on every replica; the lowest seed of the round moves the cursor; the needy bitmap
 // (+ its per-2048-chain counts) for the seed ranking of the NEXT round's k_search: chains whose left search just
 // failed (k_apply sends them for a seed) and chains whose seed went to a lower chain id; chains still running
@@ -2511,8 +2623,12 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
     alive = pk != PK_DONE;
     if (alive && cid >= P.c0 && cid - P.c0 < P.K) cls = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv & PK_WILLNEED_BIT) ? 3 : 0) : 3;
     if (pk == PK_MATCH || pk == PK_SEED) {
-      const uint32_t rid = (uint32_t)pv;
-      const bool won = P.resv[rid] == cid;
+      uint32_t rid = (uint32_t)pv;
+      bool won = P.resv[rid] == cid;
+      if (!won && pk == PK_MATCH && (pv >> PK_ALT_SHIFT)) {  // the alternatives schedule: the second candidate, secured in pass 1
+        const uint32_t alt = (uint32_t)(pv >> PK_ALT_SHIFT) - 1u;
+        if (P.resv[alt] == (ALT_KEY | cid)) { won = true; rid = alt; }
+      }
       if (won) {
         atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
         mark_dead(P, rid);
@@ -2520,7 +2636,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
         // and find_seed counts the cursor's block from the bitmap)
         if (pk == PK_MATCH) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
       }
-      if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)rid - 1;  // every seed proposed this round ends up taken
+      if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)(uint32_t)pv - 1;  // every seed proposed this round ends up taken
       needy = pk == PK_SEED && !won;
       if (pk == PK_SEED && won && cls >= 0) cls = 1;
     } else if (pk == PK_NONE) {
@@ -2865,6 +2981,7 @@ void launch_mg_resolve(hipStream_t st, const DevParams &P) {
   hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot - P.K, 256), dim3(256), 0, st, P);
 }
 void launch_mg_mark(hipStream_t st, const DevParams &P) {
+  if (P.alts == 2) hipLaunchKernelGGL(k_alt_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
   hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 }
 void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot) {

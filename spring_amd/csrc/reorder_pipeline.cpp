@@ -1270,6 +1270,12 @@ static bool dict_has_heavy_tail(const spring_reorder_ctx *ctx) {
   const uint64_t mid = (uint64_t)ctx->dict[0].mid_reads + ctx->dict[1].mid_reads, nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads;
   return nd > 0 && mid * 1000 >= nd;
 }
+// ... a quarter of them: deep coverage all over (25 600x, PhiX-like pools) -- thousands of chains sit on the same loci and
+// most proposals are lost: the alternatives schedule (opts.alternatives) pays
+static bool dict_is_contended(const spring_reorder_ctx *ctx) {
+  const uint64_t mid = (uint64_t)ctx->dict[0].mid_reads + ctx->dict[1].mid_reads, nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads;
+  return nd > 0 && mid * 4 >= nd;
+}
 static bool dict_wants_deep_kernel(const spring_reorder_ctx *ctx) {
   const uint64_t nd = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
   return nd * 100 >= nk * 115 || dict_has_heavy_tail(ctx);
@@ -1325,6 +1331,7 @@ static void fill_params(spring_reorder_ctx *ctx, DevParams &P) {
   // deep data (>= 1.3 reads per dictionary key on average: coverage of a few hundred x and up): the chain kernel
   // trims dead bin tails while it scans; opts.deep_bins = 1 / -1 forces the variant on / off (same results)
   P.deep_bins = o.deep_bins ? (o.deep_bins > 0) : dict_wants_deep_kernel(ctx);
+  if (o.alternatives == 2) P.deep_bins = 1;  // (the second candidate is found by the deep-bin variants of the round kernel)
   // ... and the next read of a chain sits at shift 0 or 1 nearly always, while every verified bin a batch holds past the
   // winner is scanned for nothing: a narrow first batch (2 + 6 + 8 + 16 shifts instead of 4 + 8 + 16: 1 600x -3 %, 6 400x
   // -4 %, 25 600x -7 %, PhiX-like -5 %; 1 + 3 + 4 + 8 + 16 the same within 1 %, 1 + 1 + 2 + 4 + 8 + 16 slower at 400x)
@@ -1419,6 +1426,20 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   DMALLOC(P.s_rec, cap * 4); DMALLOC(P.s_chunk, nchunk * sizeof(uint2));
   P.K = K; P.c0 = c0; P.Ktot = Ktot;
   P.fused = fused ? 1 : 0;
+  // candidates per match proposal (opts.alternatives): the second one travels in the proposal word beside the first
+  // (27 bits) and is resolved by k_alt_resolve in front of k_mg_mark: fused rounds, deep-bin kernel variants
+  {
+    const bool can = fused && P.deep_bins && n < ALT_MAX_READS && Ktot < ALT_KEY;
+    // (<= 0: the library's choice.  Two candidates cost a successful search one more look at its winner's bin (+10 % per round)
+    // and pay where most proposals are lost: 20 M reads, chains stage with one / two candidates: 100x 109 / 121 ms, 400x 113 /
+    // 117, 1 600x 123 / 124, 6 400x 137 / 134, 25 600x 169 / 152, PhiX-like 184 / 158, genome-like 216 / 240 -- so: pools with
+    // a quarter of the dictionary's reads in bins of >= MID_BIN entries; profiles/r05_alternatives.txt)
+    const int want = ctx->o.alternatives > 0 ? ctx->o.alternatives : (dict_is_contended(ctx) ? 2 : 1);
+    if (ctx->o.alternatives == 2 && !can)
+      return fail(SPRING_REORDER_E_ARG, "alternatives = 2 needs the fused round (no literal consensus path, fused >= 0) and a pool of fewer than %u reads", ALT_MAX_READS);
+    P.alts = (want == 2 && can) ? 2 : 1;
+    ctx->stats.alternatives = (uint64_t)P.alts;
+  }
   P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
   // Four chains per wavefront pay when a launch holds several wavefronts per slot (5 120 slots of four chains): with
   // fewer chains the GPU is not full and every wavefront waits for the slowest of its four.  25x, chains stage, four

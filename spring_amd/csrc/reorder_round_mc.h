@@ -851,7 +851,8 @@ __device__ __forceinline__ void round_mc_body(const DevParams &P) {
     h.prev = q1.x; h.first_rid = q1.y; h.n_emit = q1.z; h.n_single = q1.w;
     h.s_slot = q2.x; h.num_reads_thr = q2.y; h.num_unmatched_past = q2.z; h.prop_rid = q2.w;
     h.flags = q3.x;
-    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    h.alt1 = 0;  // (no alternatives in this kernel)
+    h.pad[0] = h.pad[1] = 0;
   }
   wave_sync();
   if (h.done) {

@@ -49,6 +49,7 @@ class ReorderOpts:
     long_split: int = 0       # long searches: chunks of 64 bin entries per part (0 = default 256, -1 = never cut a search into parts)
     debug: bool = False       # stage timings on stderr
     out_writers: int = 0      # call_reorder: threads writing the output files (0 = from the host's thread count)
+    alternatives: int = 0     # candidates per match proposal: 1, 2 (a loser takes the next passing read of the bin), 0 = library's choice
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
 
     def to_c(self):
@@ -71,6 +72,7 @@ class ReorderOpts:
         o.long_min, o.long_blocks, o.debug = self.long_min, self.long_blocks, int(self.debug)
         o.long_split, o.entry_flags = self.long_split, self.entry_flags
         o.out_writers = self.out_writers
+        o.alternatives = self.alternatives
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d

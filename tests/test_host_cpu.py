@@ -117,13 +117,13 @@ def test_ctypes_mirrors_match_the_c_header(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "spring_reorder.h"\n'
                    'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(spring_reorder_opts), '
-                   'offsetof(spring_reorder_opts, long_budget), offsetof(spring_reorder_opts, out_writers), '
-                   'sizeof(spring_reorder_stats), offsetof(spring_reorder_stats, long_splits), '
+                   'offsetof(spring_reorder_opts, long_budget), offsetof(spring_reorder_opts, alternatives), '
+                   'sizeof(spring_reorder_stats), offsetof(spring_reorder_stats, alternatives), '
                    'offsetof(spring_reorder_stats, deep_pool)); return 0; }\n')
     exe = tmp_path / "abi"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    want = [C.sizeof(_lib.Opts), _lib.Opts.long_budget.offset, _lib.Opts.out_writers.offset,
-            C.sizeof(_lib.Stats), _lib.Stats.long_splits.offset, _lib.Stats.deep_pool.offset]
+    want = [C.sizeof(_lib.Opts), _lib.Opts.long_budget.offset, _lib.Opts.alternatives.offset,
+            C.sizeof(_lib.Stats), _lib.Stats.alternatives.offset, _lib.Stats.deep_pool.offset]
     assert got == want, (got, want)

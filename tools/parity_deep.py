@@ -30,16 +30,17 @@ for a in sys.argv[1:]:
             st.run()
             outs.append((st.streams(), st.stats()))
     K = outs[0][1]["chains"]
-    assert outs[1][1]["chains"] == K
+    A = int(outs[0][1]["alternatives"])  # candidates per proposal the library chose (2 on contended pools)
+    assert outs[1][1]["chains"] == K and outs[1][1]["alternatives"] == A
     t0 = time.time()
-    want = po.reorder_rounds(read, ln, L, K, 8)
+    want = po.reorder_rounds(read, ln, L, K, 8, alternatives=A)
     for (got, gst), what in zip(outs, ("production build", "counting build")):
         for k in KEYS:
             assert np.array_equal(got[k], want[k]), (what, k)
         assert np.array_equal(got["tid_off"], want["tid_off"]), what
     for k in ("probes", "keyok", "cands", "hits", "unmatched"):
         assert outs[1][1][k] == want["stats"][k], (k, outs[1][1][k], want["stats"][k])
-    print("n=%d L=%d genome=%d (%.0fx) K=%d: production and counting builds identical to the rounds oracle (%.0f s of oracle); "
+    print("n=%d L=%d genome=%d (%.0fx) K=%d, %d candidate(s) per proposal: production and counting builds identical to the rounds oracle (%.0f s of oracle); "
           "rounds %d, lost proposals %d, %.1f candidate comparisons per read, %d searches finished by k_long (%d split), production chains stage %.1f ms"
-          % (n, L, G, n * L / G, K, time.time() - t0, outs[0][1]["rounds"], outs[0][1]["lost"],
+          % (n, L, G, n * L / G, K, A, time.time() - t0, outs[0][1]["rounds"], outs[0][1]["lost"],
              want["stats"]["cands"] / n, outs[0][1]["long_searches"], outs[0][1]["long_splits"], outs[0][1]["ms_chains"]), flush=True)
