@@ -486,6 +486,8 @@ def main():
             # a genome with the repeat structure of a real one (SPRING_SYNTH_GENOMIC: Zipf-sized repeat families, tandem
             # repeats, low-complexity runs; 25x): bins of thousands of reads beside single-read bins
             pools.append((ns, 0x20000000, max(ns * L // 25, 4 * L), "genome-like 25x (repeat families, tandem repeats)"))
+            if n >= 5 * ns:  # ... and at the headline's size (its repeat families grow with the genome: bins of tens of thousands of reads)
+                pools.append((n, 0x20000000, max(n * L // 25, 4 * L), "genome-like 25x at the headline size"))
             for pn, pflag, pG, name in pools:
                 pb = L_.spring_synth_dna_bytes(pn, L)
                 tb = torch.empty(pb, dtype=torch.uint8, device="cuda")
@@ -501,6 +503,7 @@ def main():
                     s.close()
                 sweep.append({"pool": name, "reads": pn, "Mreads_per_s": round(pn / t1 / 1e6, 1), "chains": ps["chains"],
                               "rounds": ps["rounds"], "lost_proposals": ps["lost"], "searches_by_k_long": ps["long_searches"],
+                              "split_searches": ps["long_splits"], "candidates_per_proposal": ps["alternatives"],
                               "chains_stage_ms": round(ps["ms_chains"], 1), "dictionary": {"deep": bool(ps["deep_pool"] & 1), "heavy_tail": bool(ps["deep_pool"] & 2)}})
                 del tb
             out["coverage_sweep"] = {"read_len": L, "err_ppm": a.err_ppm, "pools": sweep,

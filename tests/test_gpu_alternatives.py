@@ -101,7 +101,7 @@ def test_library_choice():
     contended pool (a quarter of the dictionary's reads in bins of >= 64 entries), one elsewhere; stats.alternatives says
     which."""
     sa = _sa()
-    for G, expect in ((400, 2), (100_000, 1), (6_000_000, 1)):
+    for G, expect in ((200, 2), (100_000, 1), (6_000_000, 1)):
         n, L, K = 40_000, 150, 200
         with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, alternatives=-1)) as st:
             st.load_synth(n, L, G, 23, 10000)
