@@ -2970,7 +2970,7 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
     if (4 * P.maxshift <= 512) hipLaunchKernelGGL(k_long_list<8>, dim3(std::min<uint32_t>(P.K, 3 * lb)), dim3(512), 0, st, P);
     else hipLaunchKernelGGL(k_long_list<LONG_WAVES>, dim3(std::min<uint32_t>(P.K, lb)), dim3(64 * LONG_WAVES), 0, st, P);
     hipLaunchKernelGGL(k_long_scan, dim3(std::min<uint32_t>(P.K * 4, 5 * lb)), dim3(64 * SCAN_WAVES), 0, st, P);
-    hipLaunchKernelGGL(k_long_fin, dim3(std::min<uint32_t>((P.K + 3) / 4, 64u)), dim3(256), 0, st, P, 1);
+    hipLaunchKernelGGL(k_long_fin, dim3(std::min<uint32_t>((P.K + 3) / 4, lb)), dim3(256), 0, st, P, 1);  // (a wavefront per search: 4 lb in flight)
   } else if (P.Lpad <= 192) RCALL(3); else RCALL(8);
 #undef RCALL2
 #undef RCALL

@@ -79,6 +79,19 @@ def test_fuzz_gpu_equals_oracle(block):
         assert np.array_equal(got2["tid_off"], want["tid_off"]), ("seed", seed, "no-stats", kw)
         for k in ("lost", "unmatched"):
             assert got2["stats"][k] == want["stats"][k], ("seed", seed, "no-stats", kw, k)
+        # two candidates per proposal (the alternatives schedule: deep-bin kernel variants, k_alt_resolve; K = 1 stays serial),
+        # production or counting build, long searches handed over after 1 / 2 / the default number of passes or never, cut
+        # into parts of 1 / 3 chunks or the default
+        if seed % 2 == 0:
+            kw3 = dict(alternatives=2, collect_stats=bool(rng.integers(0, 2)), long_budget=int(rng.choice([1, 2, 0, -1])),
+                       long_split=int(rng.choice([0, 1, 3])))
+            want3 = po.reorder_rounds(read, ln, L, K, T, alternatives=2)
+            got3 = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, **kw3))
+            for k in KEYS:
+                assert np.array_equal(got3[k], want3[k]), ("seed", seed, "two candidates", kw3, "n", n, "L", L, "K", K, "T", T, k)
+            assert np.array_equal(got3["tid_off"], want3["tid_off"]), ("seed", seed, "two candidates", kw3)
+            for k in ("lost", "unmatched") + (("probes", "keyok", "cands", "hits") if kw3["collect_stats"] else ()):
+                assert got3["stats"][k] == want3["stats"][k], ("seed", seed, "two candidates", kw3, k)
 
 
 @pytest.mark.parametrize("block", range(2))
