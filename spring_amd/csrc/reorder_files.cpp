@@ -35,6 +35,10 @@
 #include "spring_encoder.h"
 #include "spring_reorder.h"
 
+#ifndef SR_FILES_EXP
+#define SR_FILES_EXP 0
+#endif
+
 namespace sr {
 int fail(int code, const char *fmt, ...);
 }
@@ -175,9 +179,10 @@ struct FilePair {
 
 // ---- output: the streams go device -> pinned slot -> file.  Every output file belongs to one writer thread (its
 // slots are written in order, straight from the pinned memory with write / writev: no stdio copy); the files are dealt
-// out over the writers largest first, and the submitting thread hands out the slots ROUND ROBIN over the writers, so
-// that all of them work from the first copy on (round 4 submitted tid by tid: the first writer's backlog held most of
-// the ring while the others waited -- 8.3 GB/s for 5.45 GB; profiles/r05_files.txt).
+// out over the writers largest first, and the submitting thread hands the slots out ACROSS the writers -- the next one to
+// the writer with the most bytes still to come, at most three in flight per writer -- so that all of them work from the
+// first copy on and finish together (round 4 submitted tid by tid: the first writer's backlog held most of the ring
+// while the others waited -- 8.3 GB/s for 5.45 GB; profiles/r05_files.txt).
 // (the "copy done" event of a slot is made per copy, under the device whose stream records it -- an event belongs to the
 // device that was current when it was created, and the slots of this ring serve every rank of a multi-GPU call -- and
 // is destroyed by the writer thread once it has waited for it)
@@ -219,16 +224,106 @@ class Ring {  // a bounded set of pinned slots, cut from the library's cached pi
   std::vector<Slot> free_;
 };
 
+// Events are REUSED: the first hipEventSynchronize on a freshly created event costs ~0.3 ms on this stack (650 fresh events,
+// each recorded on an idle stream and waited for: 206 ms; the same with events that had been used before: 9 ms --
+// tools/r5 notes in profiles/r05_files.txt), and an output of 5.45 GB is 688 copies.  An event belongs to the device that was
+// current when it was created, hence one free list per device.
+class EventPool {
+ public:
+  ~EventPool() { for (auto &v : free_) for (hipEvent_t e : v.second) (void)hipEventDestroy(e); }
+  hipEvent_t get(int dev) {  // (device `dev` is current)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto &v = list(dev);
+      if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+  }
+  void put(int dev, hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(mu_);
+    list(dev).push_back(e);
+  }
+ private:
+  std::vector<hipEvent_t> &list(int dev) {
+    for (auto &v : free_) if (v.first == dev) return v.second;
+    free_.push_back({dev, {}});
+    return free_.back().second;
+  }
+  std::mutex mu_;
+  std::vector<std::pair<int, std::vector<hipEvent_t>>> free_;
+};
+
+// "the copy into slot k has landed": set by the ONE thread per stream that waits for the copies' events in order, read by
+// the writers.  (Round 5, first version: every writer called hipEventSynchronize for its own slots -- 24 threads inside
+// the runtime beside the submitting one -- and the copies of a 5.45 GB output ran at 23 GB/s on a link that does 52:
+// the writers spent 130-150 ms of a 245 ms leg waiting for copies, profiles/r05_files.txt.)
+struct Done {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<char> f;
+  int bad = 0;
+  void set(size_t k, bool ok) {
+    { std::lock_guard<std::mutex> lk(mu); f[k] = 1; if (!ok) bad = 1; }
+    cv.notify_all();
+  }
+  bool wait(size_t k) {  // false: a copy failed
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return f[k] != 0; });
+    return bad == 0;
+  }
+};
+class CopyWaiter {  // one per stream that copies are issued on
+ public:
+  CopyWaiter(Done *d, EventPool *pool, int dev) : done_(d), pool_(pool), dev_(dev) {}
+  void start() { th_ = std::thread([this] { run(); }); }
+  void push(hipEvent_t ev, size_t k) {
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back({ev, k}); }
+    cv_.notify_one();
+  }
+  void finish() {
+    if (!th_.joinable()) return;
+    push(nullptr, (size_t)-1);
+    th_.join();
+  }
+  ~CopyWaiter() { finish(); }
+ private:
+  void run() {
+    for (;;) {
+      std::pair<hipEvent_t, size_t> e;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        e = q_.front();
+        q_.pop_front();
+      }
+      if (!e.first) return;
+      const bool ok = hipEventSynchronize(e.first) == hipSuccess;
+      pool_->put(dev_, e.first);
+      done_->set(e.second, ok);
+    }
+  }
+  Done *done_;
+  EventPool *pool_;
+  int dev_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::pair<hipEvent_t, size_t>> q_;
+};
+
 struct Msg {
   enum Kind { OPEN_RAW, OPEN_GZ, DATA, BYTES, CLOSE, STOP } kind = STOP;
   std::string path;
   Slot slot;
   size_t len = 0;
+  size_t seq = 0;              // DATA: index of the copy's "landed" flag (Done)
   std::vector<uint8_t> bytes;  // BYTES: small host data
 };
 class Writer {
  public:
-  explicit Writer(Ring *ring) : ring_(ring) {}
+  Writer(Ring *ring, Done *done) : ring_(ring), done_(done) {}
   void start() { th_ = std::thread([this] { run(); }); }
   void push(Msg &&m) {
     { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(m)); }
@@ -244,6 +339,9 @@ class Writer {
   ~Writer() { finish(); }
   int rc = 0;
   std::string err;
+  std::atomic<int> inflight{0};  // slots queued to this writer and not yet written (the submitter's pacing)
+  double t_wait = 0, t_put = 0, t_idle = 0;  // seconds: waiting for copies / writing / waiting for messages (opts.debug)
+  size_t nslots = 0;
  private:
   void bad(const char *what, const std::string &path) {
     if (!rc) { rc = SPRING_REORDER_E_IO; err = std::string(what) + " " + path + ": " + strerror(errno); }
@@ -288,10 +386,12 @@ class Writer {
     for (;;) {
       Msg m;
       {
+        const auto t0 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return !q_.empty(); });
         m = std::move(q_.front());
         q_.pop_front();
+        t_idle += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       switch (m.kind) {
         case Msg::STOP: if (fd_ >= 0) close(fd_); return;
@@ -306,12 +406,19 @@ class Writer {
           }
           break;
         }
-        case Msg::DATA:
-          if (hipEventSynchronize(m.slot.ev) != hipSuccess && !rc) { rc = SPRING_REORDER_E_HIP; err = "device to host copy failed"; }
-          (void)hipEventDestroy(m.slot.ev);
+        case Msg::DATA: {
+          const auto ta = std::chrono::steady_clock::now();
+          if (!done_->wait(m.seq) && !rc) { rc = SPRING_REORDER_E_HIP; err = "device to host copy failed"; }
+          const auto tb = std::chrono::steady_clock::now();
+#if SR_FILES_EXP != 1  // (experiment builds: 1 = the writers drop the data, 2 = no device-to-host copies; what bounds the output leg)
           put((const uint8_t *)m.slot.pin, m.len);
+#endif
+          const auto tc = std::chrono::steady_clock::now();
+          t_wait += std::chrono::duration<double>(tb - ta).count(); t_put += std::chrono::duration<double>(tc - tb).count(); nslots++;
           ring_->release(m.slot);
+          inflight.fetch_sub(1, std::memory_order_release);
           break;
+        }
         case Msg::BYTES: put(m.bytes.data(), m.bytes.size()); break;
         case Msg::CLOSE:
           if (fd_ >= 0 && gz_ && !rc) {
@@ -328,6 +435,7 @@ class Writer {
     }
   }
   Ring *ring_;
+  Done *done_;
   std::thread th_;
   std::mutex mu_;
   std::condition_variable cv_;
@@ -349,7 +457,10 @@ struct OutFile {
   size_t total() const { size_t t = bytes.size(); for (const OutSeg &s : segs) t += s.n; return t; }
 };
 // the next slot of device bytes of file f (cursor: segment si, offset so) -> writer w.  0, or a failure code
-int w_next_slot(Writer &w, Ring &ring, const OutFile &f, size_t &si, size_t &so) {
+struct SubmitClock { double t_ring = 0, t_copy = 0, t_event = 0; };  // seconds the submitting thread spent per step (opts.debug)
+static inline double secs_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+int w_next_slot(Writer &w, Ring &ring, CopyWaiter &cw, EventPool &evs, size_t seq, bool *sent, const OutFile &f, size_t &si, size_t &so, SubmitClock &clk) {
+  *sent = false;
   while (si < f.segs.size() && so >= f.segs[si].n) { si++; so = 0; }
   if (si >= f.segs.size()) return 0;
   const OutSeg &s = f.segs[si];
@@ -358,24 +469,38 @@ int w_next_slot(Writer &w, Ring &ring, const OutFile &f, size_t &si, size_t &so)
   Msg m;
   m.kind = Msg::DATA;
   m.len = len;
+  auto tk = std::chrono::steady_clock::now();
   if (!ring.acquire(&m.slot)) return fail(SPRING_REORDER_E_HIP, "cannot pin a staging chunk for the output streams");
-  if (hipEventCreateWithFlags(&m.slot.ev, hipEventDisableTiming) != hipSuccess) {  // (device s.dev is current)
+  clk.t_ring += secs_since(tk); tk = std::chrono::steady_clock::now();
+  if (!(m.slot.ev = evs.get(s.dev))) {  // (device s.dev is current)
     ring.release(m.slot);
     return fail(SPRING_REORDER_E_HIP, "cannot create an event on device %d", s.dev);
   }
-  if (hipMemcpyAsync(m.slot.pin, s.d + so, len, hipMemcpyDeviceToHost, s.st) != hipSuccess ||
-      hipEventRecord(m.slot.ev, s.st) != hipSuccess) {
+  clk.t_event += secs_since(tk); tk = std::chrono::steady_clock::now();
+  hipError_t ce = hipSuccess;
+#if SR_FILES_EXP != 2
+  ce = hipMemcpyAsync(m.slot.pin, s.d + so, len, hipMemcpyDeviceToHost, s.st);
+#endif
+  clk.t_copy += secs_since(tk); tk = std::chrono::steady_clock::now();
+  const hipError_t re = hipEventRecord(m.slot.ev, s.st);
+  clk.t_event += secs_since(tk);
+  if (ce != hipSuccess || re != hipSuccess) {
     (void)hipStreamSynchronize(s.st);  // (a copy that did start must not land in a slot handed to someone else)
-    (void)hipEventDestroy(m.slot.ev);
+    evs.put(s.dev, m.slot.ev);
     ring.release(m.slot);
     return fail(SPRING_REORDER_E_HIP, "device to host copy of an output stream failed");
   }
+  m.seq = seq;
+  cw.push(m.slot.ev, seq);
+  m.slot.ev = nullptr;  // (the waiter's now)
+  w.inflight.fetch_add(1, std::memory_order_relaxed);
   w.push(std::move(m));
   so += len;
+  *sent = true;
   return 0;
 }
 // every file of `files` written by `nw` writer threads
-int write_out_files(const std::vector<OutFile> &files, int nw) {
+int write_out_files(const std::vector<OutFile> &files, int nw, bool dbg) {
   if (!crc_ready) crc_init();
   nw = std::max(1, std::min(nw, (int)files.size()));
   // files -> writers: largest first, each to the writer with the least bytes so far
@@ -389,47 +514,109 @@ int write_out_files(const std::vector<OutFile> &files, int nw) {
     load[w] += files[i].total() + 4096;
   }
   Ring ring(16);  // 16 x 32 MiB = 64 slots in flight at most
+  // one flag per copy, one waiting thread per stream the copies are issued on (a multi-GPU call: one per rank)
+  size_t ncopies = 0;
+  std::vector<hipStream_t> streams;
+  std::vector<int> sdev;
+  for (const OutFile &f : files)
+    for (const OutSeg &g : f.segs) {
+      ncopies += (g.n + OUT_SLOT - 1) / OUT_SLOT;
+      if (std::find(streams.begin(), streams.end(), g.st) == streams.end()) { streams.push_back(g.st); sdev.push_back(g.dev); }
+    }
+  Done done;
+  done.f.assign(ncopies + 1, 0);
+  EventPool evs;  // (declared before the waiters: they hand their events back to it until they are joined)
+  std::vector<std::unique_ptr<CopyWaiter>> CW;
+  for (size_t i = 0; i < std::max<size_t>(streams.size(), 1); i++) CW.emplace_back(new CopyWaiter(&done, &evs, sdev.empty() ? 0 : sdev[i]));
   std::vector<std::unique_ptr<Writer>> W;
-  for (int i = 0; i < nw; i++) W.emplace_back(new Writer(&ring));
+  for (int i = 0; i < nw; i++) W.emplace_back(new Writer(&ring, &done));
   try {
+    for (auto &c : CW) c->start();
     for (auto &w : W) w->start();
   } catch (const std::system_error &) {
     return fail(SPRING_REORDER_E_IO, "cannot start the writer threads");
   }
-  struct Cur { size_t fi = 0, si = 0, so = 0; bool open = false; };
+  size_t seq = 0;
+  // The next slot goes to the writer with the MOST BYTES STILL TO COME among those with fewer than three slots in flight:
+  // the copies of all writers share one link (50 GB/s), and handed out in turn every writer gets the same share -- the
+  // one with the largest file (temp.dna.singleton, 0.5 GB of 5.45 at 100 M reads) is then fed at a twenty-fourth of it
+  // until the small files are done, and the call ends when it does.  Longest first, all writers finish together.
+  struct Cur { size_t fi = 0, si = 0, so = 0; bool open = false; size_t left = 0; };
   std::vector<Cur> cur((size_t)nw);
+  for (int w = 0; w < nw; w++) cur[(size_t)w].left = load[(size_t)w];
   int ret = 0;
-  for (bool any = true; any && !ret;) {
-    any = false;
-    for (int w = 0; w < nw && !ret; w++) {
-      Cur &c = cur[(size_t)w];
-      if (c.fi >= mine[(size_t)w].size()) continue;
+  SubmitClock clk;
+  double t_pace = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  constexpr int MAX_INFLIGHT = 3;
+  for (;;) {
+    int w = -1;
+    bool any = false;
+    for (int k = 0; k < nw; k++) {
+      const Cur &c = cur[(size_t)k];
+      if (c.fi >= mine[(size_t)k].size()) continue;
       any = true;
-      const OutFile &f = files[mine[(size_t)w][c.fi]];
-      if (!c.open) {
-        Msg m;
-        m.kind = f.gz ? Msg::OPEN_GZ : Msg::OPEN_RAW;
-        m.path = f.path;
-        W[(size_t)w]->push(std::move(m));
-        if (!f.bytes.empty()) {
-          Msg b;
-          b.kind = Msg::BYTES;
-          b.bytes = f.bytes;
-          W[(size_t)w]->push(std::move(b));
-        }
-        c.open = true; c.si = 0; c.so = 0;
+      if (W[(size_t)k]->inflight.load(std::memory_order_acquire) >= MAX_INFLIGHT) continue;
+      if (w < 0 || c.left > cur[(size_t)w].left) w = k;
+    }
+    if (!any) break;
+    if (w < 0) {  // (every writer has its three slots)
+      const auto tp0 = std::chrono::steady_clock::now();
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+      t_pace += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+      continue;
+    }
+    Cur &c = cur[(size_t)w];
+    const OutFile &f = files[mine[(size_t)w][c.fi]];
+    if (!c.open) {
+      Msg m;
+      m.kind = f.gz ? Msg::OPEN_GZ : Msg::OPEN_RAW;
+      m.path = f.path;
+      W[(size_t)w]->push(std::move(m));
+      if (!f.bytes.empty()) {
+        Msg b;
+        b.kind = Msg::BYTES;
+        b.bytes = f.bytes;
+        W[(size_t)w]->push(std::move(b));
       }
-      ret = w_next_slot(*W[(size_t)w], ring, f, c.si, c.so);
-      while (c.si < f.segs.size() && c.so >= f.segs[c.si].n) { c.si++; c.so = 0; }
-      if (c.si >= f.segs.size()) {
-        Msg m;
-        m.kind = Msg::CLOSE;
-        W[(size_t)w]->push(std::move(m));
-        c.fi++; c.open = false;
-      }
+      c.open = true; c.si = 0; c.so = 0;
+    }
+    const size_t so0 = c.so, si0 = c.si;
+    {
+      size_t si2 = c.si, so2 = c.so;
+      while (si2 < f.segs.size() && so2 >= f.segs[si2].n) { si2++; so2 = 0; }
+      const size_t wi = si2 < f.segs.size() ? (size_t)(std::find(streams.begin(), streams.end(), f.segs[si2].st) - streams.begin()) : 0;
+      bool sent_one = false;
+      if ((ret = w_next_slot(*W[(size_t)w], ring, *CW[wi], evs, seq, &sent_one, f, c.si, c.so, clk))) break;
+      if (sent_one) seq++;
+    }
+    const size_t sent = c.si == si0 ? c.so - so0 : c.so;  // (w_next_slot skips exhausted segments first)
+    c.left -= std::min(c.left, sent);
+    while (c.si < f.segs.size() && c.so >= f.segs[c.si].n) { c.si++; c.so = 0; }
+    if (c.si >= f.segs.size()) {
+      Msg m;
+      m.kind = Msg::CLOSE;
+      W[(size_t)w]->push(std::move(m));
+      c.fi++; c.open = false;
+      c.left -= std::min<size_t>(c.left, 4096);
     }
   }
+  const auto t_sub = std::chrono::steady_clock::now();
+  if (ret) {  // copies that were issued still land (their flags are set); the writers drain their queues
+    for (auto &c : CW) c->finish();
+  }
   for (auto &w : W) w->finish();
+  for (auto &c : CW) c->finish();
+  if (dbg) {
+    double tw = 0, tp = 0, ti = 0, mx = 0, mxp = 0;
+    size_t ns = 0;
+    for (auto &w : W) { tw += w->t_wait; tp += w->t_put; ti += w->t_idle; ns += w->nslots; mx = std::max(mx, w->t_wait + w->t_put); mxp = std::max(mxp, w->t_put); }
+    fprintf(stderr, "[files] %d writers, %zu slots: submitted after %.1f ms (waiting for a free writer %.1f ms), joined %.1f ms later; per writer on average "
+            "%.1f ms waiting for copies, %.1f ms writing, %.1f ms without a message; busiest writer %.1f ms (most time writing: %.1f ms); the submitting thread: %.1f ms for a free slot, "
+            "%.1f ms in hipMemcpyAsync, %.1f ms in event calls\n", nw, ns,
+            std::chrono::duration<double, std::milli>(t_sub - t_begin).count(), 1e3 * t_pace,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_sub).count(), 1e3 * tw / nw, 1e3 * tp / nw, 1e3 * ti / nw, 1e3 * mx, 1e3 * mxp, 1e3 * clk.t_ring, 1e3 * clk.t_copy, 1e3 * clk.t_event);
+  }
   if (ret) return ret;
   for (auto &w : W) if (w->rc) return fail(w->rc, "%s", w->err.c_str());
   return 0;
@@ -658,7 +845,7 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
     const unsigned hw = std::thread::hardware_concurrency();
     const int nw = o.out_writers > 0 ? o.out_writers : (int)std::max(4u, std::min(24u, hw ? hw / 4 : 8u));
     lap("emit temp.dna");
-    if ((r = write_out_files(files, nw))) return r;
+    if ((r = write_out_files(files, nw, dbg))) return r;
     lap("D2H + write files");
     // the stage consumes its inputs (reorder.h:232,241) -- once its outputs exist: a failed call leaves them in place
     // Unlinking a file whose pages sit in the page cache frees them page by page (0.3 s for the 4 GB of 100 M reads on
