@@ -98,6 +98,16 @@ typedef struct {
                              PhiX-like pools: -10 ... -14 % of the chain stage) --, else 1 (a second candidate costs every
                              successful search another look at its bin).  Needs fused rounds and fewer than 2^27 - 1 reads; 2
                              on a shallower pool runs the deep-bin kernel variant */
+  int32_t phases;         /* the chain schedule.  1: all chains advance in lock-step rounds (specification:
+                             orc_reorder_rounds).  2: the chains run as two groups whose rounds alternate -- one group's round kernel
+                             runs beside the other group's, so the chip is never left draining between rounds (specification:
+                             orc_reorder_rounds_ph; -19 % of the chain stage on 100 M x 150 bp).  A group searches on the pool as it
+                             was after its own last round and loses a read the other group took in between; group 0 takes its
+                             contig seeds from the upper half of the read ids, group 1 from the lower half.  The OUTPUT DEPENDS on
+                             it for num_chains > 1 (both are legal `-t K` interleavings).  0 = the library's choice, reported in
+                             stats.phases: 2 where the four-chains-per-wavefront round kernel runs on one GPU with at least 49 152
+                             chains, else 1.  2 needs that kernel (shallow dictionary, no work counters, one GPU), at least 4 096
+                             chains and fewer than 2^31 reads */
 } spring_reorder_opts;
 
 typedef struct {
@@ -123,6 +133,7 @@ typedef struct {
   uint64_t table_marked_lines; /* ... and this many of its lines were over-subscribed: their keys live at the redirect address */
   uint64_t long_splits;    /* long searches that were split into parts over several blocks (k_long) */
   uint64_t alternatives;   /* candidates per match proposal the chain phase ran with (opts.alternatives, or the library's choice) */
+  uint64_t phases;         /* chain groups the chain phase ran with (opts.phases, or the library's choice) */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);

@@ -986,6 +986,223 @@ int orc_reorder_rounds_alt(const uint64_t *read, const uint16_t *len, uint32_t n
   return 0;
 }
 
+/* -------------------------------------------------- K-chain schedule with two chain groups (opts.phases = 2)
+ *
+ * The rounds schedule above leaves the GPU draining between rounds (every chain waits for the slowest of the round).
+ * Here the chains form two groups, [0, Kh) and [Kh, K) with Kh = K/2 rounded up to a multiple of 2048, whose rounds
+ * ALTERNATE: half-step h belongs to group h & 1.  In its half-step a group does what a round does above, with two
+ * differences that make its search independent of the other group's half-step in front of it (so that on the GPU the
+ * two can run side by side):
+ *   - phase A looks at the pool as it was after the group's OWN last half-step (view[g] = the truth after half-step
+ *     h - 2), not at the other group's claims of half-step h - 1;
+ *   - phase B resolves the group's proposals among themselves (lowest chain id) AND against the truth: a read the other
+ *     group claimed in half-step h - 1 is lost (the chain retries, as after losing to a lower chain id).
+ *   Seeds: group 0 takes the (r+1)-th highest untaken read of [nmid, n) at or below its cursor, group 1 of [0, nmid),
+ *   nmid = n/2 rounded down to a multiple of 4096, r = the chain's rank among its group's seed-needing chains; a group
+ *   whose range is used up lets its chains finish (reorder.h:593-599) while the other carries on.
+ * One candidate per proposal.  Every read is still claimed exactly once, by a chain whose search saw it untaken and
+ * within Hamming distance: a legal interleaving of the reference's `-t K` run like the rounds schedule.
+ */
+static void ph_apply(rctx_t *x, chain_t *c, const uint64_t *read, const uint16_t *len, int L, int W, orc_stats *st) {
+  if (c->prop_kind == PROP_MATCH) {
+    const int shift = c->prop_shift;
+    c->retrying = 0;
+    c->current = c->prop_rid;
+    int ref_len_old = c->c.ref_len;
+    updaterefcount(read + (size_t)c->current * W, &c->c, 0, c->prop_rev, shift, len[c->current], L, W, st);
+    char rcch;
+    if (!c->prop_rev) { /* reorder.h:490-497,:508 */
+      if (!c->left_search) {
+        c->cur_read_pos = c->ref_pos + shift;
+        c->ref_pos = c->cur_read_pos;
+      } else {
+        c->cur_read_pos = c->ref_pos + ref_len_old - shift - len[c->current];
+        c->ref_pos = c->ref_pos + ref_len_old - shift - c->c.ref_len;
+      }
+      rcch = c->left_search ? 'r' : 'd';
+    } else { /* reorder.h:528-535,:546 */
+      if (!c->left_search) {
+        c->cur_read_pos = c->ref_pos + ref_len_old + shift - len[c->current];
+        c->ref_pos = c->ref_pos + ref_len_old + shift - c->c.ref_len;
+      } else {
+        c->cur_read_pos = c->ref_pos - shift;
+        c->ref_pos = c->cur_read_pos;
+      }
+      rcch = c->left_search ? 'd' : 'r';
+    }
+    if (c->prev_unmatched) ob_push(&c->ob, (uint32_t)c->prev, 'd', '0', 0, len[c->prev]);
+    ob_push(&c->ob, (uint32_t)c->current, rcch, '1', c->cur_read_pos, len[c->current]);
+    c->prev_unmatched = 0;
+  } else if (c->prop_kind == PROP_SEED) { /* reorder.h:580-587,:600-613 */
+    c->current = c->prop_rid;
+    c->unmatched++;
+    updaterefcount(read + (size_t)c->current * W, &c->c, 1, 0, 0, len[c->current], L, W, st);
+    c->ref_pos = 0; c->cur_read_pos = 0;
+    if (c->prev_unmatched) ob_push_s(&c->ob, (uint32_t)c->prev);
+    c->prev_unmatched = 1;
+    c->first_rid = c->current;
+    c->prev = c->current;
+    c->mode = MODE_SEARCH;
+  } else if (c->mode == MODE_SEARCH) { /* search failed (reorder.h:559-575) */
+    c->retrying = 0;
+    c->num_unmatched_past_1M_thr++;
+    if (!c->left_search) {
+      c->left_search = 1;
+      updaterefcount(read + (size_t)c->first_rid * W, &c->c, 1, 1, 0, len[c->first_rid], L, W, st);
+      c->ref_pos = 0; c->cur_read_pos = 0;
+    } else {
+      c->left_search = 0;
+      c->mode = MODE_NEED_SEED;
+    }
+  }
+  (void)x;
+}
+
+uint32_t orc_phase_split(uint32_t K) { return (uint32_t)((((uint64_t)K / 2 + 2047) / 2048) * 2048); }
+
+int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
+                          int num_thr, orc_out *out, orc_stats *st) {
+  const uint32_t Kh = orc_phase_split(K), nmid = (n / 2) & ~4095u;
+  if (K < 4096 || Kh >= K || num_thr <= 0 || nmid == 0) return -1;
+  rctx_t x;
+  memset(&x, 0, sizeof(x));
+  memset(st, 0, sizeof(*st));
+  x.read = read; x.len = len; x.n = n; x.L = L; x.W = orc_limbs(L); x.maxshift = L / 2; x.st = st;
+  const int W = x.W;
+  int s[2], e[2];
+  orc_dict_windows(L, s, e);
+  for (int l = 0; l < 2; l++) { x.dict[l].start = s[l]; x.dict[l].end = e[l]; }
+  for (int l = 0; l < 2; l++) dict_build(&x.dict[l], read, len, n, W);
+  uint8_t *truth = (uint8_t *)calloc(n, 1), *view[2];
+  view[0] = (uint8_t *)calloc(n, 1); view[1] = (uint8_t *)calloc(n, 1);
+  uint32_t *resv[2];
+  for (int g = 0; g < 2; g++) { resv[g] = (uint32_t *)malloc(sizeof(uint32_t) * n); memset(resv[g], 0xff, sizeof(uint32_t) * n); }
+  chain_t *ch = (chain_t *)calloc(K, sizeof(chain_t));
+  uint32_t *seedlist = (uint32_t *)malloc(sizeof(uint32_t) * K);
+  uint32_t *won[2], nwon[2] = {0, 0}; /* reads claimed in the group's last half-step */
+  won[0] = (uint32_t *)malloc(sizeof(uint32_t) * K); won[1] = (uint32_t *)malloc(sizeof(uint32_t) * K);
+  const uint32_t glo[2] = {0, Kh}, ghi[2] = {Kh, K};
+  const int64_t slo[2] = {(int64_t)nmid, 0};
+  int64_t cursor[2] = {(int64_t)n - 1, (int64_t)nmid - 1};
+  uint32_t alive = 0;
+
+  uint32_t firstread = 0;
+  for (uint32_t i = 0; i < K; i++) { /* reorder.h:405-431 */
+    chain_t *c = &ch[i];
+    c->current = firstread;
+    if (truth[firstread])
+      c->done = 1;
+    else {
+      truth[firstread] = view[0][firstread] = view[1][firstread] = 1;
+      c->unmatched++;
+      updaterefcount(read + (size_t)c->current * W, &c->c, 1, 0, 0, len[c->current], L, W, st);
+      c->first_rid = c->prev = c->current;
+      c->prev_unmatched = 1;
+      alive++;
+    }
+    firstread += n / K;
+  }
+
+  for (uint64_t h = 0; alive; h++) {
+    const int g = (int)(h & 1);
+    if (!g) st->rounds++;
+    x.taken = view[g];
+    /* ---- phase A: proposals of group g from its own view */
+    uint32_t nneed = 0;
+    for (uint32_t i = glo[g]; i < ghi[g]; i++)
+      if (!ch[i].done && ch[i].mode == MODE_NEED_SEED) nneed++;
+    uint32_t nseed = 0;
+    if (nneed) {
+      for (int64_t j = cursor[g]; j >= slo[g] && nseed < nneed; j--)
+        if (!view[g][j]) seedlist[nseed++] = (uint32_t)j;
+    }
+    uint32_t rank = 0;
+    for (uint32_t i = glo[g]; i < ghi[g]; i++) {
+      chain_t *c = &ch[i];
+      if (c->done) continue;
+      c->prop_kind = PROP_NONE;
+      if (c->mode == MODE_NEED_SEED) {
+        if (rank < nseed) {
+          c->prop_kind = PROP_SEED;
+          c->prop_rid = seedlist[rank];
+        } else { /* the group's range is used up (reorder.h:593-599) */
+          if (c->prev_unmatched) ob_push_s(&c->ob, (uint32_t)c->prev);
+          c->done = 1;
+          alive--;
+        }
+        rank++;
+        continue;
+      }
+      if (!c->retrying) {
+        st->iterations++;
+        if (c->num_reads_thr % 1000000 == 0) {
+          if ((float)c->num_unmatched_past_1M_thr > STOP_CRITERIA_REORDER * 1000000) c->stop_searching = 1;
+          c->num_unmatched_past_1M_thr = 0;
+        }
+        c->num_reads_thr++;
+      }
+      if (!c->stop_searching) {
+        uint32_t k; int sh, rv;
+        if (rounds_search(&x, &c->c, &k, &sh, &rv, NULL, 0, NULL)) {
+          c->prop_kind = PROP_MATCH; c->prop_rid = k; c->prop_shift = sh; c->prop_rev = rv;
+        }
+      }
+    }
+    for (uint32_t i = glo[g]; i < ghi[g]; i++) {
+      chain_t *c = &ch[i];
+      if (c->done || c->prop_kind == PROP_NONE) continue;
+      if (resv[g][c->prop_rid] > i) resv[g][c->prop_rid] = i;
+    }
+    /* ---- phase B: resolve (lowest chain id of the group, and the read still free in truth) + apply */
+    nwon[g] = 0;
+    for (uint32_t i = glo[g]; i < ghi[g]; i++) {
+      chain_t *c = &ch[i];
+      if (c->done) continue;
+      if (c->prop_kind != PROP_NONE) {
+        if (resv[g][c->prop_rid] != i || truth[c->prop_rid]) {
+          st->lost++;
+          if (c->mode == MODE_SEARCH) c->retrying = 1;
+          continue;
+        }
+        truth[c->prop_rid] = 1;
+        won[g][nwon[g]++] = c->prop_rid;
+      }
+      ph_apply(&x, c, read, len, L, W, st);
+    }
+    /* the group's view for its next half-step: the truth as of now (its own claims + the other group's last ones) */
+    for (uint32_t j = 0; j < nwon[g]; j++) view[g][won[g][j]] = 1;
+    for (uint32_t j = 0; j < nwon[g ^ 1]; j++) view[g][won[g ^ 1][j]] = 1;
+    if (nseed) cursor[g] = (int64_t)seedlist[nseed - 1] - 1;
+  }
+
+  /* assemble: chain i -> tid i % num_thr, chains ascending inside a tid */
+  uint64_t nm = 0, ns = 0;
+  for (int t = 0; t < num_thr; t++) {
+    if (out->tid_off) out->tid_off[t] = nm;
+    if (out->tid_off_s) out->tid_off_s[t] = ns;
+    for (uint32_t i = (uint32_t)t; i < K; i += (uint32_t)num_thr) {
+      outbuf_t *o = &ch[i].ob;
+      memcpy(out->order + nm, o->order, o->n * sizeof(uint32_t));
+      memcpy(out->rc + nm, o->rc, o->n);
+      memcpy(out->flag + nm, o->flag, o->n);
+      memcpy(out->pos + nm, o->pos, o->n * sizeof(int64_t));
+      memcpy(out->rlen + nm, o->rlen, o->n * sizeof(uint16_t));
+      memcpy(out->order_s + ns, o->order_s, o->ns * sizeof(uint32_t));
+      nm += o->n;
+      ns += o->ns;
+    }
+  }
+  if (out->tid_off) out->tid_off[num_thr] = nm;
+  if (out->tid_off_s) out->tid_off_s[num_thr] = ns;
+  out->n_matched = nm;
+  out->n_single = ns;
+  for (uint32_t i = 0; i < K; i++) { st->unmatched += ch[i].unmatched; ob_free(&ch[i].ob); }
+  free(ch); free(seedlist); free(truth);
+  for (int g = 0; g < 2; g++) { free(view[g]); free(resv[g]); free(won[g]); }
+  for (int l = 0; l < 2; l++) dict_free(&x.dict[l]);
+  return 0;
+}
+
 /* ------------------------------------------------------------ writetofile */
 
 size_t orc_write_dna_stream(const uint64_t *read, const uint16_t *len, int L, const uint32_t *order,

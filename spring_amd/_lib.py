@@ -34,7 +34,7 @@ class Opts(C.Structure):
                 ("num_devices", C.c_int32), ("devices", C.c_int32 * 8), ("mg_host_transport", C.c_int32),
                 ("table_mode", C.c_int32), ("plan0", C.c_int32 * 6), ("plan1", C.c_int32 * 6), ("long_min", C.c_int32),
                 ("long_blocks", C.c_int32), ("debug", C.c_int32), ("long_split", C.c_int32), ("entry_flags", C.c_int32),
-                ("out_writers", C.c_int32), ("alternatives", C.c_int32)]
+                ("out_writers", C.c_int32), ("alternatives", C.c_int32), ("phases", C.c_int32)]
 
 
 class FastqInfo(C.Structure):
@@ -65,7 +65,7 @@ class Stats(C.Structure):
                 + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64),
                    ("ms_exchange", C.c_double), ("ms_resolve_mark", C.c_double), ("chains", C.c_uint64),
                    ("deep_pool", C.c_uint64), ("long_searches", C.c_uint64),
-                   ("table_minz", C.c_uint64), ("table_marked_lines", C.c_uint64), ("long_splits", C.c_uint64), ("alternatives", C.c_uint64)])
+                   ("table_minz", C.c_uint64), ("table_marked_lines", C.c_uint64), ("long_splits", C.c_uint64), ("alternatives", C.c_uint64), ("phases", C.c_uint64)])
 
     def asdict(self):
         d = {}

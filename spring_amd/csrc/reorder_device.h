@@ -87,6 +87,7 @@ struct Globals {
   uint32_t e_alloc;   // next unallocated chunk of the matched-record buffer
   uint32_t s_alloc;   // next unallocated chunk of the singleton buffer
   uint32_t pad;
+  long long cursor_b; // the second chain group's cursor (two-group schedule: DevParams::phases)
 };
 
 // The dictionary table (both dictionaries in one): 2^(64-bshift) buckets of 32 bytes, [tag x4 | payload x4]; a probe loads
@@ -185,8 +186,24 @@ struct DevParams {
   unsigned long long *dbg;  // [0..63] phase clocks / visits summed over the wavefronts that ran > 1M clocks, [64] how many
 #endif
   Globals *glob;
+  long long *cursor;  // the seed cursor the launch works with (&glob->cursor; the second chain group: &glob->cursor_b)
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;
+  // The two-group schedule (phases = 2; specification: oracle/reorder_oracle.c::orc_reorder_rounds_ph).
+  // The chains run as two groups -- [0, Kh) and [Kh, K), Kh a multiple of 2048 -- whose rounds alternate: group g searches
+  // on ITS view of the pool (taken = view_g: everything marked up to its own last mark step), while the other group's mark
+  // step runs; its mark step (k_ph_mark) then resolves its proposals against the other group's view as well (taken_other:
+  // a read the other group took in between is lost), sets its winners in its own view, leaves them in won[] for the other
+  // group's next mark step, and folds the other group's last winners (won_other[]) into its own view.  So a launch of one
+  // group never reads what a launch of the other group that may run beside it writes, and the two round kernels fill each
+  // other's drain.  Seeds: group 0 from reads [seed_lo, n) downwards, group 1 from [0, seed_lo of group 0).
+  // A launch covers the chains [g0, g0 + Kg) (phases = 1: all of them).
+  int phases;
+  uint32_t g0, Kg, g0_other, Kg_other;
+  uint32_t seed_lo, seed_hi;   // this group's seeds are reads [seed_lo, seed_hi) (phases = 1: [0, n))
+  uint32_t nb_lo, nb_hi;       // ... and its chains the blocks [nb_lo, nb_hi) of 2048 chains (needy_cnt)
+  const uint64_t *taken_other; // the other group's view (k_ph_mark only)
+  uint32_t *won, *won_other;   // [Kg] / [Kg_other]: read a chain secured in its group's last mark step | kind << 31 (1: a match), 0xffffffff none
   unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
   uint32_t *alive_wave;       // [ceil(Ktot / 64)] chains not done per 64 chains, rewritten every round by k_mg_mark
   Chain *chains;
@@ -245,6 +262,8 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal);
 void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg);
 void launch_mg_resolve(hipStream_t st, const DevParams &P);
 void launch_mg_mark(hipStream_t st, const DevParams &P);
+void launch_ph_mark(hipStream_t st, const DevParams &P);       // mark step of one chain group (two-group schedule)
+void launch_delay(hipStream_t st, uint32_t microseconds);      // a one-thread kernel that waits (staggers the two groups' first rounds)
 void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot /* [8] */);
 void launch_scatter(hipStream_t st, const DevParams &P, uint64_t cap_m, uint64_t cap_s, const uint64_t *off_m,
                     const uint64_t *off_s);

@@ -845,7 +845,7 @@ __global__ void k_init_seeds(DevParams P) {
 // the pool is exhausted; *is_last = this chain proposes the lowest seed of the round.
 __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid, int lane, bool *is_last) {
   int r = 0, tot = 0;
-  long long top = P.glob->cursor;  // issued together with the loads below
+  long long top = *P.cursor;  // issued together with the loads below
   const uint32_t nw = (P.Ktot + 31) / 32;
   const uint32_t myw = cid >> 5;
   if (P.needy_cnt) {
@@ -1763,7 +1763,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     if (!DEFER && lane == 0) {  // DEFER: every rank reads PK_NOSEED in the gathered words (k_mg_mark); the chain says PK_DONE from now on
       atomicAnd(&P.needy[cid >> 5], ~(1u << (cid & 31)));
       atomicSub(&P.glob->alive, 1u);
-      if (h.cursor_writer) P.glob->cursor = -1;  // (see search_step: the pool is exhausted)
+      if (h.cursor_writer) *P.cursor = -1;  // (see search_step: the pool is exhausted)
     }
     h.cursor_writer = 0;
     store_hot(c, h, lane);
@@ -1809,7 +1809,7 @@ __device__ __forceinline__ bool apply_step(const DevParams &P, Chain *c, uint32_
     }
   }
   if (!DEFER && kind == PROP_SEED && h.cursor_writer) {  // every seed proposed this round ends up taken, win or lose
-    if (lane == 0) P.glob->cursor = (long long)h.prop_rid - 1;
+    if (lane == 0) *P.cursor = (long long)h.prop_rid - 1;
     h.cursor_writer = 0;
   }
   R_new = uni_i32(R_new);
@@ -2636,13 +2636,13 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
         // and find_seed counts the cursor's block from the bitmap)
         if (pk == PK_MATCH) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
       }
-      if (pv & PK_CURSOR_BIT) P.glob->cursor = (long long)(uint32_t)pv - 1;  // every seed proposed this round ends up taken
+      if (pv & PK_CURSOR_BIT) *P.cursor = (long long)(uint32_t)pv - 1;  // every seed proposed this round ends up taken
       needy = pk == PK_SEED && !won;
       if (pk == PK_SEED && won && cls >= 0) cls = 1;
     } else if (pk == PK_NONE) {
       needy = (pv & PK_WILLNEED_BIT) != 0;
     } else if (pk == PK_NOSEED && (pv & PK_CURSOR_BIT)) {
-      P.glob->cursor = -1;  // the last-ranked needy chain found nothing: the pool is exhausted (search_step)
+      *P.cursor = -1;  // the last-ranked needy chain found nothing: the pool is exhausted (search_step)
     }
   }
   const uint64_t nb = __ballot(needy);
@@ -2681,6 +2681,97 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
       P.ord_cnt[blockIdx.x] = make_uint4(s_wc[0][0] + s_wc[1][0] + s_wc[2][0] + s_wc[3][0], s_wc[0][1] + s_wc[1][1] + s_wc[2][1] + s_wc[3][1],
                                          s_wc[0][2] + s_wc[1][2] + s_wc[2][2] + s_wc[3][2], s_wc[0][3] + s_wc[1][3] + s_wc[2][3] + s_wc[3][3]);
   }
+}
+// ---------------------------------------------- the two-group schedule (DevParams::phases = 2): one group's mark step
+// Specification: oracle/reorder_oracle.c::orc_reorder_rounds_ph.  The launch covers the chains [g0, g0 + Kg) of ONE group
+// (one GPU: c0 = 0).  What k_mg_mark does for every chain -- winners claim their read, the lowest seed of the round moves the
+// cursor, needy bitmap + counts, running chains, the class lists of k_round_mc -- for this group's chains, on this group's
+// view (taken / resv / cursor / needy counts are the group's own); and what only two groups need:
+//  * a proposal that holds its resv[] entry still loses when the OTHER group has taken the read since this group's
+//    search looked at the pool (taken_other, complete up to the other group's last mark step -- the step in front of this
+//    one: the host orders the mark steps A, B, A, B ... by events); resv[] then gets RESV_LOST, which is what the chain's
+//    apply half reads in the next round kernel (it must not look at taken_other: the other group's next mark step may run
+//    beside it);
+//  * won[]: the read every chain secured (bit 31: a match), for the other group's next mark step;
+//  * won_other[]: the other group's winners of its last mark step go into THIS group's view, and out of the block counts
+//    of this group's seed region (ublk[b] belongs to the group that picks seeds from block b: only its mark step writes it,
+//    so its round kernel -- which may run beside the other group's mark step -- reads settled counts).
+constexpr uint32_t RESV_LOST = 0xfffffffeu;
+__global__ __launch_bounds__(256) void k_ph_mark(DevParams P) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t cid = P.g0 + t, gend = P.g0 + P.Kg;
+  const int lane = threadIdx.x & 63;
+  bool needy = false, alive = false;
+  int cls = -1;
+  if (cid < gend) {
+    const unsigned long long pv = P.prop[cid];
+    const int pk = (int)(pv >> 32) & 7;
+    uint32_t wonv = 0xffffffffu;
+    alive = pk != PK_DONE;
+    if (alive) cls = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv & PK_WILLNEED_BIT) ? 3 : 0) : 3;
+    if (pk == PK_MATCH || pk == PK_SEED) {
+      const uint32_t rid = (uint32_t)pv;
+      bool won = P.resv[rid] == cid;
+      if (won && is_taken(P.taken_other, rid)) { won = false; P.resv[rid] = RESV_LOST; }
+      if (won) {
+        atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+        if (pk == PK_MATCH && rid >= P.seed_lo && rid < P.seed_hi) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+        wonv = rid | (pk == PK_MATCH ? 0x80000000u : 0u);
+      }
+      if (pv & PK_CURSOR_BIT) *P.cursor = (long long)rid - 1;  // every seed proposed this round ends up taken (by someone)
+      needy = pk == PK_SEED && !won;
+      if (pk == PK_SEED && won && cls >= 0) cls = 1;
+    } else if (pk == PK_NONE) {
+      needy = (pv & PK_WILLNEED_BIT) != 0;
+    } else if (pk == PK_NOSEED && (pv & PK_CURSOR_BIT)) {
+      *P.cursor = -1;
+    }
+    P.won[t] = wonv;
+  }
+  for (uint32_t j = t; j < P.Kg_other; j += gridDim.x * blockDim.x) {
+    const uint32_t w = P.won_other[j];
+    if (w == 0xffffffffu) continue;
+    const uint32_t rid = w & 0x7fffffffu;
+    atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+    if ((w >> 31) && rid >= P.seed_lo && rid < P.seed_hi) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+  }
+  const uint64_t nb = __ballot(needy);
+  const uint32_t na = (uint32_t)__popcll(__ballot(alive));
+  const uint32_t cb = cid & ~63u;  // (g0 is a multiple of 2048: a wavefront covers two whole bitmap words of its group)
+  if (lane == 0 && cb < gend) {
+    P.needy[cb >> 5] = (uint32_t)nb;
+    if (cb + 32 < ((gend + 31) & ~31u)) P.needy[(cb >> 5) + 1] = (uint32_t)(nb >> 32);
+    if (nb) atomicAdd(&P.needy_cnt_next[cid >> 11], (uint32_t)__popcll(nb));
+    P.alive_wave[cid >> 6] = na;
+  }
+  if (t < P.nb_hi - P.nb_lo) P.needy_cnt[P.nb_lo + t] = 0;  // what this group's NEXT mark step accumulates into
+  {  // class lists of this block's chains (k_round_mc; as in k_mg_mark)
+    __shared__ uint32_t s_wc[4][4];  // [wave][class]
+    const int wv = threadIdx.x >> 6;
+    const uint32_t segi = P.g0 / MARK_BLOCK + blockIdx.x;
+    uint32_t mypos = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t m = __ballot(cls == k);
+      if (lane == 0) s_wc[wv][k] = (uint32_t)__popcll(m);
+      if (cls == k) mypos = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    }
+    __syncthreads();
+    if (cls >= 0) {
+      uint32_t base = 0;
+      for (int k = 0; k < cls; k++) base += s_wc[0][k] + s_wc[1][k] + s_wc[2][k] + s_wc[3][k];
+      for (int w = 0; w < wv; w++) base += s_wc[w][cls];
+      P.ord[(size_t)segi * MARK_BLOCK + base + mypos] = cid;
+    }
+    if (threadIdx.x == 0)
+      P.ord_cnt[segi] = make_uint4(s_wc[0][0] + s_wc[1][0] + s_wc[2][0] + s_wc[3][0], s_wc[0][1] + s_wc[1][1] + s_wc[2][1] + s_wc[3][1],
+                                   s_wc[0][2] + s_wc[1][2] + s_wc[2][2] + s_wc[3][2], s_wc[0][3] + s_wc[1][3] + s_wc[2][3] + s_wc[3][3]);
+  }
+}
+// waits on the device: the second group's first round starts half a round after the first group's
+__global__ void k_delay(uint32_t us) {
+  const uint64_t t0 = wall_clock64();  // 100 MHz
+  while (wall_clock64() - t0 < (uint64_t)us * 100u) __builtin_amdgcn_s_sleep(64);
 }
 // first round: every local chain in class 2
 __global__ void k_init_ord(DevParams P) {
@@ -2908,7 +2999,7 @@ void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v) {
 __global__ void k_check_seed_state(DevParams P, uint64_t nwords, unsigned long long *bad) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= nwords) return;
-  const long long top = P.glob->cursor;
+  const long long top = *P.cursor;
   const uint64_t v = P.taken[w];
   // (1) bits of reads > cursor
   const long long first = (long long)w * 64;
@@ -2986,7 +3077,8 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
   // reference-equivalent work counters, or the deep-bin machinery (tail trimming, balanced scan, resumed searches)
   if (P.mc && !stats && !P.deep_bins) {
     // one class-list segment per block of MARK_BLOCK chain ids that holds local chains, a fixed number of wavefronts each
-    const uint32_t nseg = (P.c0 + P.K + MARK_BLOCK - 1) / MARK_BLOCK - P.c0 / MARK_BLOCK;
+    // (two-group schedule: the launch covers one group, chains [g0, g0 + Kg); else g0 = 0, Kg = K)
+    const uint32_t nseg = (P.c0 + P.g0 + P.Kg + MARK_BLOCK - 1) / MARK_BLOCK - (P.c0 + P.g0) / MARK_BLOCK;
     const dim3 g4(nseg * MC_WAVES_PER_BLOCK);
     if (P.Lpad <= 192) {
       if (mg) hipLaunchKernelGGL((k_round_mc<3, true>), g4, b, 0, st, P);
@@ -3037,6 +3129,10 @@ void launch_mg_mark(hipStream_t st, const DevParams &P) {
   if (P.alts == 2) hipLaunchKernelGGL(k_alt_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
   hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 }
+void launch_ph_mark(hipStream_t st, const DevParams &P) {
+  if (P.Kg) hipLaunchKernelGGL(k_ph_mark, GRID1(P.Kg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
+}
+void launch_delay(hipStream_t st, uint32_t microseconds) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, microseconds); }
 void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot) {
   if (P.K) hipLaunchKernelGGL(k_chain_summary, GRID1(P.K, 256), dim3(256), 0, st, P, sum, tot);
 }

@@ -150,6 +150,12 @@ struct spring_reorder_ctx {
   bool mg = false;
   uint32_t *cnt_buf[2] = {nullptr, nullptr};  // needy_cnt double buffer (reorder_device.h)
   uint64_t round_no = 0;
+  // two-group schedule (DevParams::phases = 2): the second group's stream, the stream of the host's look at the running
+  // chains, the second group's view of the pool and its reservation words, the winners of either group's last mark step
+  hipStream_t st2 = nullptr, st3 = nullptr;
+  uint64_t *taken2 = nullptr;
+  uint32_t *resv2 = nullptr, *won = nullptr;
+  uint32_t Kh = 0, nmid = 0;
   bool in_source_fallback = false;  // load_dna <-> load_dna_source recursion guard
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
@@ -380,6 +386,8 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   for (void *p : ctx->allocs) pool_free(ctx->dev, p);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
+  if (ctx->st2) (void)hipStreamDestroy(ctx->st2);
+  if (ctx->st3) (void)hipStreamDestroy(ctx->st3);
   delete ctx;
 }
 
@@ -1398,7 +1406,8 @@ static uint32_t auto_chains(uint32_t n, bool deep, bool very_deep, bool heavy_ta
 
 // device state of the chain phase for the chains [c0, c0 + K) of Ktot this context owns; `d_prop`: caller's
 // proposal buffer or null.  Used by run_chains (c0 = 0, K = Ktot) and mg_begin.
-static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32_t Ktot, bool fused, void *d_prop) {
+static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32_t Ktot, bool fused, void *d_prop,
+                        bool allow_phases = false) {
   hipStream_t st = ctx->st;
   const uint32_t n = ctx->n;
   ctx->K = K;
@@ -1414,6 +1423,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   const size_t needy_bytes = (((size_t)Ktot + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
   DMALLOC(P.needy, needy_bytes);
   DMALLOC(P.glob, sizeof(Globals));
+  P.cursor = &P.glob->cursor;
   DMALLOC(P.chains, (size_t)K * sizeof(Chain));
   DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
   DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t) + 64);  // (k_round_mc reads whole quads: up to 12 bytes past a column)
@@ -1454,6 +1464,34 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !ctx->user_plan0) {
     memset(P.plan[0], 0, sizeof(P.plan[0]));   // (fill_params assumed the four-chain kernel: 4 + 8 + 16)
     P.plan[0][0] = 8; P.plan[0][1] = 16;
+  }
+  // The chain schedule (opts.phases, DevParams::phases): two chain groups whose rounds alternate where the four-chain round
+  // kernel runs (what it buys is the drain of that kernel: a round costs ~46 us + 158 us per 65 536 chains, and two half
+  // launches side by side cost what their chains cost -- tools/overlap_probe.py: 395 -> 320 ms on 100 M x 150 bp).
+  {
+    const uint32_t half = (uint32_t)((((uint64_t)K / 2 + 2047) / 2048) * 2048);  // group 0: chains [0, half)
+    const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
+    const bool can = allow_phases && fused && P.mc && !ctx->o.collect_stats && !P.deep_bins && P.alts == 1 && Ktot == K && c0 == 0 &&
+                     !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
+    const int want = ctx->o.phases > 0 ? ctx->o.phases : (K >= 49152 ? 2 : 1);
+    if (ctx->o.phases == 2 && !can)
+      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the four-chain round kernel (shallow dictionary, no work counters, fused >= 0 "
+                  "and not 2, at least 49152 chains or fused = 3), one GPU, one candidate per proposal, at least 4096 chains and "
+                  "8192 .. 2^31 - 1 reads");
+    if (ctx->o.phases > 2) return fail(SPRING_REORDER_E_ARG, "phases: 0 (library's choice), 1 or 2");
+    P.phases = (want == 2 && can) ? 2 : 1;
+    ctx->Kh = half; ctx->nmid = nmid;
+    ctx->stats.phases = (uint64_t)P.phases;
+  }
+  P.g0 = 0; P.Kg = K; P.g0_other = 0; P.Kg_other = 0;
+  P.seed_lo = 0; P.seed_hi = n;
+  P.nb_lo = 0; P.nb_hi = (Ktot + 2047) / 2048;
+  P.taken_other = nullptr; P.won = P.won_other = nullptr;
+  ctx->taken2 = nullptr; ctx->resv2 = nullptr; ctx->won = nullptr;
+  if (P.phases == 2) {
+    DMALLOC(ctx->taken2, nwords * 8);
+    DMALLOC(ctx->resv2, nn * 4);
+    DMALLOC(ctx->won, (size_t)K * 4);
   }
   P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
   ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
@@ -1513,12 +1551,18 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   Globals g;
   memset(&g, 0, sizeof(g));
   g.cursor = (long long)n - 1;
+  g.cursor_b = (long long)ctx->nmid - 1;
   g.e_alloc = g.s_alloc = K * CHUNK;
   g.alive = n == 0 ? 0 : (n / Ktot > 0 ? K : (c0 == 0 ? 1 : 0));  // chains that get a seed (reorder.h:405-421)
   HIPCHK(hipMemsetAsync(P.e_chunk, 0xff, nchunk * sizeof(uint2), st));  // owner 0xffffffff: chunk never handed out
   HIPCHK(hipMemsetAsync(P.s_chunk, 0xff, nchunk * sizeof(uint2), st));
   HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
   launch_init_chains(st, P);
+  if (P.phases == 2) {  // both groups start from the same pool: the chains' first seeds are taken
+    HIPCHK(hipMemcpyAsync(ctx->taken2, P.taken, nwords * 8, hipMemcpyDeviceToDevice, st));
+    launch_fill_u32(st, ctx->resv2, n, 0xffffffffu);
+    HIPCHK(hipMemsetAsync(ctx->won, 0xff, (size_t)K * 4, st));
+  }
   HIPCHK(hipGetLastError());
   ctx->round_no = 0;
   return 0;
@@ -1546,6 +1590,130 @@ static int running_chains(spring_reorder_ctx *ctx, std::vector<uint32_t> &buf, u
   return 0;
 }
 
+// The two-group schedule (DevParams::phases = 2).  Group 0 runs on the context's stream, group 1 on
+// a second one; a round of a group = its round kernel, then its mark step, which waits (event) for the other group's
+// last mark step: the mark steps strictly alternate A, B, A, B ..., the round kernels overlap.  A third stream carries the
+// host's look at the running chains (one batch late, as in the one-group loop), so neither group's stream ever waits
+// for the host.
+static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
+  DevParams &P = ctx->P;
+  const uint32_t K = P.K;
+  if (!ctx->st2) HIPCHK(hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking));
+  if (!ctx->st3) HIPCHK(hipStreamCreateWithFlags(&ctx->st3, hipStreamNonBlocking));
+  hipStream_t sg[2] = {ctx->st, ctx->st2}, sc = ctx->st3;
+  struct Group { uint32_t g0, Kg, seed_lo, seed_hi; uint64_t *taken; uint32_t *resv; long long *cursor; uint64_t round_no; } gp[2];
+  gp[0] = {0u, ctx->Kh, ctx->nmid, ctx->n, P.taken, P.resv, &P.glob->cursor, 0};
+  gp[1] = {ctx->Kh, K - ctx->Kh, 0u, ctx->nmid, ctx->taken2, ctx->resv2, &P.glob->cursor_b, 0};
+  auto params_of = [&](int g) {
+    DevParams Q = P;
+    const Group &a = gp[g], &b = gp[g ^ 1];
+    Q.g0 = a.g0; Q.Kg = a.Kg; Q.g0_other = b.g0; Q.Kg_other = b.Kg;
+    Q.seed_lo = a.seed_lo; Q.seed_hi = a.seed_hi;
+    Q.nb_lo = a.g0 / 2048; Q.nb_hi = (a.g0 + a.Kg + 2047) / 2048;
+    Q.taken = a.taken; Q.taken_other = b.taken; Q.resv = a.resv; Q.cursor = a.cursor;
+    Q.won = ctx->won + a.g0; Q.won_other = ctx->won + b.g0;
+    const int w = (int)(a.round_no & 1);  // (set_round_buffers, per group: the groups touch disjoint blocks of the buffers)
+    Q.needy_cnt = ctx->cnt_buf[w ^ 1]; Q.needy_cnt_next = ctx->cnt_buf[w];
+    return Q;
+  };
+  hipEvent_t ev[2] = {nullptr, nullptr}, bev[2] = {nullptr, nullptr}, ev0 = nullptr;
+  struct EvFree { hipEvent_t *e; int n; ~EvFree() { for (int i = 0; i < n; i++) if (e[i]) (void)hipEventDestroy(e[i]); } };
+  EvFree g1{ev, 2}, g2{bev, 2}, g3{&ev0, 1};
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&bev[i], hipEventDisableTiming));
+  }
+  HIPCHK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+  std::vector<hipEvent_t> tev;  // opts.time_search: an event pair around every round-kernel launch, on the launch's stream
+  struct TevFree { std::vector<hipEvent_t> &v; ~TevFree() { for (auto &e : v) (void)hipEventDestroy(e); } } tev_guard{tev};
+  if (timed) {
+    tev.resize(4 * (size_t)R);
+    for (auto &e : tev) HIPCHK(hipEventCreate(&e));
+  }
+  const size_t nw = ((size_t)K + 63) / 64;
+  uint32_t *h_aw = nullptr;
+  HIPCHK(hipHostMalloc((void **)&h_aw, 2 * nw * sizeof(uint32_t), hipHostMallocDefault));
+  struct HostFree { void *p; ~HostFree() { if (p) (void)hipHostFree(p); } } h_aw_guard{h_aw};
+  // group 1 starts behind the set-up (on the context's stream) and half a round late
+  HIPCHK(hipEventRecord(ev0, sg[0]));
+  HIPCHK(hipStreamWaitEvent(sg[1], ev0, 0));
+  launch_delay(sg[1], 90);
+  bool have_b = false;
+  uint64_t rounds = 0, launches = 0;
+  double ms_search = 0;
+  auto enqueue_batch = [&]() -> int {
+    for (int r = 0; r < R; r++) {
+      for (int g = 0; g < 2; g++) {
+        const DevParams Q = params_of(g);
+        if (timed) HIPCHK(hipEventRecord(tev[4 * r + 2 * g], sg[g]));
+        launch_round(sg[g], Q, false, false);
+        if (timed) HIPCHK(hipEventRecord(tev[4 * r + 2 * g + 1], sg[g]));
+        if (g == 1 || have_b) HIPCHK(hipStreamWaitEvent(sg[g], ev[g ^ 1], 0));  // the other group's last mark step
+        launch_ph_mark(sg[g], Q);
+        HIPCHK(hipEventRecord(ev[g], sg[g]));
+        gp[g].round_no++;
+      }
+      have_b = true;
+    }
+    rounds += R;
+    return 0;
+  };
+  auto count_batch = [&](int slot) -> int {  // behind both groups' last mark steps of the batch
+    HIPCHK(hipStreamWaitEvent(sc, ev[0], 0));
+    HIPCHK(hipStreamWaitEvent(sc, ev[1], 0));
+    HIPCHK(hipMemcpyAsync(h_aw + (size_t)slot * nw, P.alive_wave, nw * 4, hipMemcpyDeviceToHost, sc));
+    HIPCHK(hipEventRecord(bev[slot], sc));
+    return 0;
+  };
+  auto collect_times = [&]() -> int {  // (time_search: the batch is complete)
+    for (int i = 0; i < 2 * R; i++) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, tev[2 * i], tev[2 * i + 1]));
+      ms_search += ms;
+    }
+    launches += 2 * (uint64_t)R;
+    return 0;
+  };
+  int rr;
+  if (timed) {  // a batch at a time (the events are read between batches)
+    for (;;) {
+      if ((rr = enqueue_batch())) return rr;
+      if ((rr = count_batch(0))) return rr;
+      HIPCHK(hipEventSynchronize(bev[0]));
+      HIPCHK(hipStreamSynchronize(sg[0]));
+      HIPCHK(hipStreamSynchronize(sg[1]));
+      if ((rr = collect_times())) return rr;
+      uint64_t a = 0;
+      for (size_t i = 0; i < nw; i++) a += h_aw[i];
+      if (!a) break;
+    }
+  } else {
+    if ((rr = enqueue_batch())) return rr;
+    if ((rr = count_batch(0))) return rr;
+    for (int b = 0;; b ^= 1) {
+      if ((rr = enqueue_batch())) return rr;
+      if ((rr = count_batch(b ^ 1))) return rr;
+      HIPCHK(hipEventSynchronize(bev[b]));
+      uint64_t a = 0;
+      for (size_t i = 0; i < nw; i++) a += h_aw[(size_t)b * nw + i];
+      HIPCHK(hipGetLastError());
+      if (ctx->o.debug) fprintf(stderr, "[chains] rounds %llu running %llu (two groups)\n", (unsigned long long)(rounds - R), (unsigned long long)a);
+      if (!a) break;
+    }
+  }
+  // everything behind the chain phase is queued on the context's stream
+  HIPCHK(hipStreamWaitEvent(sg[0], ev[1], 0));
+  HIPCHK(hipEventRecord(ctx->ev[5], sg[0]));
+  HIPCHK(hipStreamSynchronize(sg[1]));
+  HIPCHK(hipStreamSynchronize(sc));
+  HIPCHK(hipStreamSynchronize(sg[0]));
+  ctx->round_no = gp[0].round_no;
+  ctx->stats.rounds = rounds;
+  ctx->stats.ms_search_kernel = ms_search;
+  ctx->stats.search_launches = launches;
+  return 0;
+}
+
 int spring_reorder_auto_chains(spring_reorder_ctx *ctx, uint32_t *chains, int32_t *deep) {
   if (!ctx) return fail(SPRING_REORDER_E_ARG, "ctx is NULL");
   if (ctx->stage < ST_DICT) return fail(SPRING_REORDER_E_STATE, "auto_chains: build_dict first");
@@ -1569,10 +1737,16 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   const bool fused = !literal && ctx->o.fused >= 0;
   ctx->stats.chains = K;
   ctx->stats.deep_pool = (dict_is_deep(ctx) ? 1 : 0) | (dict_has_heavy_tail(ctx) ? 2 : 0);
-  int r0 = setup_chains(ctx, K, 0, K, fused, nullptr);
+  int r0 = setup_chains(ctx, K, 0, K, fused, nullptr, true);
   if (r0) return r0;
   DevParams &P = ctx->P;
   int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : (K >= 256 ? 16 : 256);
+  if (P.phases == 2) {
+    int rp = run_chains_phased(ctx, R, timed);
+    if (rp) return rp;
+    ctx->stage = ST_CHAINS;
+    return 0;
+  }
   std::vector<hipEvent_t> tev;
   if (timed) {
     tev.resize(2 * (size_t)R);

@@ -322,9 +322,9 @@ __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t 
 // find_seed for a 16-lane group (fused rounds: needy_cnt is kept by k_mg_mark).  See find_seed.
 __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t cid, int gl, bool *is_last) {
   int r = 0, tot = 0;
-  const long long top = P.glob->cursor;
+  const long long top = *P.cursor;
   const uint32_t nw = (P.Ktot + 31) / 32, myw = cid >> 5;
-  const uint32_t nblk = (nw + 63) / 64, myblk = myw >> 6;
+  const uint32_t myblk = myw >> 6;  // (ranks count the chains of this launch's group: blocks [nb_lo, nb_hi) of 2048 chains)
 #pragma unroll
   for (int k = 0; k < 4; k++) {  // the 64 bitmap words of this chain's own block of 2048 chains
     const uint32_t w = myblk * 64 + 4 * gl + k;
@@ -332,7 +332,7 @@ __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t c
     if (w < myw) r += __popc(v);
     else if (w == myw) r += __popc(v & ((1u << (cid & 31)) - 1u));
   }
-  for (uint32_t b = gl; b < nblk; b += G) {
+  for (uint32_t b = P.nb_lo + gl; b < P.nb_hi; b += G) {
     const uint32_t v = P.needy_cnt[b];
     tot += (int)v;
     if (b < myblk) r += (int)v;
@@ -340,7 +340,8 @@ __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t c
   const uint32_t rank = (uint32_t)gsum_i(r), nneedy = (uint32_t)gsum_i(tot);
   *is_last = rank + 1 == nneedy;
   uint32_t need = rank + 1;
-  if (top < 0) return -1;
+  if (top < (long long)P.seed_lo) return -1;  // (seeds come from reads [seed_lo, ...) -- the whole pool unless the chains run in two groups)
+  const long long blo = (long long)(P.seed_lo >> UBLK_SHIFT);
   constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // bitmap words per block
   constexpr int WPG = WPB_ / G;                // ... per lane of the group
   static_assert(WPG >= 1 && WPG * G == WPB_ && WPG <= G, "a block is 1..16 bitmap words per lane");
@@ -376,9 +377,9 @@ __device__ __forceinline__ long long find_seed_mc(const DevParams &P, uint32_t c
     if (tot0 >= need) return pick(bt, need);
     need -= tot0;
   }
-  for (long long b0 = bt - 1; b0 >= 0; b0 -= G) {
+  for (long long b0 = bt - 1; b0 >= blo; b0 -= G) {
     const long long bb = b0 - gl;
-    const int u = bb >= 0 ? (int)P.ublk[bb] : 0;
+    const int u = bb >= blo ? (int)P.ublk[bb] : 0;
     const int incl = gincl_scan_i(u, gl);
     const uint32_t total = (uint32_t)__shfl(incl, G - 1, G);
     if (total < need) { need -= total; continue; }
@@ -820,7 +821,7 @@ __device__ __forceinline__ void round_mc_body(const DevParams &P) {
   // (the loop costs the body 30 VGPRs, an occupancy step: 487-710 ms).
   uint32_t li;
   {
-    const uint32_t seg = P.c0 / MARK_BLOCK + blockIdx.x / MC_WAVES_PER_BLOCK, b = blockIdx.x % MC_WAVES_PER_BLOCK;
+    const uint32_t seg = (P.c0 + P.g0) / MARK_BLOCK + blockIdx.x / MC_WAVES_PER_BLOCK, b = blockIdx.x % MC_WAVES_PER_BLOCK;
     const uint4 n = P.ord_cnt[seg];
     const uint32_t w0 = (n.x + 3) / 4, w1 = w0 + (n.y + 3) / 4, w2 = w1 + (n.z + 3) / 4, w3 = w2 + (n.w + 3) / 4;
     if (b >= w3) return;

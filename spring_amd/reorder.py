@@ -51,6 +51,7 @@ class ReorderOpts:
     out_writers: int = 0      # call_reorder: threads writing the output files (0 = from the host's thread count)
     alternatives: int = 0     # candidates per match proposal: 1, 2 (a loser takes the next passing read of the bin), 0 = library's choice
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
+    phases: int = 0           # chain schedule: 1 lock-step rounds, 2 two chain groups whose rounds alternate (the output depends on it), 0 = library's choice
 
     def to_c(self):
         o = _lib.Opts()
@@ -73,6 +74,7 @@ class ReorderOpts:
         o.long_split, o.entry_flags = self.long_split, self.entry_flags
         o.out_writers = self.out_writers
         o.alternatives = self.alternatives
+        o.phases = self.phases
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d

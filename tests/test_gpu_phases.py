@@ -1,0 +1,95 @@
+"""The schedule with two chain groups (`opts.phases = 2`): the chains run as two groups whose rounds
+alternate, one group's round kernel beside the other's, each group searching on the pool as it was after its own last
+round.  Executable specification: oracle/reorder_oracle.c::orc_reorder_rounds_ph (its invariants are checked on CPU in
+tests/test_oracle.py).  Here: the HIP path through the C ABI == that oracle, bit for bit -- which also says that two
+kernels running side by side on two streams never read what the other writes (any such race would show as a difference
+from the sequential oracle, or between repeated runs)."""
+import numpy as np
+import pytest
+
+from helpers import KEYS, check_invariants
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _sa():
+    import spring_amd
+    return spring_amd
+
+
+def _same(a, b, what):
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), (what, k, len(a[k]), len(b[k]))
+    assert np.array_equal(a["tid_off"], b["tid_off"]) and np.array_equal(a["tid_off_s"], b["tid_off_s"]), what
+
+
+def _run(n, L, G, K, T, seed=23, err=10000, **kw):
+    sa = _sa()
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, fused=3, deep_bins=-1, **kw)) as st:
+        st.load_synth(n, L, G, seed, err)
+        got = st.run().streams()
+        dna = st.download_dna()
+    return got, dna
+
+
+@pytest.mark.parametrize("n,L,cov,K,T", [(300_000, 100, 30, 4096, 8), (200_000, 150, 25, 6144, 3), (160_000, 150, 60, 8192, 2),
+                                         (100_000, 64, 20, 4100, 1), (60_000, 251, 25, 4096, 2), (40_000, 100, 25, 12288, 5)])
+def test_two_groups_vs_oracle(n, L, cov, K, T):
+    """Group sizes that differ (6144 -> 4096 + 2048; 4100 -> 4096 + 4), chains that outnumber the reads of a seed range
+    (12288 chains on 40 000 reads: most finish at once), read lengths of both instantiations of the round kernel."""
+    got, dna = _run(n, L, n * L // cov, K, T, phases=2)
+    assert got["stats"]["phases"] == 2 and got["stats"]["chains"] == K
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds_ph(read, ln, L, K, T)
+    _same(got, want, (n, L, K))
+    assert got["stats"]["unmatched"] == want["stats"]["unmatched"] and got["stats"]["lost"] == want["stats"]["lost"]
+    check_invariants(got, read, ln, L, n)
+
+
+def test_repeated_runs_and_batch_sizes_agree():
+    """The same streams whatever the host does around the launches: rounds per look at the running chains, HIP events around
+    every round kernel (opts.time_search), repeated runs."""
+    n, L, K = 250_000, 150, 4096
+    ref, dna = _run(n, L, n * L // 25, K, 4, phases=2)
+    for kw in (dict(), dict(rounds_per_sync=1), dict(rounds_per_sync=5), dict(time_search=True), dict()):
+        got, _ = _run(n, L, n * L // 25, K, 4, phases=2, **kw)
+        _same(got, ref, kw)
+        if kw.get("time_search"):
+            assert got["stats"]["search_launches"] >= 2 and got["stats"]["ms_search_kernel"] > 0
+    read, ln = po.load_dna(dna, n, L)
+    _same(ref, po.reorder_rounds_ph(read, ln, L, K, 4), "oracle")
+
+
+def test_contended_pool_two_groups():
+    """A few thousand chains on a genome of a few kilobases: most proposals are lost, many of them to the OTHER group (a read
+    it took between this group's search and its mark step)."""
+    n, L, G, K = 120_000, 100, 3_000, 4096
+    got, dna = _run(n, L, G, K, 2, phases=2)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds_ph(read, ln, L, K, 2)
+    _same(got, want, "contended")
+    assert got["stats"]["lost"] == want["stats"]["lost"] and want["stats"]["lost"] > 0
+
+
+def test_one_group_schedule_untouched_and_library_choice():
+    """phases = 1 is the rounds schedule of every other test; the library's own choice below 49 152 chains is 1."""
+    n, L, K = 120_000, 100, 4096
+    one, dna = _run(n, L, n * L // 25, K, 2, phases=1)
+    auto, _ = _run(n, L, n * L // 25, K, 2)
+    assert one["stats"]["phases"] == 1 and auto["stats"]["phases"] == 1
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds(read, ln, L, K, 2)
+    _same(one, want, "phases = 1")
+    _same(auto, want, "library's choice")
+
+
+def test_refused_where_it_cannot_run():
+    sa = _sa()
+    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=2), dict(num_chains=4096, fused=3, collect_stats=True),
+               dict(num_chains=4096, fused=3, alternatives=2), dict(num_chains=4096)):
+        with sa.ReorderStage(sa.ReorderOpts(num_thr=1, phases=2, **kw)) as st:
+            st.load_synth(50_000, 100, 200_000, 5, 10000)
+            st.build_dict()
+            with pytest.raises(sa.ReorderError):
+                st.run_chains()
