@@ -76,7 +76,7 @@ def algorithmic_bytes_apply(st):
     return 2 * n * 12 + n * 16
 
 
-def compression_cost(spring_amd, a, dev, reads_per_chain):
+def compression_cost(spring_amd, a, dev, reads_per_chain, phases=1):
     """bits per base of the reorder + encoder output after BSC (the reference's, oracle/_ref/ref_bsc) for K = default
     and K = num_thr on a sample with the workload's coverage and error rate (encoder.cpp:111-156 is where SPRING
     hands these streams to BSC)."""
@@ -89,7 +89,6 @@ def compression_cost(spring_amd, a, dev, reads_per_chain):
     if not bsc_bin:
         return {"error": "oracle/_ref/ref_bsc is not built (make -C oracle ref, needs the reference sources)"}
     n, L = a.cost_sample, a.readlen
-    G = max(n * L // a.coverage, 2 * L)
 
     def bsc(b):
         if not len(b):
@@ -100,12 +99,9 @@ def compression_cost(spring_amd, a, dev, reads_per_chain):
             subprocess.run([bsc_bin, fi, fo], check=True, stdout=subprocess.DEVNULL)
             return os.path.getsize(fo)
 
-    res = {}
-    # the sample runs at the headline run's reads per chain (the default is capped at 65 536 chains: 1 526 reads per
-    # chain at 100 M reads; a 4 M-read sample left to the default rule would run at 1 024 and overstate the cost)
-    k_same = max(1, int(round(n / max(reads_per_chain, 1.0))))
-    for name, K in (("default", k_same), ("num_thr", a.num_thr)):
-        with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=K, num_thr=1)) as st:
+    def sized(n, K, **kw):
+        G = max(n * L // a.coverage, 2 * L)
+        with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=K, num_thr=1, **kw)) as st:
             st.load_synth(n, L, G, 5, a.err_ppm)
             st.run()
             sst = st.stats()
@@ -116,13 +112,26 @@ def compression_cost(spring_amd, a, dev, reads_per_chain):
         dpos = np.diff(e["pos"].astype(np.int64), prepend=0).astype(np.int32)
         tot = (bsc(packed) + bsc(dpos.tobytes()) + bsc(bytes(e["noise"])) + bsc(e["noisepos"].tobytes())
                + bsc(e["rc"].tobytes()) + bsc(bytes(e["unaligned"])))
-        res[name] = {"chains": int(sst["chains"]), "contigs": int(info["num_contigs"]), "bytes": int(tot),
-                     "bits_per_base": round(tot * 8.0 / (n * L), 4), "chains_stage_ms": round(sst["ms_chains"], 1)}
-    d, r = res["default"], res["num_thr"]
-    return {"sample_reads": n, "read_len": L, "coverage": a.coverage, "default_chains": d, "reference_granularity": r,
-            "size_ratio_default_vs_num_thr": round(d["bytes"] / r["bytes"], 4),
-            "what": "read streams (consensus, positions, noise, noise positions, orientation, unaligned) after the reference's "
-                    "BSC; reads per chain %d (as in the headline run) vs %d (K = num_thr = %d)" % (n // max(d["chains"], 1), n // max(r["chains"], 1), a.num_thr)}
+        return {"chains": int(sst["chains"]), "chain_groups": int(sst.get("phases", 1)), "contigs": int(info["num_contigs"]), "bytes": int(tot),
+                "bits_per_base": round(tot * 8.0 / (n * L), 4), "chains_stage_ms": round(sst["ms_chains"], 1)}
+
+    # the sample runs at the headline run's reads per chain (the default is capped at 65 536 chains: 1 526 reads per
+    # chain at 100 M reads; a 4 M-read sample left to the default rule would run at 1 024 and overstate the cost)
+    k_same = max(1, int(round(n / max(reads_per_chain, 1.0))))
+    d, r = sized(n, k_same, phases=1), sized(n, a.num_thr)
+    out = {"sample_reads": n, "read_len": L, "coverage": a.coverage, "default_chains": d, "reference_granularity": r,
+           "size_ratio_default_vs_num_thr": round(d["bytes"] / r["bytes"], 4),
+           "what": "read streams (consensus, positions, noise, noise positions, orientation, unaligned) after the reference's "
+                   "BSC; reads per chain %d (as in the headline run) vs %d (K = num_thr = %d)" % (n // max(d["chains"], 1), n // max(r["chains"], 1), a.num_thr)}
+    if phases == 2:
+        # the headline run's schedule (two chain groups) needs 4 096 chains: a larger sample at the same reads per chain,
+        # one group against two (the K = num_thr run above would take a minute on it)
+        n2 = max(n, int(4200 * reads_per_chain))
+        k2 = max(4096, int(round(n2 / max(reads_per_chain, 1.0))))
+        g1, g2 = sized(n2, k2, phases=1), sized(n2, k2, phases=2)
+        out["two_chain_groups"] = {"sample_reads": n2, "one_group": g1, "two_groups": g2,
+                                   "size_ratio_two_groups_vs_one": round(g2["bytes"] / g1["bytes"], 4)}
+    return out
 
 
 def headline_line(a, world, el, st, G):
@@ -141,19 +150,27 @@ def headline_line(a, world, el, st, G):
             "parallelism": "1 process per GPU, independent lanes" if world > 1 else "single GPU",
             "stage_ms": {k: round(st[k], 2) for k in ("ms_unpack", "ms_dict", "ms_chains", "ms_finalize")},
             "unmatched": st["unmatched"], "singletons": st["n_single"], "rounds": st["rounds"],
+            "chain_groups": int(st.get("phases", 1)),  # 2: the chains run as two groups whose rounds alternate (opts.phases)
         },
     }
 
 
-def roofline_block(alg_bytes, kernel_ms, launches, traffic):
+def roofline_block(alg_bytes, kernel_ms, launches, traffic, busy_ms=None):
     """`roofline` of the bench line from the algorithmic bytes of all launches, their summed duration (HIP events) and
-    the PMC traffic per launch (or None)."""
+    the PMC traffic per launch (or None).  busy_ms: the time during which at least one launch was running (the union of
+    their intervals, from the same events).  With the two-group schedule (stats.phases = 2) two launches of the kernel run
+    side by side nearly all the time, each of them slowed by the other: `achieved` = bytes of all launches / busy time =
+    bytes per launch / average launch duration x the average number of launches running at a time (`concurrent_launches`).
+    With one launch at a time (busy_ms = kernel_ms) that is bytes per launch / average launch duration."""
     launches = max(int(launches), 1)
-    ach = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    busy = busy_ms if busy_ms and busy_ms > 0 else kernel_ms
+    ach = alg_bytes / (busy * 1e-3) / 1e9 if busy > 0 else 0.0
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
             "launches": launches, "avg_launch_us": round(kernel_ms * 1e3 / launches, 2),
-            "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1)}
+            "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
+            "concurrent_launches": round(kernel_ms / busy, 3) if busy > 0 else None, "busy_ms": round(busy, 2),
+            "achieved_per_launch_alone": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None}
 
 
 def kernels_sha():
@@ -340,8 +357,9 @@ def main():
         alg_search = algorithmic_bytes_search(sr, W)
         alg = alg_search + algorithmic_bytes_apply(sr)
         ms = st_t["ms_search_kernel"]
+        busy = st_t.get("ms_search_busy") or ms
         launches = max(st_t["search_launches"], 1)
-        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        phases = max(int(st_t.get("phases", 1)), 1)
         # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so the
         # figure comes from the committed summary of separate --pmc passes over this same command
         # (profiles/README.md; FETCH_SIZE*1024 + WRITE_SIZE*1024, calibrated on tools/random_gather_bench:
@@ -362,15 +380,17 @@ def main():
         try:
             fetch = ks["fetch_bytes_per_launch"] if traffic is not None else None
             if fetch:
-                rate = fetch / 64.0 / (ms * 1e-3 / launches) / 1e9
+                rate = fetch * launches / 64.0 / (busy * 1e-3) / 1e9  # (all launches' requests over the time any of them ran)
                 req = {"achieved": round(rate, 2), "peak": RANDOM_REQ_PEAK_G, "unit": "G random 64-byte requests/s",
                        "frac": round(rate / RANDOM_REQ_PEAK_G, 3)}
         except Exception:
             req = None
-        out["roofline"] = roofline_block(alg, ms, launches, traffic)
+        out["roofline"] = roofline_block(alg, ms, launches, traffic, busy)
         out["roofline"].update({
             "traffic_kernels_sha": kernels_sha(),
-            "kernel": "sr::k_round_mc (four chains per wavefront: apply of the last proposal + Hamming search)",
+            "kernel": "sr::k_round_mc (four chains per wavefront: apply of the last proposal + Hamming search)"
+                      + ("; two chain groups: a launch covers half of the chains and runs beside the other group's launch" if phases == 2 else ""),
+            "phases": phases, "chains_per_launch": int(st["chains"]) // phases,
             "algorithmic_bytes_per_read": round(alg / n, 1),
             "algorithmic_bytes_model": "SURVEY 8(d): P*16 + Kv*(4+B) + C*(7+B) [search] + R*12 + E*16 [claims, emission]; "
                                        "the chain state the kernel also moves (counts, consensus) is not counted",
@@ -381,7 +401,7 @@ def main():
             "valu_issue_frac": ks.get("valu_issue_frac") if traffic is not None else None,
             # the L1 miss queue (profiles/r03_tcp_queue.txt, r04_minimizer_table.txt): L1 -> L2 read requests per chain and round,
             # their mean latency in L1 clocks, and how many are in flight per CU on average (the queue is 64 deep)
-            "l1_requests_per_chain_round": (round(ks["l1_read_requests_per_launch"] / st["chains"], 1)
+            "l1_requests_per_chain_round": (round(ks["l1_read_requests_per_launch"] / (st["chains"] / phases), 1)
                                             if traffic is not None and ks.get("l1_read_requests_per_launch") else None),
             "l1_request_latency_clocks": (round(ks["l1_read_request_latency_clocks"], 0)
                                           if traffic is not None and ks.get("l1_read_request_latency_clocks") else None),
@@ -615,7 +635,7 @@ def main():
         # compiled in place, test infrastructure oracle/_ref/ref_bsc, outside any timed region) for the default chain
         # count against the reference's own granularity K = num_thr, same reads
         try:
-            out["compression_cost"] = compression_cost(spring_amd, a, dev, n / max(float(st.get("chains", 0)), 1.0))
+            out["compression_cost"] = compression_cost(spring_amd, a, dev, n / max(float(st.get("chains", 0)), 1.0), int(st.get("phases", 1)))
         except Exception as e:  # noqa: BLE001
             out["compression_cost"] = {"error": repr(e)}
     if rank == 0:

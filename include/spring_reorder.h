@@ -105,9 +105,9 @@ typedef struct {
                              was after its own last round and loses a read the other group took in between; group 0 takes its
                              contig seeds from the upper half of the read ids, group 1 from the lower half.  The OUTPUT DEPENDS on
                              it for num_chains > 1 (both are legal `-t K` interleavings).  0 = the library's choice, reported in
-                             stats.phases: 2 where the four-chains-per-wavefront round kernel runs on one GPU with at least 49 152
-                             chains, else 1.  2 needs that kernel (shallow dictionary, no work counters, one GPU), at least 4 096
-                             chains and fewer than 2^31 reads */
+                             stats.phases: 2 from 49 152 chains on where it can run, else 1.  2 needs the fused round without the
+                             deep-bin machinery (a shallow dictionary), one GPU, one candidate per proposal, at least 4 096 chains and
+                             8 192 .. 2^31 - 1 reads */
 } spring_reorder_opts;
 
 typedef struct {
@@ -134,6 +134,8 @@ typedef struct {
   uint64_t long_splits;    /* long searches that were split into parts over several blocks (k_long) */
   uint64_t alternatives;   /* candidates per match proposal the chain phase ran with (opts.alternatives, or the library's choice) */
   uint64_t phases;         /* chain groups the chain phase ran with (opts.phases, or the library's choice) */
+  double ms_search_busy;   /* time_search = 1: the time during which at least one round kernel was running (the union of the
+                              launches' intervals); = ms_search_kernel unless two chain groups run side by side (phases = 2) */
 } spring_reorder_stats;
 
 void spring_reorder_default_opts(spring_reorder_opts *o);

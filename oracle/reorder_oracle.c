@@ -989,7 +989,7 @@ int orc_reorder_rounds_alt(const uint64_t *read, const uint16_t *len, uint32_t n
 /* -------------------------------------------------- K-chain schedule with two chain groups (opts.phases = 2)
  *
  * The rounds schedule above leaves the GPU draining between rounds (every chain waits for the slowest of the round).
- * Here the chains form two groups, [0, Kh) and [Kh, K) with Kh = K/2 rounded up to a multiple of 2048, whose rounds
+ * Here the chains form two groups, [0, Kh) and [Kh, K) with Kh = K/2 rounded to the nearest multiple of 2048 (at least 2048), whose rounds
  * ALTERNATE: half-step h belongs to group h & 1.  In its half-step a group does what a round does above, with two
  * differences that make its search independent of the other group's half-step in front of it (so that on the GPU the
  * two can run side by side):
@@ -1058,7 +1058,10 @@ static void ph_apply(rctx_t *x, chain_t *c, const uint64_t *read, const uint16_t
   (void)x;
 }
 
-uint32_t orc_phase_split(uint32_t K) { return (uint32_t)((((uint64_t)K / 2 + 2047) / 2048) * 2048); }
+uint32_t orc_phase_split(uint32_t K) {
+  const uint64_t h = (((uint64_t)K / 2 + 1024) / 2048) * 2048;
+  return (uint32_t)(h < 2048 ? 2048 : h);
+}
 
 int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
                           int num_thr, orc_out *out, orc_stats *st) {

@@ -65,7 +65,8 @@ class Stats(C.Structure):
                 + [("search_launches", C.c_uint64), ("device_bytes", C.c_uint64),
                    ("ms_exchange", C.c_double), ("ms_resolve_mark", C.c_double), ("chains", C.c_uint64),
                    ("deep_pool", C.c_uint64), ("long_searches", C.c_uint64),
-                   ("table_minz", C.c_uint64), ("table_marked_lines", C.c_uint64), ("long_splits", C.c_uint64), ("alternatives", C.c_uint64), ("phases", C.c_uint64)])
+                   ("table_minz", C.c_uint64), ("table_marked_lines", C.c_uint64), ("long_splits", C.c_uint64), ("alternatives", C.c_uint64), ("phases", C.c_uint64),
+                   ("ms_search_busy", C.c_double)])
 
     def asdict(self):
         d = {}

@@ -189,7 +189,7 @@ struct DevParams {
   long long *cursor;  // the seed cursor the launch works with (&glob->cursor; the second chain group: &glob->cursor_b)
   // chains: this context owns global chains [c0, c0+K) of Ktot (single GPU: c0 = 0, Ktot = K)
   uint32_t K, c0, Ktot;
-  // The two-group schedule (phases = 2; specification: oracle/reorder_oracle.c::orc_reorder_rounds_ph).
+  // The two-group schedule (phases = 2; specification: orc_reorder_rounds_ph (the test suite's CPU restatement of the schedule)).
   // The chains run as two groups -- [0, Kh) and [Kh, K), Kh a multiple of 2048 -- whose rounds alternate: group g searches
   // on ITS view of the pool (taken = view_g: everything marked up to its own last mark step), while the other group's mark
   // step runs; its mark step (k_ph_mark) then resolves its proposals against the other group's view as well (taken_other:

@@ -852,14 +852,14 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
     // multi-GPU pools (k_mg_bits fills needy_cnt): needy_cnt[b] = seed-needing chains among chains
     // [2048 b, 2048 b + 2048), then the 64 bitmap words of this chain's own block -- two independent loads per
     // lane, whatever the total number of chains
-    const uint32_t nblk = (nw + 63) / 64, myblk = myw >> 6;
+    const uint32_t myblk = myw >> 6;  // (ranks count the chains of this launch's group: blocks [nb_lo, nb_hi) of 2048 chains)
     {
       const uint32_t w = myblk * 64 + lane;
       const uint32_t v = w < nw ? P.needy[w] : 0u;
       if (w < myw) r += __popc(v);
       else if (w == myw) r += __popc(v & ((1u << (cid & 31)) - 1u));
     }
-    for (uint32_t b = lane; b < nblk; b += 64) {
+    for (uint32_t b = P.nb_lo + lane; b < P.nb_hi; b += 64) {
       const uint32_t v = P.needy_cnt[b];
       tot += (int)v;
       if (b < myblk) r += (int)v;
@@ -891,7 +891,8 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   // taken bit).  Seeds are always taken from the top and every read above the cursor is taken, so below the cursor's
   // block ublk[] is the exact number of untaken reads; the cursor's own block is counted from its bitmap words
   // (WPL per lane, highest first), which are fetched together with the counts of the 63 blocks below it.
-  if (top < 0) return -1;
+  if (top < (long long)P.seed_lo) return -1;  // (seeds come from reads [seed_lo, ...): the whole pool unless the chains run in two groups)
+  const long long blo = (long long)(P.seed_lo >> UBLK_SHIFT);
   const long long bt = top >> UBLK_SHIFT;
   constexpr int WPB_ = 1 << (UBLK_SHIFT - 6);  // bitmap words per block
   constexpr int WPL = WPB_ / 64;               // ... per lane
@@ -929,13 +930,13 @@ __device__ __forceinline__ long long find_seed(const DevParams &P, uint32_t cid,
   uint64_t uu[WPL];
   {
     const long long b = bt - 1 - lane;
-    int u = b >= 0 ? (int)P.ublk[b] : 0;  // (in flight together with the cursor block's words)
+    int u = b >= blo ? (int)P.ublk[b] : 0;  // (in flight together with the cursor block's words)
     const int cnt = load_block(bt, uu);
     const uint32_t tot0 = (uint32_t)wave_sum_i(cnt);
     if (tot0 >= need) return pick_in_block(bt, uu, cnt, need);
     need -= tot0;
-    for (long long b0 = bt - 1; b0 >= 0; b0 -= 64) {
-      if (b0 != bt - 1) { const long long bb = b0 - lane; u = bb >= 0 ? (int)P.ublk[bb] : 0; }
+    for (long long b0 = bt - 1; b0 >= blo; b0 -= 64) {
+      if (b0 != bt - 1) { const long long bb = b0 - lane; u = bb >= blo ? (int)P.ublk[bb] : 0; }
       const int incl = wave_incl_scan_i(u, lane);
       const uint32_t total = (uint32_t)__shfl(incl, 63, 64);
       if (total < need) { need -= total; continue; }
@@ -1917,7 +1918,7 @@ __device__ __forceinline__ void round_body(const DevParams &P) {
   static_assert(sizeof(WaveLds) <= sizeof(uint32_t) * STAGE_WORDS, "WaveLds overlays s_stage");
   WaveLds &lds = *reinterpret_cast<WaveLds *>(s_stage);
   const int lane = threadIdx.x;
-  const uint32_t li = blockIdx.x;
+  const uint32_t li = P.g0 + blockIdx.x;  // (two-group schedule: the launch covers the chains [g0, g0 + Kg); else g0 = 0)
   const uint32_t cid = P.c0 + li;
   Chain *c = &P.chains[li];
 #ifdef SR_PHASE_TIMING
@@ -2683,7 +2684,7 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
   }
 }
 // ---------------------------------------------- the two-group schedule (DevParams::phases = 2): one group's mark step
-// Specification: oracle/reorder_oracle.c::orc_reorder_rounds_ph.  The launch covers the chains [g0, g0 + Kg) of ONE group
+// Specification: orc_reorder_rounds_ph (the test suite's CPU restatement of the schedule).  The launch covers the chains [g0, g0 + Kg) of ONE group
 // (one GPU: c0 = 0).  What k_mg_mark does for every chain -- winners claim their read, the lowest seed of the round moves the
 // cursor, needy bitmap + counts, running chains, the class lists of k_round_mc -- for this group's chains, on this group's
 // view (taken / resv / cursor / needy counts are the group's own); and what only two groups need:
@@ -3070,8 +3071,8 @@ void launch_apply(hipStream_t st, const DevParams &P, bool literal) {
 }
 // fused round: one wavefront (= one block) per chain; NP = 3 covers reads up to 192 bases, 8 the rest
 void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
-  if (!P.K) return;
-  const dim3 g(P.K), b(64);
+  if (!P.K || !P.Kg) return;
+  const dim3 g(P.Kg), b(64);
   const size_t dyn = (size_t)P.dbg_search_lds;
   // four chains per wavefront (k_round_mc) unless the run needs what only the one-chain kernel has: the
   // reference-equivalent work counters, or the deep-bin machinery (tail trimming, balanced scan, resumed searches)

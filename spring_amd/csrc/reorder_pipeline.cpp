@@ -1469,15 +1469,15 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // kernel runs (what it buys is the drain of that kernel: a round costs ~46 us + 158 us per 65 536 chains, and two half
   // launches side by side cost what their chains cost -- tools/overlap_probe.py: 395 -> 320 ms on 100 M x 150 bp).
   {
-    const uint32_t half = (uint32_t)((((uint64_t)K / 2 + 2047) / 2048) * 2048);  // group 0: chains [0, half)
+    const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)K / 2 + 1024) / 2048) * 2048, 2048);  // group 0: chains [0, half): K / 2 to the nearest multiple of 2048
     const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
-    const bool can = allow_phases && fused && P.mc && !ctx->o.collect_stats && !P.deep_bins && P.alts == 1 && Ktot == K && c0 == 0 &&
+    const bool can = allow_phases && fused && !P.deep_bins && P.alts == 1 && Ktot == K && c0 == 0 &&
                      !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
     const int want = ctx->o.phases > 0 ? ctx->o.phases : (K >= 49152 ? 2 : 1);
     if (ctx->o.phases == 2 && !can)
-      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the four-chain round kernel (shallow dictionary, no work counters, fused >= 0 "
-                  "and not 2, at least 49152 chains or fused = 3), one GPU, one candidate per proposal, at least 4096 chains and "
-                  "8192 .. 2^31 - 1 reads");
+      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path) without the deep-bin "
+                  "machinery (a shallow dictionary, or deep_bins = -1), one GPU, one candidate per proposal, at least 4096 chains "
+                  "and 8192 .. 2^31 - 1 reads");
     if (ctx->o.phases > 2) return fail(SPRING_REORDER_E_ARG, "phases: 0 (library's choice), 1 or 2");
     P.phases = (want == 2 && can) ? 2 : 1;
     ctx->Kh = half; ctx->nmid = nmid;
@@ -1598,6 +1598,7 @@ static int running_chains(spring_reorder_ctx *ctx, std::vector<uint32_t> &buf, u
 static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
   DevParams &P = ctx->P;
   const uint32_t K = P.K;
+  const bool stats = ctx->o.collect_stats != 0;
   if (!ctx->st2) HIPCHK(hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking));
   if (!ctx->st3) HIPCHK(hipStreamCreateWithFlags(&ctx->st3, hipStreamNonBlocking));
   hipStream_t sg[2] = {ctx->st, ctx->st2}, sc = ctx->st3;
@@ -1637,7 +1638,7 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
   // group 1 starts behind the set-up (on the context's stream) and half a round late
   HIPCHK(hipEventRecord(ev0, sg[0]));
   HIPCHK(hipStreamWaitEvent(sg[1], ev0, 0));
-  launch_delay(sg[1], 90);
+  launch_delay(sg[1], 80);  // (the offset of the steady state sets itself within a few rounds whatever this is: 0 .. 160 us measured alike)
   bool have_b = false;
   uint64_t rounds = 0, launches = 0;
   double ms_search = 0;
@@ -1646,7 +1647,7 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
       for (int g = 0; g < 2; g++) {
         const DevParams Q = params_of(g);
         if (timed) HIPCHK(hipEventRecord(tev[4 * r + 2 * g], sg[g]));
-        launch_round(sg[g], Q, false, false);
+        launch_round(sg[g], Q, stats, false);
         if (timed) HIPCHK(hipEventRecord(tev[4 * r + 2 * g + 1], sg[g]));
         if (g == 1 || have_b) HIPCHK(hipStreamWaitEvent(sg[g], ev[g ^ 1], 0));  // the other group's last mark step
         launch_ph_mark(sg[g], Q);
@@ -1665,12 +1666,25 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
     HIPCHK(hipEventRecord(bev[slot], sc));
     return 0;
   };
+  double ms_busy = 0;
   auto collect_times = [&]() -> int {  // (time_search: the batch is complete)
+    // summed launch durations, and the time during which at least one of the launches was running: their union (the two
+    // groups' kernels run side by side, so the sum counts most of the batch twice)
+    std::vector<std::pair<float, float>> iv(2 * (size_t)R);
     for (int i = 0; i < 2 * R; i++) {
-      float ms = 0;
+      float ms = 0, s0 = 0;
       HIPCHK(hipEventElapsedTime(&ms, tev[2 * i], tev[2 * i + 1]));
+      HIPCHK(hipEventElapsedTime(&s0, tev[0], tev[2 * i]));
       ms_search += ms;
+      iv[i] = {s0, s0 + ms};
     }
+    std::sort(iv.begin(), iv.end());
+    float cs = iv[0].first, ce = iv[0].second;
+    for (size_t i = 1; i < iv.size(); i++) {
+      if (iv[i].first > ce) { ms_busy += ce - cs; cs = iv[i].first; ce = iv[i].second; }
+      else ce = std::max(ce, iv[i].second);
+    }
+    ms_busy += ce - cs;
     launches += 2 * (uint64_t)R;
     return 0;
   };
@@ -1710,6 +1724,7 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
   ctx->round_no = gp[0].round_no;
   ctx->stats.rounds = rounds;
   ctx->stats.ms_search_kernel = ms_search;
+  ctx->stats.ms_search_busy = ms_busy;
   ctx->stats.search_launches = launches;
   return 0;
 }
@@ -1840,6 +1855,7 @@ int spring_reorder_run_chains(spring_reorder_ctx *ctx) {
   for (auto &e : tev) (void)hipEventDestroy(e);
   ctx->stats.rounds = rounds;
   ctx->stats.ms_search_kernel = ms_search;
+  ctx->stats.ms_search_busy = ms_search;
   ctx->stats.search_launches = launches;
   ctx->stage = ST_CHAINS;
   return 0;
@@ -2108,7 +2124,7 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
   if (h_stage) (void)hipHostFree(h_stage);
   for (auto &e : tev) if (e) (void)hipEventDestroy(e);
   if (timed) {
-    ctx->stats.ms_search_kernel = ms_round; ctx->stats.search_launches = timed_rounds;
+    ctx->stats.ms_search_kernel = ms_round; ctx->stats.ms_search_busy = ms_round; ctx->stats.search_launches = timed_rounds;
     ctx->stats.ms_exchange = ms_xchg; ctx->stats.ms_resolve_mark = ms_mark;
   }
   if (ret) {

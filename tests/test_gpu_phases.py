@@ -24,9 +24,9 @@ def _same(a, b, what):
     assert np.array_equal(a["tid_off"], b["tid_off"]) and np.array_equal(a["tid_off_s"], b["tid_off_s"]), what
 
 
-def _run(n, L, G, K, T, seed=23, err=10000, **kw):
+def _run(n, L, G, K, T, seed=23, err=10000, fused=3, **kw):
     sa = _sa()
-    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, fused=3, deep_bins=-1, **kw)) as st:
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, fused=fused, deep_bins=-1, **kw)) as st:
         st.load_synth(n, L, G, seed, err)
         got = st.run().streams()
         dna = st.download_dna()
@@ -34,9 +34,9 @@ def _run(n, L, G, K, T, seed=23, err=10000, **kw):
 
 
 @pytest.mark.parametrize("n,L,cov,K,T", [(300_000, 100, 30, 4096, 8), (200_000, 150, 25, 6144, 3), (160_000, 150, 60, 8192, 2),
-                                         (100_000, 64, 20, 4100, 1), (60_000, 251, 25, 4096, 2), (40_000, 100, 25, 12288, 5)])
+                                         (100_000, 64, 20, 5000, 1), (60_000, 251, 25, 4096, 2), (40_000, 100, 25, 12288, 5)])
 def test_two_groups_vs_oracle(n, L, cov, K, T):
-    """Group sizes that differ (6144 -> 4096 + 2048; 4100 -> 4096 + 4), chains that outnumber the reads of a seed range
+    """Group sizes that differ (6144 -> 4096 + 2048; 5000 -> 2048 + 2952), chains that outnumber the reads of a seed range
     (12288 chains on 40 000 reads: most finish at once), read lengths of both instantiations of the round kernel."""
     got, dna = _run(n, L, n * L // cov, K, T, phases=2)
     assert got["stats"]["phases"] == 2 and got["stats"]["chains"] == K
@@ -45,6 +45,15 @@ def test_two_groups_vs_oracle(n, L, cov, K, T):
     _same(got, want, (n, L, K))
     assert got["stats"]["unmatched"] == want["stats"]["unmatched"] and got["stats"]["lost"] == want["stats"]["lost"]
     check_invariants(got, read, ln, L, n)
+    # the other mapping of a round to the hardware (one chain per wavefront), and its counting build: the same streams and
+    # the oracle's reference-equivalent work counters
+    one, _ = _run(n, L, n * L // cov, K, T, phases=2, fused=2)
+    _same(one, want, ("one chain per wavefront", n, L, K))
+    cnt, _ = _run(n, L, n * L // cov, K, T, phases=2, fused=0, collect_stats=True)
+    _same(cnt, want, ("counting build", n, L, K))
+    assert cnt["stats"]["phases"] == 2
+    for k in ("unmatched", "probes", "keyok", "cands", "hits", "iterations", "lost"):
+        assert cnt["stats"][k] == want["stats"][k], (k, cnt["stats"][k], want["stats"][k])
 
 
 def test_repeated_runs_and_batch_sizes_agree():
@@ -86,8 +95,8 @@ def test_one_group_schedule_untouched_and_library_choice():
 
 def test_refused_where_it_cannot_run():
     sa = _sa()
-    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=2), dict(num_chains=4096, fused=3, collect_stats=True),
-               dict(num_chains=4096, fused=3, alternatives=2), dict(num_chains=4096)):
+    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=-1), dict(num_chains=4096, deep_bins=1),
+               dict(num_chains=4096, fused=3, alternatives=2), dict(num_chains=4096, force_literal_update=True)):
         with sa.ReorderStage(sa.ReorderOpts(num_thr=1, phases=2, **kw)) as st:
             st.load_synth(50_000, 100, 200_000, 5, 10000)
             st.build_dict()

@@ -172,7 +172,7 @@ def test_alternatives_schedule_specification():
 def test_two_group_schedule_specification():
     """orc_reorder_rounds_ph (opts.phases = 2): every read claimed exactly once and every emitted record consistent with
     its contig (check_invariants), whatever the split of the chains; the group split is what the header says."""
-    assert po.lib().orc_phase_split(4096) == 2048 and po.lib().orc_phase_split(6144) == 4096 and po.lib().orc_phase_split(65536) == 32768
+    assert [po.lib().orc_phase_split(k) for k in (4096, 4100, 6144, 8191, 65536, 100000)] == [2048, 2048, 4096, 4096, 32768, 49152]
     for seed, n, L, G, K, T in ((5, 20_000, 100, 60_000, 4096, 3), (6, 30_000, 150, 4_000, 6144, 2), (7, 9_000, 64, 30_000, 4100, 1)):
         a = rs.np_reads(seed, G, n, L, 0.01)
         read, ln = po.load_dna(rs.pack_fixed(a), n, L)
