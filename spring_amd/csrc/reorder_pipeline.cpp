@@ -1450,30 +1450,19 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     P.alts = (want == 2 && can) ? 2 : 1;
     ctx->stats.alternatives = (uint64_t)P.alts;
   }
-  P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
-  // Four chains per wavefront pay when a launch holds several wavefronts per slot (5 120 slots of four chains): with
-  // fewer chains the GPU is not full and every wavefront waits for the slowest of its four.  25x, chains stage, four
-  // chains / one chain per wavefront: 4 882 chains (5 M reads) 74 / 47 ms, 19 531 (20 M) 106 / 100, 39 062 (40 M)
-  // 184 / 179, 65 536 (70 M) 282 / 293, 65 536 (100 M) 405 / 418 (tools/variant_probe2.py; at 60-100x the one-chain
-  // kernel's lead below 40 000 chains is 5-16 %)
-  if (K < 49152 && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
-  if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
-  if (ctx->minz && !(fused && P.mc && !ctx->o.collect_stats && !P.deep_bins))
-    return fail(SPRING_REORDER_E_ARG, "table_mode = 2 (minimizer-addressed table) is an experiment of the four-chain round kernel: "
-                "shallow dictionary, at least 49152 chains or fused = 3, no work counters");
-  if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !ctx->user_plan0) {
-    memset(P.plan[0], 0, sizeof(P.plan[0]));   // (fill_params assumed the four-chain kernel: 4 + 8 + 16)
-    P.plan[0][0] = 8; P.plan[0][1] = 16;
-  }
-  // The chain schedule (opts.phases, DevParams::phases): two chain groups whose rounds alternate where the four-chain round
-  // kernel runs (what it buys is the drain of that kernel: a round costs ~46 us + 158 us per 65 536 chains, and two half
-  // launches side by side cost what their chains cost -- tools/overlap_probe.py: 395 -> 320 ms on 100 M x 150 bp).
+  // The chain schedule (opts.phases, DevParams::phases): two chain groups whose rounds alternate.  What it buys is what a
+  // round costs beyond its chains -- the drain of the round kernel, the mark step, the kernel boundaries (~46 us + 158 us per
+  // 65 536 chains with one group): two half launches side by side cost what their chains cost.  Chains stage, 25x pools,
+  // one group / two groups (one chain per wavefront) / two groups (four chains per wavefront): 15 M reads (14 648 chains)
+  // 82 / 81 / 105 ms, 25 M 119 / 109 / 121, 30 M 140 / 129 / 130, 35 M 159 / 149 / 142, 70 M 285 / 234 / 234, 100 M
+  // 398 / - / 335; 5 M and 10 M reads are slower with two groups (47 -> 59, 65 -> 70: a group's launch no longer fills
+  // the chip).  So: two groups from 16 384 chains on, four chains per wavefront from 32 768 on (with one group: 49 152).
   {
     const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)K / 2 + 1024) / 2048) * 2048, 2048);  // group 0: chains [0, half): K / 2 to the nearest multiple of 2048
     const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
     const bool can = allow_phases && fused && !P.deep_bins && P.alts == 1 && Ktot == K && c0 == 0 &&
                      !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
-    const int want = ctx->o.phases > 0 ? ctx->o.phases : (K >= 49152 ? 2 : 1);
+    const int want = ctx->o.phases > 0 ? ctx->o.phases : (K >= 16384 ? 2 : 1);
     if (ctx->o.phases == 2 && !can)
       return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path) without the deep-bin "
                   "machinery (a shallow dictionary, or deep_bins = -1), one GPU, one candidate per proposal, at least 4096 chains "
@@ -1482,6 +1471,21 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     P.phases = (want == 2 && can) ? 2 : 1;
     ctx->Kh = half; ctx->nmid = nmid;
     ctx->stats.phases = (uint64_t)P.phases;
+  }
+  P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
+  // Four chains per wavefront pay when a launch holds several wavefronts per slot (5 120 slots of four chains): with
+  // fewer chains the GPU is not full and every wavefront waits for the slowest of its four.  25x, chains stage, four
+  // chains / one chain per wavefront: 4 882 chains (5 M reads) 74 / 47 ms, 19 531 (20 M) 106 / 100, 39 062 (40 M)
+  // 184 / 179, 65 536 (70 M) 282 / 293, 65 536 (100 M) 405 / 418 (tools/variant_probe2.py; at 60-100x the one-chain
+  // kernel's lead below 40 000 chains is 5-16 %)
+  if (K < (P.phases == 2 ? 32768u : 49152u) && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
+  if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
+  if (ctx->minz && !(fused && P.mc && !ctx->o.collect_stats && !P.deep_bins))
+    return fail(SPRING_REORDER_E_ARG, "table_mode = 2 (minimizer-addressed table) is an experiment of the four-chain round kernel: "
+                "shallow dictionary, at least 49152 chains or fused = 3, no work counters");
+  if (!P.mc && !P.deep_bins && ctx->o.first_shifts == 0 && !ctx->user_plan0) {
+    memset(P.plan[0], 0, sizeof(P.plan[0]));   // (fill_params assumed the four-chain kernel: 4 + 8 + 16)
+    P.plan[0][0] = 8; P.plan[0][1] = 16;
   }
   P.g0 = 0; P.Kg = K; P.g0_other = 0; P.Kg_other = 0;
   P.seed_lo = 0; P.seed_hi = n;

@@ -300,10 +300,11 @@ def test_full_size_properties_100M_150bp():
     n, L, T = 100_000_000, 150, 8
     outs = []
     for _ in range(2):
-        with sa.ReorderStage(sa.ReorderOpts(num_thr=T)) as s:
+        with sa.ReorderStage(sa.ReorderOpts(num_thr=T, phases=-1)) as s:  # (the library's choice: two chain groups at this size)
             s.load_synth(n, L, n * L // 25, 11, 10000)  # counter-based generator: same bytes both times
             outs.append(s.run().streams())
     a, b = outs
+    assert a["stats"]["phases"] == 2 and a["stats"]["chains"] == 65536
     for k in KEYS:
         assert np.array_equal(a[k], b[k]), k
     seen = np.zeros(n, dtype=np.uint8)
@@ -545,6 +546,37 @@ def test_parity_10M_reads():
             st.load_synth(n, L, n * L // 25, 3, 10000)
             got = st.run().streams()
         _same(got, want, ("10M-production", fused))
+        assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+        for k in ("unmatched", "lost"):
+            assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
+
+
+@pytest.mark.slow
+def test_parity_10M_reads_two_chain_groups():
+    """The same pool under the schedule with two chain groups (opts.phases = 2, what the library runs from 16 384 chains
+    on): the counting build (streams + reference-equivalent work counters) and both production mappings against
+    orc_reorder_rounds_ph."""
+    sa = _sa()
+    n, L, T = 10_000_000, 150, 8
+    K = max(1, min(65536, n >> 10))
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, collect_stats=True, phases=2)) as st:
+        st.load_synth(n, L, n * L // 25, 3, 10000)
+        got = st.run().streams()
+        dna = st.download_dna()
+    assert got["stats"]["phases"] == 2
+    read, ln = po.load_dna(dna, n, L)
+    del dna
+    want = po.reorder_rounds_ph(read, ln, L, K, T)
+    _same(got, want, "10M, two groups")
+    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+    for k in ("probes", "keyok", "cands", "hits", "unmatched", "iterations", "lost"):
+        assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])
+    del got
+    for fused in (3, 0):
+        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, fused=fused, phases=2)) as st:
+            st.load_synth(n, L, n * L // 25, 3, 10000)
+            got = st.run().streams()
+        _same(got, want, ("10M-production, two groups", fused))
         assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
         for k in ("unmatched", "lost"):
             assert got["stats"][k] == want["stats"][k], (k, got["stats"][k], want["stats"][k])

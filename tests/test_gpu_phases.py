@@ -82,15 +82,25 @@ def test_contended_pool_two_groups():
 
 
 def test_one_group_schedule_untouched_and_library_choice():
-    """phases = 1 is the rounds schedule of every other test; the library's own choice below 49 152 chains is 1."""
+    """phases = 1 is the rounds schedule of every other test; the library's own choice (negative, like 0 outside this test
+    suite: conftest.py) is one group below 16 384 chains and two from there on."""
     n, L, K = 120_000, 100, 4096
     one, dna = _run(n, L, n * L // 25, K, 2, phases=1)
-    auto, _ = _run(n, L, n * L // 25, K, 2)
+    auto, _ = _run(n, L, n * L // 25, K, 2, phases=-1)
     assert one["stats"]["phases"] == 1 and auto["stats"]["phases"] == 1
     read, ln = po.load_dna(dna, n, L)
     want = po.reorder_rounds(read, ln, L, K, 2)
     _same(one, want, "phases = 1")
     _same(auto, want, "library's choice")
+    sa = _sa()
+    n, K = 200_000, 16384
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, phases=-1)) as st:  # (kernel mapping and schedule: the library's)
+        st.load_synth(n, L, n * L // 25, 23, 10000)
+        auto = st.run().streams()
+        dna = st.download_dna()
+    assert auto["stats"]["phases"] == 2
+    read, ln = po.load_dna(dna, n, L)
+    _same(auto, po.reorder_rounds_ph(read, ln, L, K, 2), "library's choice, 16 384 chains")
 
 
 def test_refused_where_it_cannot_run():
