@@ -53,6 +53,8 @@ def lib():
                                              C.c_void_p, C.c_void_p]
         L.orc_reorder_rounds_ph.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                             C.c_void_p, C.c_void_p]
+        L.orc_reorder_rounds_ph_alt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p]
         L.orc_phase_split.restype = C.c_uint32
         L.orc_phase_split.argtypes = [C.c_uint32]
         L.orc_reorder_omp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
@@ -279,14 +281,15 @@ def reorder_rounds(read, ln, L, num_chains, num_thr=1, alternatives=1):
     return _finish(o, arrs, st)
 
 
-def reorder_rounds_ph(read, ln, L, num_chains, num_thr=1):
+def reorder_rounds_ph(read, ln, L, num_chains, num_thr=1, alternatives=1):
     """The schedule with two chain groups whose rounds alternate (ReorderOpts.phases = 2)."""
     n = len(ln)
     read = np.ascontiguousarray(read, dtype=np.uint64)
     ln = np.ascontiguousarray(ln, dtype=np.uint16)
     o, arrs = _alloc_out(n, num_thr)
     st = OrcStats()
-    rc = lib().orc_reorder_rounds_ph(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr, C.byref(o), C.byref(st))
+    rc = lib().orc_reorder_rounds_ph_alt(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr, alternatives,
+                                         C.byref(o), C.byref(st))
     assert rc == 0, "orc_reorder_rounds_ph: needs num_chains >= 4096 and n >= 8192"
     return _finish(o, arrs, st)
 

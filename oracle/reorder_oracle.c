@@ -712,6 +712,7 @@ typedef struct {
   uint32_t prop_rid;
   uint32_t alt[8]; /* further passing candidates of the winning bin, in scan order */
   int nalt;
+  int got; /* two-group schedule: index of the candidate the chain secured in this half-step, -1 none */
   outbuf_t ob;
 } chain_t;
 
@@ -1065,8 +1066,16 @@ uint32_t orc_phase_split(uint32_t K) {
 
 int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
                           int num_thr, orc_out *out, orc_stats *st) {
+  return orc_reorder_rounds_ph_alt(read, len, n, L, K, num_thr, 1, out, st);
+}
+
+/* ... with A candidates per match proposal (orc_reorder_rounds_alt): a candidate is SECURED when it holds the group's resv[]
+ * entry of its pass (an earlier pass beats a later one, the lowest chain id wins a pass) AND the read is still free in
+ * truth; a chain that has not secured a candidate of an earlier pass proposes its next one */
+int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
+                              int num_thr, int A, orc_out *out, orc_stats *st) {
   const uint32_t Kh = orc_phase_split(K), nmid = (n / 2) & ~4095u;
-  if (K < 4096 || Kh >= K || num_thr <= 0 || nmid == 0) return -1;
+  if (K < 4096 || Kh >= K || num_thr <= 0 || nmid == 0 || A < 1 || A > 8) return -1;
   rctx_t x;
   memset(&x, 0, sizeof(x));
   memset(st, 0, sizeof(*st));
@@ -1144,34 +1153,58 @@ int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n,
         }
         c->num_reads_thr++;
       }
+      c->nalt = 0;
       if (!c->stop_searching) {
         uint32_t k; int sh, rv;
-        if (rounds_search(&x, &c->c, &k, &sh, &rv, NULL, 0, NULL)) {
+        if (rounds_search(&x, &c->c, &k, &sh, &rv, c->alt, A - 1, &c->nalt)) {
           c->prop_kind = PROP_MATCH; c->prop_rid = k; c->prop_shift = sh; c->prop_rev = rv;
         }
       }
     }
+    /* resolution in A passes (truth does not change before phase B: "free in truth" = not claimed up to half-step h - 1) */
+#define PH_SECURED(C, I, Q) (resv[g][(Q) ? (C)->alt[(Q) - 1] : (C)->prop_rid] == (((uint32_t)(Q) << 28) | (I)) && \
+                             !truth[(Q) ? (C)->alt[(Q) - 1] : (C)->prop_rid])
+    for (int p = 0; p < A; p++) {
+      for (uint32_t i = glo[g]; i < ghi[g]; i++) {
+        chain_t *c = &ch[i];
+        if (c->done || c->prop_kind == PROP_NONE) continue;
+        int got = 0;
+        for (int q = 0; q < p && !got; q++) {
+          if (q > c->nalt) break;
+          got = PH_SECURED(c, i, q);
+        }
+        if (got || p > c->nalt || (p > 0 && c->prop_kind != PROP_MATCH)) continue;
+        const uint32_t rp = p ? c->alt[p - 1] : c->prop_rid, key = ((uint32_t)p << 28) | i;
+        if (resv[g][rp] > key) resv[g][rp] = key;
+      }
+    }
+    /* ---- phase B: the first secured candidate is applied */
+    nwon[g] = 0;
+    /* (the secured candidates are judged first: truth must stay as it was while they are) */
     for (uint32_t i = glo[g]; i < ghi[g]; i++) {
       chain_t *c = &ch[i];
       if (c->done || c->prop_kind == PROP_NONE) continue;
-      if (resv[g][c->prop_rid] > i) resv[g][c->prop_rid] = i;
+      c->got = -1;
+      for (int q = 0; q <= c->nalt && c->got < 0; q++)
+        if (PH_SECURED(c, i, q)) c->got = q;
     }
-    /* ---- phase B: resolve (lowest chain id of the group, and the read still free in truth) + apply */
-    nwon[g] = 0;
     for (uint32_t i = glo[g]; i < ghi[g]; i++) {
       chain_t *c = &ch[i];
       if (c->done) continue;
       if (c->prop_kind != PROP_NONE) {
-        if (resv[g][c->prop_rid] != i || truth[c->prop_rid]) {
+        const int got = c->got;
+        if (got < 0) {
           st->lost++;
           if (c->mode == MODE_SEARCH) c->retrying = 1;
           continue;
         }
+        if (got > 0) c->prop_rid = c->alt[got - 1]; /* same probe, same alignment, the next read of the bin */
         truth[c->prop_rid] = 1;
         won[g][nwon[g]++] = c->prop_rid;
       }
       ph_apply(&x, c, read, len, L, W, st);
     }
+#undef PH_SECURED
     /* the group's view for its next half-step: the truth as of now (its own claims + the other group's last ones) */
     for (uint32_t j = 0; j < nwon[g]; j++) view[g][won[g][j]] = 1;
     for (uint32_t j = 0; j < nwon[g ^ 1]; j++) view[g][won[g ^ 1][j]] = 1;

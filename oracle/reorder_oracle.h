@@ -96,10 +96,12 @@ int orc_reorder_rounds_alt(const uint64_t *read, const uint16_t *len, uint32_t n
                        uint32_t num_chains, int num_thr, int alternatives, orc_out *out, orc_stats *st);
 
 /* the schedule with two chain groups whose rounds alternate (spring_reorder_opts::phases = 2; see reorder_oracle.c):
- * group 0 = chains [0, orc_phase_split(K)), group 1 the rest; needs K >= 4096 and n >= 8192; one candidate per proposal */
+ * group 0 = chains [0, orc_phase_split(K)), group 1 the rest; needs K >= 4096 and n >= 8192; _alt: with A candidates per match proposal */
 uint32_t orc_phase_split(uint32_t num_chains);
 int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
                           uint32_t num_chains, int num_thr, orc_out *out, orc_stats *st);
+int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
+                              uint32_t num_chains, int num_thr, int alternatives, orc_out *out, orc_stats *st);
 
 /* CPU-baseline port: T free-running OpenMP threads like the reference's `-t T`; NOT deterministic
  * for T > 1 (like the reference).  Outputs laid out per thread (tid_off has T+1 entries). */

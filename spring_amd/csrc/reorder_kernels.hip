@@ -77,6 +77,25 @@ __device__ __forceinline__ uint64_t lds_window(const uint64_t *s, int bitpos) {
 __device__ __forceinline__ bool is_taken(const uint64_t *__restrict__ taken, uint32_t rid) {
   return (taken[rid >> 6] >> (rid & 63)) & 1ull;
 }
+// Liveness of a bin entry for this launch.  r: the entry as loaded (with DevParams::epos bit 31 = its read is taken) -> the
+// read id.  One chain group: the flag IS the bitmap.  Two groups (DevParams::phases = 2): the flag is set once the read is
+// taken in BOTH groups' views (k_ph_mark sets it when it folds the other group's winners into its own view), so a set flag
+// still means dead -- for every launch, now and later: such an entry may be trimmed -- and a clear one means "ask this
+// group's bitmap" (the read may have been taken in this view only).  trimmable: dead for every group.
+__device__ __forceinline__ bool entry_dead(const DevParams &P, uint32_t &r, bool &trimmable) {
+  if (P.idmask != 0xffffffffu) {
+    const bool f = (r >> 31) != 0;
+    r &= 0x7fffffffu;
+    trimmable = f;
+    if (f || P.phases != 2) return f;
+    return is_taken(P.taken, r);
+  }
+  const bool d = is_taken(P.taken, r);
+  // (no flags: with two groups a dead entry is trimmed only when the other group's view has it too; that bitmap may be
+  // written beside this launch -- bits are only ever set, and a set bit holds for every later launch of either group)
+  trimmable = d && (P.phases != 2 || is_taken(P.taken_other, r));
+  return d;
+}
 
 // exact key -> bin map in two levels (replaces boomphf lookup + findpos + key re-check,
 // reorder.h:271-285), ONE table for both dictionaries (TabView, reorder_device.h):
@@ -1122,14 +1141,13 @@ __device__ __forceinline__ void eval_probe(const DevParams &P, const uint64_t *s
         }
         *walk_left = j;
       }
-      const uint32_t r = single ? pay : ids[start + j];
-      bool known_live = false;
-      if (TRIM && !single && P.idmask != 0xffffffffu) {  // (the entry itself says whether its read is taken)
-        if (r >> 31) continue;
-        known_live = true;
-      }
-      if (!SPEC && !known_live && is_taken(P.taken, r)) continue;
-      if (TRIM && top_live < 0) top_live = j;
+      uint32_t r = single ? pay : ids[start + j];
+      if (TRIM && !single) {  // (with DevParams::epos the entry itself says whether its read is taken)
+        bool trimmable;
+        const bool dead = entry_dead(P, r, trimmable);
+        if (top_live < 0 && !trimmable) top_live = j;  // (the dead tail above it is dead for every launch)
+        if (dead) continue;
+      } else if (!SPEC && is_taken(P.taken, r)) continue;
       const int wt = within_thresh(r, single);
       if (SPEC && wt == -2) continue;  // taken
       if (wt < 0) break;  // fingerprint collision (single-read bin)
@@ -1197,8 +1215,8 @@ __device__ __forceinline__ uint32_t find_alt(const DevParams &P, const uint64_t 
     bool live = false;
     if (j >= 0) {
       r = ids[start + (uint32_t)j];
-      if (P.idmask != 0xffffffffu) { live = !(r >> 31); r &= 0x7fffffffu; }
-      else live = !is_taken(P.taken, r);
+      bool tr_;
+      live = !entry_dead(P, r, tr_);
     }
     const uint64_t Lm = __ballot(live);
     uint64_t cand = Lm;
@@ -1311,7 +1329,7 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(ow, o, 64); if (lane >= o) ow = max(ow, t); }
       wave_sync();
-      bool lv = false, ps = false;
+      bool lv = false, ps = false, nt = false;  // live, passes, not trimmable (live, or dead in this group's view only)
       uint32_t r = 0;
       // (every lane takes part in the shuffles: a lane outside a branch supplies nothing)
       const int src = ow >= 0 ? ow : 0;
@@ -1322,9 +1340,9 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
         const int pl = ow & 1, prev = (ow >> 1) & 1, psh = sh_base + (ow >> 2);
         g_u32_t *pids = (g_u32_t *)(pl ? uni_ptr(P.ids[1]) : uni_ptr(P.ids[0]));
         r = pids[pst + (uint32_t)j];
-        bool dead;
-        if (P.idmask != 0xffffffffu) { dead = (r >> 31) != 0; r &= 0x7fffffffu; }
-        else dead = is_taken(P.taken, r);
+        bool trimmable;
+        const bool dead = entry_dead(P, r, trimmable);
+        nt = !trimmable;
         if (!dead) {
           lv = true;
           const int pds = pl ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
@@ -1332,13 +1350,13 @@ __device__ __forceinline__ void probe_batch(const DevParams &P, const uint64_t *
                              prev ? ref_len + psh : ref_len - psh, pds, klen2, r, false, stage, lane) == 1;
         }
       }
-      const uint64_t Lm = __ballot(lv), Pm = __ballot(ps);
+      const uint64_t Lm = __ballot(lv), Pm = __ballot(ps), Tm = __ballot(nt);
       bool myhit = false, fin = own && rem == 0;  // (a bin already trimmed to nothing)
       int hit_t = 0;
       if (take > 0) {
         const uint64_t mine = (take >= 64 ? ~0ull : ((1ull << take) - 1)) << off;
-        const uint64_t ml = Lm & mine, mp = Pm & mine;
-        if (top_live == -2 && ml) top_live = jn - (__ffsll((unsigned long long)ml) - 1 - off);
+        const uint64_t ml = Lm & mine, mp = Pm & mine, mt = Tm & mine;
+        if (top_live == -2 && mt) top_live = jn - (__ffsll((unsigned long long)mt) - 1 - off);
         if (mp) {
           hit_t = __ffsll((unsigned long long)mp) - 1;
           const int before = livec + __popcll(ml & ((1ull << hit_t) - 1));
@@ -2393,8 +2411,8 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_long_scan(DevParams P) {
                                       prev ? ref_len + psh : ref_len - psh, rk[k], sgk[k]) <= THRESH;
           tw[k] = ~0ull;
           if (has[k] && (kbig[k] || sp[k])) {
-            if (P.idmask != 0xffffffffu) tw[k] = kdead[k] ? ~0ull : 0ull;  // (the entry said it: no request)
-            else tw[k] = P.taken[rk[k] >> 6];
+            if (P.idmask != 0xffffffffu && (kdead[k] || P.phases != 2)) tw[k] = kdead[k] ? ~0ull : 0ull;  // (the entry said it: no request)
+            else tw[k] = P.taken[rk[k] >> 6];  // (two chain groups: a clear flag may still be a read taken in this group's view)
           }
         }
         // C: the entries that are free and pass the bound, packed in key order (chunk, then lane) into the staging rows
@@ -2471,7 +2489,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_long_scan(DevParams P) {
           const unsigned long long ahead = (unsigned long long)cq * 64 + cfp;  // entries of the bin visited before the pass
           uint32_t mycnt = 0;
           for (unsigned long long pp = (unsigned long long)tid; pp < ahead; pp += 64 * SCAN_WAVES)
-            { const uint32_t rr = pids[st0 + (cnt - 1 - (uint32_t)pp)]; mycnt += P.idmask != 0xffffffffu ? !(rr >> 31) : !is_taken(P.taken, rr); }
+            { uint32_t rr = pids[st0 + (cnt - 1 - (uint32_t)pp)]; bool tr_; mycnt += !entry_dead(P, rr, tr_); }
           const uint32_t wsum = (uint32_t)wave_sum_i((int)mycnt);
           if (wsum) atomicAdd(&s_ctl, lane == 0 ? wsum : 0u);
           __syncthreads();
@@ -2711,15 +2729,22 @@ __global__ __launch_bounds__(256) void k_ph_mark(DevParams P) {
     alive = pk != PK_DONE;
     if (alive) cls = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv & PK_WILLNEED_BIT) ? 3 : 0) : 3;
     if (pk == PK_MATCH || pk == PK_SEED) {
-      const uint32_t rid = (uint32_t)pv;
+      uint32_t rid = (uint32_t)pv;
       bool won = P.resv[rid] == cid;
       if (won && is_taken(P.taken_other, rid)) { won = false; P.resv[rid] = RESV_LOST; }
+      if (!won && pk == PK_MATCH && (pv >> PK_ALT_SHIFT)) {  // the alternatives schedule: the second candidate, secured in pass 1 (k_ph_alt_resolve)
+        const uint32_t alt = (uint32_t)(pv >> PK_ALT_SHIFT) - 1u;
+        if (P.resv[alt] == (ALT_KEY | cid)) {
+          if (is_taken(P.taken_other, alt)) P.resv[alt] = RESV_LOST;
+          else { won = true; rid = alt; }
+        }
+      }
       if (won) {
         atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
         if (pk == PK_MATCH && rid >= P.seed_lo && rid < P.seed_hi) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
         wonv = rid | (pk == PK_MATCH ? 0x80000000u : 0u);
       }
-      if (pv & PK_CURSOR_BIT) *P.cursor = (long long)rid - 1;  // every seed proposed this round ends up taken (by someone)
+      if (pv & PK_CURSOR_BIT) *P.cursor = (long long)(uint32_t)pv - 1;  // every seed proposed this round ends up taken (by someone)
       needy = pk == PK_SEED && !won;
       if (pk == PK_SEED && won && cls >= 0) cls = 1;
     } else if (pk == PK_NONE) {
@@ -2735,7 +2760,10 @@ __global__ __launch_bounds__(256) void k_ph_mark(DevParams P) {
     const uint32_t rid = w & 0x7fffffffu;
     atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
     if ((w >> 31) && rid >= P.seed_lo && rid < P.seed_hi) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+    mark_dead(P, rid);  // taken in both views from here on: its bin entries say so (entry_dead)
   }
+  if (t == 0 && P.longq) { P.longq[0] = 0; P.longq[1] = 0; }  // this group's long searches of the round are done (as in k_mg_mark)
+  if (P.longq && t < 2) P.lctl[t] = 0;
   const uint64_t nb = __ballot(needy);
   const uint32_t na = (uint32_t)__popcll(__ballot(alive));
   const uint32_t cb = cid & ~63u;  // (g0 is a multiple of 2048: a wavefront covers two whole bitmap words of its group)
@@ -2768,6 +2796,19 @@ __global__ __launch_bounds__(256) void k_ph_mark(DevParams P) {
       P.ord_cnt[segi] = make_uint4(s_wc[0][0] + s_wc[1][0] + s_wc[2][0] + s_wc[3][0], s_wc[0][1] + s_wc[1][1] + s_wc[2][1] + s_wc[3][1],
                                    s_wc[0][2] + s_wc[1][2] + s_wc[2][2] + s_wc[3][2], s_wc[0][3] + s_wc[1][3] + s_wc[2][3] + s_wc[3][3]);
   }
+}
+// pass 1 of the alternatives schedule for one group (k_alt_resolve; before the group's k_ph_mark, behind the other group's last
+// mark step): a chain that did not secure its first candidate -- it went to a lower chain id of the group, or to the
+// other group since the search -- proposes its second one
+__global__ void k_ph_alt_resolve(DevParams P) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.Kg) return;
+  const uint32_t cid = P.g0 + t;
+  const unsigned long long pv = P.prop[cid];
+  if (((int)(pv >> 32) & 7) != PK_MATCH || !(pv >> PK_ALT_SHIFT)) return;
+  const uint32_t rid = (uint32_t)pv;
+  if (P.resv[rid] == cid && !is_taken(P.taken_other, rid)) return;
+  atomicMin(&P.resv[(uint32_t)(pv >> PK_ALT_SHIFT) - 1u], ALT_KEY | cid);
 }
 // waits on the device: the second group's first round starts half a round after the first group's
 __global__ void k_delay(uint32_t us) {
@@ -3131,7 +3172,9 @@ void launch_mg_mark(hipStream_t st, const DevParams &P) {
   hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 }
 void launch_ph_mark(hipStream_t st, const DevParams &P) {
-  if (P.Kg) hipLaunchKernelGGL(k_ph_mark, GRID1(P.Kg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
+  if (!P.Kg) return;
+  if (P.alts == 2) hipLaunchKernelGGL(k_ph_alt_resolve, GRID1(P.Kg, 256), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_ph_mark, GRID1(P.Kg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
 }
 void launch_delay(hipStream_t st, uint32_t microseconds) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, microseconds); }
 void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot) {

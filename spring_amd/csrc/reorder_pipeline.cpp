@@ -156,6 +156,7 @@ struct spring_reorder_ctx {
   uint64_t *taken2 = nullptr;
   uint32_t *resv2 = nullptr, *won = nullptr;
   uint32_t Kh = 0, nmid = 0;
+  struct LongBufs { uint32_t *longq = nullptr, *lctl = nullptr, *lparts = nullptr; LongHead *lhead = nullptr; uint2 *lbin = nullptr; uint16_t *lbcode = nullptr; } lb2;  // group 1's (DevParams::longq ...)
   bool in_source_fallback = false;  // load_dna <-> load_dna_source recursion guard
   // FASTQ front end (f1): reads with N, per input file
   uint8_t *d_N[2] = {nullptr, nullptr};
@@ -1460,13 +1461,11 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   {
     const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)K / 2 + 1024) / 2048) * 2048, 2048);  // group 0: chains [0, half): K / 2 to the nearest multiple of 2048
     const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
-    const bool can = allow_phases && fused && !P.deep_bins && P.alts == 1 && Ktot == K && c0 == 0 &&
-                     !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
+    const bool can = allow_phases && fused && Ktot == K && c0 == 0 && !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
     const int want = ctx->o.phases > 0 ? ctx->o.phases : (K >= 16384 ? 2 : 1);
     if (ctx->o.phases == 2 && !can)
-      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path) without the deep-bin "
-                  "machinery (a shallow dictionary, or deep_bins = -1), one GPU, one candidate per proposal, at least 4096 chains "
-                  "and 8192 .. 2^31 - 1 reads");
+      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path), one GPU, at least 4096 "
+                  "chains and 8192 .. 2^31 - 1 reads");
     if (ctx->o.phases > 2) return fail(SPRING_REORDER_E_ARG, "phases: 0 (library's choice), 1 or 2");
     P.phases = (want == 2 && can) ? 2 : 1;
     ctx->Kh = half; ctx->nmid = nmid;
@@ -1492,6 +1491,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   P.nb_lo = 0; P.nb_hi = (Ktot + 2047) / 2048;
   P.taken_other = nullptr; P.won = P.won_other = nullptr;
   ctx->taken2 = nullptr; ctx->resv2 = nullptr; ctx->won = nullptr;
+  ctx->lb2 = spring_reorder_ctx::LongBufs();
   if (P.phases == 2) {
     DMALLOC(ctx->taken2, nwords * 8);
     DMALLOC(ctx->resv2, nn * 4);
@@ -1532,6 +1532,17 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
       DMALLOC(P.lhead, (size_t)K * sizeof(LongHead));
       DMALLOC(P.lbin, (size_t)K * P.lbin_stride * sizeof(uint2));
       DMALLOC(P.lbcode, (size_t)K * P.lbin_stride * sizeof(uint16_t));
+      if (P.phases == 2) {  // the second chain group's own set: its long-search kernels run beside the first group's
+        const size_t K1 = (size_t)K - ctx->Kh;
+        DMALLOC(ctx->lb2.longq, (K1 + 2) * 4);
+        HIPCHK(hipMemsetAsync(ctx->lb2.longq, 0, 8, st));
+        DMALLOC(ctx->lb2.lctl, 64);
+        HIPCHK(hipMemsetAsync(ctx->lb2.lctl, 0, 64, st));
+        DMALLOC(ctx->lb2.lparts, K1 * LONG_MAX_PARTS * 4);
+        DMALLOC(ctx->lb2.lhead, K1 * sizeof(LongHead));
+        DMALLOC(ctx->lb2.lbin, K1 * P.lbin_stride * sizeof(uint2));
+        DMALLOC(ctx->lb2.lbcode, K1 * P.lbin_stride * sizeof(uint16_t));
+      }
       for (int l = 0; l < 2; l++) {  // ... and the signatures k_long rejects most bin entries from (16 bytes per dictionary entry)
         ulonglong2 *sg = nullptr;
         const uint64_t m = ctx->dict[l].numreads;
@@ -1617,18 +1628,23 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
     Q.nb_lo = a.g0 / 2048; Q.nb_hi = (a.g0 + a.Kg + 2047) / 2048;
     Q.taken = a.taken; Q.taken_other = b.taken; Q.resv = a.resv; Q.cursor = a.cursor;
     Q.won = ctx->won + a.g0; Q.won_other = ctx->won + b.g0;
+    if (g == 1 && P.longq) {
+      Q.longq = ctx->lb2.longq; Q.lctl = ctx->lb2.lctl; Q.lparts = ctx->lb2.lparts; Q.lhead = ctx->lb2.lhead;
+      Q.lbin = ctx->lb2.lbin; Q.lbcode = ctx->lb2.lbcode;
+    }
     const int w = (int)(a.round_no & 1);  // (set_round_buffers, per group: the groups touch disjoint blocks of the buffers)
     Q.needy_cnt = ctx->cnt_buf[w ^ 1]; Q.needy_cnt_next = ctx->cnt_buf[w];
     return Q;
   };
-  hipEvent_t ev[2] = {nullptr, nullptr}, bev[2] = {nullptr, nullptr}, ev0 = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr}, bev[2] = {nullptr, nullptr}, ev0 = nullptr, evt = nullptr;
   struct EvFree { hipEvent_t *e; int n; ~EvFree() { for (int i = 0; i < n; i++) if (e[i]) (void)hipEventDestroy(e[i]); } };
-  EvFree g1{ev, 2}, g2{bev, 2}, g3{&ev0, 1};
+  EvFree g1{ev, 2}, g2{bev, 2}, g3{&ev0, 1}, g4{&evt, 1};
   for (int i = 0; i < 2; i++) {
     HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&bev[i], hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
   std::vector<hipEvent_t> tev;  // opts.time_search: an event pair around every round-kernel launch, on the launch's stream
   struct TevFree { std::vector<hipEvent_t> &v; ~TevFree() { for (auto &e : v) (void)hipEventDestroy(e); } } tev_guard{tev};
   if (timed) {
@@ -1661,6 +1677,15 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
       have_b = true;
     }
     rounds += R;
+    if (P.deep_bins && (ctx->dict[0].ndeep || ctx->dict[1].ndeep)) {
+      // compaction of the deep bins (k_trim_bins moves bin entries: no search may run beside it): both groups meet here, every
+      // R rounds -- the entries it drops are dead in both groups' views (their flags, or group 0's bitmap, the smaller one here)
+      HIPCHK(hipStreamWaitEvent(sg[0], ev[1], 0));
+      for (int l = 0; l < 2; l++)
+        launch_trim_bins(sg[0], ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, gp[0].taken, const_cast<ulonglong2 *>(P.sig[l]), P.epos[l]);
+      HIPCHK(hipEventRecord(evt, sg[0]));
+      HIPCHK(hipStreamWaitEvent(sg[1], evt, 0));
+    }
     return 0;
   };
   auto count_batch = [&](int slot) -> int {  // behind both groups' last mark steps of the batch
@@ -2256,6 +2281,10 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
     uint32_t ns = 0;  // (k_mg_mark zeroes [0..1] every round, [3] counts the run's split searches)
     HIPCHK(hipMemcpy(&ns, P.lctl + 3, 4, hipMemcpyDeviceToHost));
     s.long_splits = ns;
+    if (P.phases == 2 && ctx->lb2.lctl) {  // (the second chain group's)
+      HIPCHK(hipMemcpy(&ns, ctx->lb2.lctl + 3, 4, hipMemcpyDeviceToHost));
+      s.long_splits += ns;
+    }
   }
   ctx->dfree(d_off_m); ctx->dfree(d_off_s);
   // the append-order buffers are no longer needed

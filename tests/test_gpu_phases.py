@@ -81,6 +81,37 @@ def test_contended_pool_two_groups():
     assert got["stats"]["lost"] == want["stats"]["lost"] and want["stats"]["lost"] > 0
 
 
+@pytest.mark.parametrize("A", [1, 2])
+@pytest.mark.parametrize("budget,flags", [(-1, 0), (0, 0), (1, 0), (3, -1), (-1, -1)])
+@pytest.mark.parametrize("n,L,G,K", [(120_000, 100, 3_000, 4096), (90_000, 150, 900, 4300), (150_000, 120, 40_000, 6144)])
+def test_two_groups_deep_bin_kernels(n, L, G, K, A, budget, flags):
+    """The deep-bin machinery under two chain groups: bin entries that carry their read's taken bit (set once BOTH groups'
+    views have the read; a clear flag asks the group's bitmap), dead tails trimmed only where they are dead for both
+    groups, bin compaction where the groups meet, the long-search kernels with a queue per group (budget 1: nearly every
+    search over a multi-read bin), two candidates per proposal (k_ph_alt_resolve).  Bins of hundreds to thousands of reads,
+    some beyond MAX_SEARCH_REORDER."""
+    sa = _sa()
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, deep_bins=1, long_budget=budget, long_split=1 if budget == 1 else 0,
+                                        entry_flags=flags, alternatives=A, phases=2)) as st:
+        st.load_synth(n, L, G, 23, 10000)
+        got = st.run().streams()
+        dna = st.download_dna()
+    assert got["stats"]["phases"] == 2 and got["stats"]["alternatives"] == A
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds_ph(read, ln, L, K, 2, alternatives=A)
+    _same(got, want, ("deep", n, K, A, budget, flags))
+    assert got["stats"]["lost"] == want["stats"]["lost"] and got["stats"]["unmatched"] == want["stats"]["unmatched"]
+    if budget > 0:
+        assert got["stats"]["long_searches"] > 0
+    if budget == 0 and flags == 0:  # the counting build (serial walks instead of the balanced scan) and its work counters
+        with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, deep_bins=1, alternatives=A, phases=2, collect_stats=True)) as st:
+            st.load_synth(n, L, G, 23, 10000)
+            cnt = st.run().streams()
+        _same(cnt, want, ("deep, counting build", n, K, A))
+        for k in ("unmatched", "probes", "keyok", "cands", "hits", "iterations", "lost"):
+            assert cnt["stats"][k] == want["stats"][k], (k, cnt["stats"][k], want["stats"][k])
+
+
 def test_one_group_schedule_untouched_and_library_choice():
     """phases = 1 is the rounds schedule of every other test; the library's own choice (negative, like 0 outside this test
     suite: conftest.py) is one group below 16 384 chains and two from there on."""
@@ -105,8 +136,7 @@ def test_one_group_schedule_untouched_and_library_choice():
 
 def test_refused_where_it_cannot_run():
     sa = _sa()
-    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=-1), dict(num_chains=4096, deep_bins=1),
-               dict(num_chains=4096, fused=3, alternatives=2), dict(num_chains=4096, force_literal_update=True)):
+    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=-1), dict(num_chains=4096, force_literal_update=True)):
         with sa.ReorderStage(sa.ReorderOpts(num_thr=1, phases=2, **kw)) as st:
             st.load_synth(50_000, 100, 200_000, 5, 10000)
             st.build_dict()

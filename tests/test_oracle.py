@@ -179,6 +179,9 @@ def test_two_group_schedule_specification():
         r = po.reorder_rounds_ph(read, ln, L, K, T)
         check_invariants(r, read, ln, L, n)
         assert len(r["order"]) + len(r["order_s"]) == n
+        r2 = po.reorder_rounds_ph(read, ln, L, K, T, alternatives=2)  # two candidates per proposal: fewer lost proposals
+        check_invariants(r2, read, ln, L, n)
+        assert len(r2["order"]) + len(r2["order_s"]) == n and r2["stats"]["lost"] <= r["stats"]["lost"]
         one = po.reorder_rounds(read, ln, L, K, T)
         # same pool, same chain count: the two schedules find contigs of the same kind (within a few per cent)
         assert abs(int(r["stats"]["unmatched"]) - int(one["stats"]["unmatched"])) <= 0.05 * n
