@@ -2716,7 +2716,111 @@ __global__ __launch_bounds__(256) void k_mg_mark(DevParams P) {
 //    of this group's seed region (ublk[b] belongs to the group that picks seeds from block b: only its mark step writes it,
 //    so its round kernel -- which may run beside the other group's mark step -- reads settled counts).
 constexpr uint32_t RESV_LOST = 0xfffffffeu;
-__global__ __launch_bounds__(256) void k_ph_mark(DevParams P) {
+// ONE wavefront per block of MARK_BLOCK chains, four chains per lane: the kernel runs beside the other group's round
+// kernel, whose one-wavefront workgroups take every slot the moment it frees -- a workgroup of four wavefronts waits
+// for four free slots on one CU and starves (k_ph_mark as a copy of k_mg_mark, 256 threads per block, took 145 us beside
+// the round kernel of a deep pool and 11 us alone).
+__global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
+  constexpr int CPL = MARK_BLOCK / 64;  // chains per lane
+  const int lane = threadIdx.x;
+  const uint32_t gend = P.g0 + P.Kg;
+  const uint32_t cbase = P.g0 + blockIdx.x * MARK_BLOCK;  // sub-block j holds chains cbase + 64 j + lane
+  unsigned long long pv[CPL];
+  uint32_t rs[CPL];
+  bool inr[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; j++) {  // (all proposal words first, then all reservation words: two round trips, not eight)
+    const uint32_t cid = cbase + 64 * j + lane;
+    inr[j] = cid < gend;
+    pv[j] = inr[j] ? P.prop[cid] : ((unsigned long long)PK_DONE << 32);
+  }
+#pragma unroll
+  for (int j = 0; j < CPL; j++) {
+    const int pk = (int)(pv[j] >> 32) & 7;
+    rs[j] = (pk == PK_MATCH || pk == PK_SEED) ? P.resv[(uint32_t)pv[j]] : 0xffffffffu;
+  }
+  int cls[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; j++) {
+    const uint32_t cid = cbase + 64 * j + lane;
+    const int pk = (int)(pv[j] >> 32) & 7;
+    bool needy = false;
+    const bool alive = pk != PK_DONE;
+    cls[j] = -1;
+    if (inr[j]) {
+      uint32_t wonv = 0xffffffffu;
+      if (alive) cls[j] = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv[j] & PK_WILLNEED_BIT) ? 3 : 0) : 3;
+      if (pk == PK_MATCH || pk == PK_SEED) {
+        uint32_t rid = (uint32_t)pv[j];
+        bool won = rs[j] == cid;
+        if (won && is_taken(P.taken_other, rid)) { won = false; P.resv[rid] = RESV_LOST; }
+        if (!won && pk == PK_MATCH && (pv[j] >> PK_ALT_SHIFT)) {  // the alternatives schedule: the second candidate, secured in pass 1 (k_ph_alt_resolve)
+          const uint32_t alt = (uint32_t)(pv[j] >> PK_ALT_SHIFT) - 1u;
+          if (P.resv[alt] == (ALT_KEY | cid)) {
+            if (is_taken(P.taken_other, alt)) P.resv[alt] = RESV_LOST;
+            else { won = true; rid = alt; }
+          }
+        }
+        if (won) {
+          atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+          if (pk == PK_MATCH && rid >= P.seed_lo && rid < P.seed_hi) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+          wonv = rid | (pk == PK_MATCH ? 0x80000000u : 0u);
+        }
+        if (pv[j] & PK_CURSOR_BIT) *P.cursor = (long long)(uint32_t)pv[j] - 1;  // every seed proposed this round ends up taken (by someone)
+        needy = pk == PK_SEED && !won;
+        if (pk == PK_SEED && won && cls[j] >= 0) cls[j] = 1;
+      } else if (pk == PK_NONE) {
+        needy = (pv[j] & PK_WILLNEED_BIT) != 0;
+      } else if (pk == PK_NOSEED && (pv[j] & PK_CURSOR_BIT)) {
+        *P.cursor = -1;
+      }
+      P.won[cid - P.g0] = wonv;
+    }
+    const uint64_t nb = __ballot(needy);
+    const uint32_t na = (uint32_t)__popcll(__ballot(alive && inr[j]));
+    const uint32_t cb = cbase + 64 * j;  // (g0 is a multiple of 2048: a sub-block covers two whole bitmap words of its group)
+    if (lane == 0 && cb < gend) {
+      P.needy[cb >> 5] = (uint32_t)nb;
+      if (cb + 32 < ((gend + 31) & ~31u)) P.needy[(cb >> 5) + 1] = (uint32_t)(nb >> 32);
+      if (nb) atomicAdd(&P.needy_cnt_next[cb >> 11], (uint32_t)__popcll(nb));
+      P.alive_wave[cb >> 6] = na;
+    }
+  }
+  const uint32_t t = blockIdx.x * 64 + lane;  // (one thread per ...)
+  for (uint32_t j = t; j < P.Kg_other; j += gridDim.x * 64) {  // the other group's last winners: into this group's view
+    const uint32_t w = P.won_other[j];
+    if (w == 0xffffffffu) continue;
+    const uint32_t rid = w & 0x7fffffffu;
+    atomicOr((unsigned long long *)&P.taken[rid >> 6], 1ull << (rid & 63));
+    if ((w >> 31) && rid >= P.seed_lo && rid < P.seed_hi) atomicSub(&P.ublk[rid >> UBLK_SHIFT], 1u);
+    mark_dead(P, rid);  // taken in both views from here on: its bin entries say so (entry_dead)
+  }
+  if (t == 0 && P.longq) { P.longq[0] = 0; P.longq[1] = 0; }  // this group's long searches of the round are done (as in k_mg_mark)
+  if (P.longq && t < 2) P.lctl[t] = 0;
+  if (t < P.nb_hi - P.nb_lo) P.needy_cnt[P.nb_lo + t] = 0;  // what this group's NEXT mark step accumulates into
+  {  // class lists of this block's chains (k_round_mc; the order of k_mg_mark: class 0 first, chain ids ascending in a class)
+    const uint32_t segi = P.g0 / MARK_BLOCK + blockIdx.x;
+    uint32_t tot[4], base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t run = base;
+#pragma unroll
+      for (int j = 0; j < CPL; j++) {
+        const uint64_t m = __ballot(cls[j] == k);
+        if (cls[j] == k) P.ord[(size_t)segi * MARK_BLOCK + run + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = cbase + 64 * j + lane;
+        run += (uint32_t)__popcll(m);
+      }
+      tot[k] = run - base;
+      base = run;
+    }
+    if (lane == 0) P.ord_cnt[segi] = make_uint4(tot[0], tot[1], tot[2], tot[3]);
+  }
+}
+// The same step with four wavefronts per block of MARK_BLOCK chains and one chain per thread (k_mg_mark's shape): a quarter of
+// the dependent steps per thread.  Beside the four-chain round kernel of a shallow pool (short-lived wavefronts, 5 per SIMD)
+// its workgroups find their slots -- 12 us against 9 alone, and the mark step is on every round's critical path there
+// (100 M x 150 bp: chains stage 335 ms with this kernel, 353 with the one above) --, so shallow pools run this one.
+__global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t cid = P.g0 + t, gend = P.g0 + P.Kg;
   const int lane = threadIdx.x & 63;
@@ -3173,8 +3277,9 @@ void launch_mg_mark(hipStream_t st, const DevParams &P) {
 }
 void launch_ph_mark(hipStream_t st, const DevParams &P) {
   if (!P.Kg) return;
-  if (P.alts == 2) hipLaunchKernelGGL(k_ph_alt_resolve, GRID1(P.Kg, 256), dim3(256), 0, st, P);
-  hipLaunchKernelGGL(k_ph_mark, GRID1(P.Kg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
+  if (P.alts == 2) hipLaunchKernelGGL(k_ph_alt_resolve, GRID1(P.Kg, 64), dim3(64), 0, st, P);   // (one-wavefront workgroups: see k_ph_mark)
+  if (P.deep_bins) hipLaunchKernelGGL(k_ph_mark, GRID1(P.Kg, MARK_BLOCK), dim3(64), 0, st, P);
+  else hipLaunchKernelGGL(k_ph_mark_wide, GRID1(P.Kg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
 }
 void launch_delay(hipStream_t st, uint32_t microseconds) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, microseconds); }
 void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot) {

@@ -132,6 +132,14 @@ def test_one_group_schedule_untouched_and_library_choice():
     assert auto["stats"]["phases"] == 2
     read, ln = po.load_dna(dna, n, L)
     _same(auto, po.reorder_rounds_ph(read, ln, L, K, 2), "library's choice, 16 384 chains")
+    # a pool of very deep bins, whose long searches go to the k_long kernels: one group, whatever the chain count
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=2, phases=-1, alternatives=1)) as st:
+        st.load_synth(n, L, 300, 23, 10000)
+        auto = st.run().streams()
+        dna = st.download_dna()
+    assert auto["stats"]["phases"] == 1
+    read, ln = po.load_dna(dna, n, L)
+    _same(auto, po.reorder_rounds(read, ln, L, K, 2), "library's choice, very deep bins")
 
 
 def test_refused_where_it_cannot_run():

@@ -16,7 +16,8 @@ f = glob.glob(O + "/prof/**/*kernel_trace.csv", recursive=True)[0]
 ev = []
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    kind = "R" if "k_round_mc" in k else "M" if ("k_ph_mark" in k or "k_mg_mark" in k) else None
+    kind = ("R" if "k_round" in k else "M" if ("k_ph_mark" in k or "k_mg_mark" in k) else "T" if "k_trim_bins" in k else
+            "L" if "k_long" in k else "A" if "alt_resolve" in k else None)
     if kind:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, r.get("Queue_Id", "?")))
 ev.sort()
@@ -40,7 +41,7 @@ with open(O + "/phase_timeline.txt", "w") as o:
     mid = len(ev) // 2
     t0 = ev[mid][0]
     o.write("window from the middle of the run (us from its start; queue):\n")
-    for s, e, k, q in ev[mid:mid + 48]:
+    for s, e, k, q in ev[mid:mid + int(__import__('os').environ.get('TL_ROWS', '48'))]:
         o.write("  %s q%-3s %9.1f .. %9.1f  (%6.1f)\n" % (k, q, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
 PY
 rm -rf "$O/prof"
