@@ -13,11 +13,11 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-def _random_case(seed):
+def _random_case(seed, nlo=1, nhi=2500, Ks=(1, 2, 3, 7, 16, 63, 256, 1000, 4096)):
     rng = np.random.default_rng(seed)
     kind = rng.integers(0, 5)
     L = int(rng.choice([20, 33, 50, 64, 75, 100, 101, 127, 128, 150, 151, 200, 250, 300, 400, 511]))
-    n = int(rng.integers(1, 2500))
+    n = int(rng.integers(nlo, nhi))
     err = float(rng.choice([0.0, 0.002, 0.01, 0.03, 0.08]))
     cov = int(rng.choice([2, 8, 25, 60, 400]))
     G = max(n * L // cov, L + 5)
@@ -40,7 +40,7 @@ def _random_case(seed):
         reads = rs.var_length_reads(seed, max(G, L + 5), n, 1, max(L // 2, 1), err)
         reads += rs.var_length_reads(seed + 1, max(G, L + 5), max(n // 10, 1), L, L, err)
         n = len(reads); dna = rs.pack_var(reads); maxlen = L
-    K = int(rng.choice([1, 2, 3, 7, 16, 63, 256, 1000, 4096]))
+    K = int(rng.choice(list(Ks)))
     T = int(rng.choice([1, 2, 3, 8]))
     return dna, n, maxlen, K, T
 
@@ -92,6 +92,38 @@ def test_fuzz_gpu_equals_oracle(block):
             assert np.array_equal(got3["tid_off"], want3["tid_off"]), ("seed", seed, "two candidates", kw3)
             for k in ("lost", "unmatched") + (("probes", "keyok", "cands", "hits") if kw3["collect_stats"] else ()):
                 assert got3["stats"][k] == want3["stats"][k], ("seed", seed, "two candidates", kw3, k)
+
+
+@pytest.mark.parametrize("block", range(max(_BLOCKS // 4, 1)))
+def test_fuzz_two_chain_groups(block):
+    """The schedule with two chain groups (opts.phases = 2, specification orc_reorder_rounds_ph[_alt]) on random read sets of
+    8 192 .. 30 000 reads with 4 096 .. 12 288 chains (a few reads per chain: seed ranges run dry, groups of unequal size, chains
+    that never get a seed), a random kernel variant per case: four chains / one chain per wavefront, the deep-bin machinery with
+    or without entry flags, long searches handed to the long-search kernels after 1 / 2 passes or never, one or two candidates
+    per proposal, production or counting build."""
+    import spring_amd
+    for seed in range(7000 + 10 * block, 7000 + 10 * (block + 1)):
+        dna, n, L, K, T = _random_case(seed, 8192, 30000, (4096, 4100, 5000, 6144, 8192, 12288))
+        if n < 8192:  # (the duplicate-heavy generator rounds n down)
+            continue
+        rng = np.random.default_rng(seed + 5)
+        A = int(rng.choice([1, 1, 2]))
+        deep = 1 if A == 2 else int(rng.choice([1, -1, -1]))
+        kw = dict(deep_bins=deep, alternatives=A, collect_stats=bool(rng.integers(0, 2)))
+        if deep == 1:
+            kw.update(long_budget=int(rng.choice([1, 2, 0, -1])), long_split=int(rng.choice([0, 1, 3])), entry_flags=int(rng.choice([0, -1])))
+        else:
+            kw.update(fused=int(rng.choice([3, 3, 0, 2])))
+        read, ln = po.load_dna(dna, n, L)
+        want = po.reorder_rounds_ph(read, ln, L, K, T, alternatives=A)
+        got = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, phases=2, **kw))
+        assert got["stats"]["phases"] == 2
+        for k in KEYS:
+            assert np.array_equal(got[k], want[k]), ("seed", seed, "two groups", kw, "n", n, "L", L, "K", K, "T", T, k)
+        assert np.array_equal(got["tid_off"], want["tid_off"]), ("seed", seed, "two groups", kw)
+        for k in ("lost", "unmatched") + (("probes", "keyok", "cands", "hits", "iterations") if kw["collect_stats"] else ()):
+            assert got["stats"][k] == want["stats"][k], ("seed", seed, "two groups", kw, k, got["stats"][k], want["stats"][k])
+        check_invariants(got, read, ln, L, n)
 
 
 @pytest.mark.parametrize("block", range(2))

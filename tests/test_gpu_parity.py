@@ -702,6 +702,20 @@ def test_call_reorder_many_chains_and_device_list(tmp_path, devices):
     _check_file_set(_read_file_set(tmp_path, T), want, read, ln, L, T)
 
 
+def test_call_reorder_two_chain_groups(tmp_path):
+    """The drop-in with the chains in two groups (opts.phases = 2 -- what the call chooses by itself from 16 384 chains on):
+    the file set == the two-group oracle's streams."""
+    sa = _sa()
+    from spring_amd.reorder import CompressionParams
+    n, L, K, T = 200_000, 100, 4096, 5
+    dna = sa.synth_dna_host(n, L, n * L // 25, 31, 10000)
+    (tmp_path / "input_clean_1.dna").write_bytes(dna)
+    sa.call_reorder(str(tmp_path), CompressionParams(L, [n, 0], num_thr=T), sa.ReorderOpts(num_chains=K, num_thr=T, phases=2))
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds_ph(read, ln, L, K, T)
+    _check_file_set(_read_file_set(tmp_path, T), want, read, ln, L, T)
+
+
 def test_call_reorder_lengths_that_hide_in_a_fixed_size_stream(tmp_path):
     """Reads of 97..100 bases all take 2 + 25 bytes: the stream has the size of a fixed-length one, the device-side
     length check notices, and the stage falls back to walking the records."""
