@@ -1239,6 +1239,131 @@ int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_
   return 0;
 }
 
+/* -------------------------------------------------- replay check of a reorder output (any schedule, any size)
+ *
+ * Which read a chain takes next depends on the schedule (the reference's own `-t K` output differs from run to run); that
+ * every emitted match was one the reference COULD have made does not.  orc_check_contigs replays every contig of an output
+ * from its streams alone, with the reference's own state machine: the seed (flag '0', 'd', pos 0) resets the consensus
+ * (updaterefcount, reorder.h:133-142); for every following record the orientation character and the position give back
+ * (reverse?, shift) by inverting reorder.h:490-497 / :528-535 for the search direction the contig is in, and the read must
+ * then be exactly what search_match accepts (reorder.h:246-318): a shift in [0, maxshift), a dictionary whose probe is
+ * valid at that shift (reorder.h:264-268) and whose window of the shifted consensus EQUALS the read's own key (so the
+ * dictionary would have returned the read's bin), and at most THRESH_REORDER differing bits over the compared range
+ * (reorder.h:291-302); then the consensus is updated (updaterefcount -- the function that tests/test_oracle_vs_ref_units.py
+ * pins against the reference's own code) and ref_pos advanced as the reference does.  A contig searches rightwards first and
+ * leftwards after one reset to the reverse complement of its first read (reorder.h:559-575): the replay switches direction at
+ * the first record that does not verify rightwards and, should a later record then fail, tries every other switch point.
+ * What it cannot see is global: whether a better-placed candidate was free at the time, and whether a singleton had a match.
+ * Returns 0; res: contigs, matched records, contigs that no switch point verifies, index of the first bad record. */
+static int chk_step(const uint64_t *read, const uint16_t *len, int L, int W, int maxshift, const int ds[2], const int de[2],
+                    cons_t *c, int64_t *ref_pos, int left, uint32_t r, char rcch, int64_t p, orc_stats *st) {
+  const int n = len[r], R_old = c->ref_len;
+  const int rev = left ? (rcch == 'd') : (rcch == 'r');
+  int64_t sh;
+  if (!rev) sh = !left ? p - *ref_pos : *ref_pos + R_old - n - p;        /* reorder.h:490-497 */
+  else sh = !left ? p - *ref_pos - R_old + n : *ref_pos - p;             /* reorder.h:528-535 */
+  if (sh < 0 || sh >= maxshift) return 0;
+  const int shift = (int)sh;
+  uint64_t x[ORC_WMAX];
+  memcpy(x, rev ? c->revref : c->ref, sizeof(uint64_t) * W);
+  for (int k = 0; k < shift; k++) { if (rev) shl2(x, W); else shr2(x, W); }  /* reorder.h:556-557 */
+  const uint64_t *rd = read + (size_t)r * W;
+  int findable = 0;
+  for (int l = 0; l < 2 && !findable; l++) {
+    if (!rev) { if (de[l] + shift >= R_old) continue; }
+    else if (de[l] >= R_old + shift || ds[l] <= shift) continue;      /* reorder.h:264-268 */
+    if (n <= de[l]) continue;                                          /* the read is not in dictionary l (bitset_util.h:101) */
+    const int nb = 2 * (de[l] - ds[l] + 1);
+    if (window64(x, W, 2 * ds[l], nb) == window64(rd, W, 2 * ds[l], nb)) findable = 1;
+  }
+  if (!findable) return 0;
+  int lo = rev ? shift : 0, m = rev ? R_old + shift : R_old - shift;
+  if (n < m) m = n;
+  if (hamming_range(x, rd, W, lo, m) > THRESH_REORDER) return 0;
+  updaterefcount(rd, c, 0, rev, shift, n, L, W, st);
+  if (!rev) *ref_pos = !left ? p : *ref_pos + R_old - shift - c->ref_len;
+  else *ref_pos = !left ? *ref_pos + R_old + shift - c->ref_len : p;
+  return 1;
+}
+
+/* replay records [a, b) of one contig with the left search starting at record sw (sw == b: never; sw < 0: at the first
+ * record that fails rightwards); returns the index of the first record that does not verify, or -1 */
+static int64_t chk_replay(const uint64_t *read, const uint16_t *len, int L, int W, const int ds[2], const int de[2],
+                          const uint32_t *order, const char *rc, const int64_t *pos, int64_t a, int64_t b, int64_t sw,
+                          cons_t *c, orc_stats *st) {
+  const uint32_t first = order[a];
+  int64_t ref_pos = 0;
+  int left = 0;
+  updaterefcount(read + (size_t)first * W, c, 1, 0, 0, len[first], L, W, st);
+  for (int64_t i = a + 1; i < b; i++) {
+    if (!left && i == sw) {
+      left = 1;
+      updaterefcount(read + (size_t)first * W, c, 1, 1, 0, len[first], L, W, st);  /* reorder.h:567 */
+      ref_pos = 0;
+    }
+    cons_t save;
+    if (!left && sw < 0) save = *c;
+    int64_t rp = ref_pos;
+    if (chk_step(read, len, L, W, L / 2, ds, de, c, &ref_pos, left, order[i], rc[i], pos[i], st)) continue;
+    if (left || sw >= 0) return i;
+    *c = save; ref_pos = rp;  /* (a failed step leaves the state untouched, but be explicit) */
+    left = 1;
+    updaterefcount(read + (size_t)first * W, c, 1, 1, 0, len[first], L, W, st);
+    ref_pos = 0;
+    if (!chk_step(read, len, L, W, L / 2, ds, de, c, &ref_pos, left, order[i], rc[i], pos[i], st)) return i;
+  }
+  return -1;
+}
+
+int orc_check_contigs(const uint64_t *read, const uint16_t *len, uint32_t n, int L, const uint32_t *order, const char *rc,
+                      const char *flag, const int64_t *pos, uint64_t nm, const uint64_t *tid_off, int num_thr,
+                      uint64_t *res /* [4] */) {
+  (void)n;
+  const int W = orc_limbs(L);
+  int ds[2], de[2];
+  orc_dict_windows(L, ds, de);
+  /* contig starts: every flag '0'; a contig ends at the next one or at the end of its tid's stream */
+  uint64_t nc = 0;
+  for (uint64_t i = 0; i < nm; i++) nc += flag[i] == '0';
+  int64_t *st0 = (int64_t *)malloc(sizeof(int64_t) * (nc + 1)), *en0 = (int64_t *)malloc(sizeof(int64_t) * (nc + 1));
+  uint64_t k = 0, bad_structure = 0;
+  for (int t = 0; t < num_thr; t++) {
+    const uint64_t lo = tid_off[t], hi = tid_off[t + 1];
+    if (hi > lo && flag[lo] != '0') bad_structure++;
+    for (uint64_t i = lo; i < hi; i++)
+      if (flag[i] == '0') {
+        if (k && en0[k - 1] < 0) en0[k - 1] = (int64_t)i;
+        st0[k] = (int64_t)i; en0[k] = -1; k++;
+      }
+    if (k && en0[k - 1] < 0) en0[k - 1] = (int64_t)hi;
+  }
+  uint64_t bad = bad_structure, first_bad = ~0ULL, matches = 0;
+#pragma omp parallel
+  {
+    cons_t *c = (cons_t *)malloc(sizeof(cons_t));
+    orc_stats st;
+    memset(&st, 0, sizeof(st));
+#pragma omp for schedule(dynamic, 256) reduction(+ : bad, matches) reduction(min : first_bad)
+    for (int64_t q = 0; q < (int64_t)k; q++) {
+      const int64_t a = st0[q], b = en0[q];
+      matches += (uint64_t)(b - a - 1);
+      int ok = rc[a] == 'd' && pos[a] == 0 && b - a >= 2;
+      int64_t f = a;
+      if (ok) {
+        f = chk_replay(read, len, L, W, ds, de, order, rc, pos, a, b, -1, c, &st);
+        for (int64_t sw = a + 1; f >= 0 && sw <= b; sw++)  /* (rare: the greedy switch point was a coincidence) */
+          if (chk_replay(read, len, L, W, ds, de, order, rc, pos, a, b, sw, c, &st) < 0) f = -1;
+        ok = f < 0;
+      }
+      if (!ok) { bad++; if ((uint64_t)f < first_bad) first_bad = (uint64_t)f; }
+    }
+    free(c);
+  }
+  res[0] = k; res[1] = matches; res[2] = bad; res[3] = first_bad;
+  free(st0); free(en0);
+  return 0;
+}
+
 /* ------------------------------------------------------------ writetofile */
 
 size_t orc_write_dna_stream(const uint64_t *read, const uint16_t *len, int L, const uint32_t *order,

@@ -103,6 +103,13 @@ int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n,
 int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen,
                               uint32_t num_chains, int num_thr, int alternatives, orc_out *out, orc_stats *st);
 
+/* Replay check of ANY reorder output (any chain count / schedule, any size; OpenMP over the contigs): every contig's records
+ * re-derived with the reference's state machine -- each matched read at its recorded orientation and position must be one
+ * search_match would have accepted on the consensus its predecessors built (see reorder_oracle.c).  res[4] = contigs, matched
+ * records, contigs that do not verify, index of the first bad record (~0: none). */
+int orc_check_contigs(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen, const uint32_t *order, const char *rc,
+                      const char *flag, const int64_t *pos, uint64_t n_matched, const uint64_t *tid_off, int num_thr, uint64_t *res);
+
 /* CPU-baseline port: T free-running OpenMP threads like the reference's `-t T`; NOT deterministic
  * for T > 1 (like the reference).  Outputs laid out per thread (tid_off has T+1 entries). */
 int orc_reorder_omp(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen, int num_threads,

@@ -303,6 +303,8 @@ def test_full_size_properties_100M_150bp():
         with sa.ReorderStage(sa.ReorderOpts(num_thr=T, phases=-1)) as s:  # (the library's choice: two chain groups at this size)
             s.load_synth(n, L, n * L // 25, 11, 10000)  # counter-based generator: same bytes both times
             outs.append(s.run().streams())
+            if len(outs) == 2:
+                read, ln = s.download_reads()
     a, b = outs
     assert a["stats"]["phases"] == 2 and a["stats"]["chains"] == 65536
     for k in KEYS:
@@ -319,6 +321,28 @@ def test_full_size_properties_100M_150bp():
         assert fl[0] == ord("0") and fl[-1] == ord("1")
         assert not np.any((fl[:-1] == ord("0")) & (fl[1:] == ord("0")))
     assert a["stats"]["unmatched"] == int(f0.sum()) + len(a["order_s"])
+    # every one of the ~86 M matched records replayed through the reference's state machine (orc_check_contigs): the read, at
+    # its recorded orientation and position, is one search_match accepts on the consensus its contig had built by then
+    c = po.check_contigs(read, ln, L, a)
+    assert c["bad"] == 0 and c["contigs"] == int(f0.sum()) and c["matches"] == len(a["order"]) - c["contigs"], c
+
+
+@pytest.mark.parametrize("pool", ["6400x", "25600x", "phix", "genomic"])
+def test_deep_pools_at_size_replay_check(pool):
+    """20 M / 10 M-read pools of the coverage sweep with the library's own choices (chain count, deep-bin kernel variants, two
+    chain groups or long-search kernels, two candidates per proposal where the pool is contended): the output is a
+    permutation of the reads and every matched record verifies in the replay check -- sizes no oracle run reaches."""
+    sa = _sa()
+    L = 150
+    n, G, err = {"6400x": (20_000_000, 468_750, 10000), "25600x": (20_000_000, 117_187, 10000), "phix": (10_000_000, 5_400, 10000),
+                 "genomic": (20_000_000, 120_000_000, 10000 | sa.SYNTH_GENOMIC)}[pool]
+    with sa.ReorderStage(sa.ReorderOpts(num_thr=8, phases=-1, alternatives=-1)) as s:
+        s.load_synth(n, L, G, 21, err)
+        got = s.run().streams()
+        read, ln = s.download_reads()
+    check_invariants(got, read, ln, L, n)
+    c = po.check_contigs(read, ln, L, got)
+    assert c["bad"] == 0 and c["matches"] == len(got["order"]) - c["contigs"], (pool, c, got["stats"]["phases"], got["stats"]["alternatives"])
 
 
 @pytest.mark.parametrize("name,K", [("syn5k_150", 64), ("var2k", 24), ("heavy", 48), ("repeat10k", 96), ("test_1+2", 8)])

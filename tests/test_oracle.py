@@ -185,3 +185,43 @@ def test_two_group_schedule_specification():
         one = po.reorder_rounds(read, ln, L, K, T)
         # same pool, same chain count: the two schedules find contigs of the same kind (within a few per cent)
         assert abs(int(r["stats"]["unmatched"]) - int(one["stats"]["unmatched"])) <= 0.05 * n
+
+
+@pytest.mark.parametrize("name", ["syn2k_100", "syn5k_150", "var2k", "var_long", "var_short", "heavy", "repeat10k", "dups",
+                                  "tandem", "syn2k_251", "syn1k_511", "syn2k_20", "syn3k_64", "test_1+2"])
+def test_replay_check_accepts_every_schedule(name):
+    """orc_check_contigs (the schedule-independent replay of a reorder output through the reference's state machine) finds
+    nothing to object to in the serial order, the rounds schedule, two candidates per proposal and free-running threads."""
+    read, ln, n, L = _load(name)
+    outs = [("serial", po.reorder_serial(read, ln, L)), ("rounds", po.reorder_rounds(read, ln, L, 16, 3)),
+            ("two candidates", po.reorder_rounds(read, ln, L, 64, 2, alternatives=2)), ("omp", po.reorder_omp(read, ln, L, 4))]
+    for what, r in outs:
+        c = po.check_contigs(read, ln, L, r)
+        assert c["bad"] == 0, (name, what, c)
+        assert c["contigs"] == int((r["flag"] == ord("0")).sum()) and c["matches"] == len(r["order"]) - c["contigs"]
+
+
+def test_replay_check_rejects_corrupted_outputs():
+    """... and objects to an output that is a permutation of the reads with consistent flags (check_invariants passes) but
+    whose records are not matches: a read moved into another contig, a position off by one, an orientation flipped."""
+    read, ln, n, L = _load("syn5k_150")
+    good = po.reorder_rounds(read, ln, L, 16, 3)
+    assert po.check_contigs(read, ln, L, good)["bad"] == 0
+    m = np.flatnonzero(good["flag"] == ord("1"))
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        r = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in good.items()}
+        kind = trial % 4
+        i, j = (int(x) for x in rng.choice(m, 2, replace=False))
+        if kind == 0:
+            r["order"][i], r["order"][j] = r["order"][j], r["order"][i]     # two matched reads change places
+            r["rlen"][i], r["rlen"][j] = r["rlen"][j], r["rlen"][i]
+        elif kind == 1:
+            r["pos"][i] += 1
+        elif kind == 2:
+            r["rc"][i] = ord("r") if r["rc"][i] == ord("d") else ord("d")
+        else:
+            r["pos"][i] -= 3
+        check_invariants(r, read, ln, L, n)  # (still a permutation with consistent flags)
+        c = po.check_contigs(read, ln, L, r)
+        assert c["bad"] >= 1, (trial, kind, i, j, c)
