@@ -294,9 +294,11 @@ def reorder_rounds_ph(read, ln, L, num_chains, num_thr=1, alternatives=1):
     return _finish(o, arrs, st)
 
 
-def check_contigs(read, ln, L, res):
+def check_contigs(read, ln, L, res, reference_update=False):
     """Replay check of a reorder output `res` (streams() / reorder_*() dict) -> dict(contigs, matches, bad, first_bad): every
-    matched record must be a match the reference's search_match accepts on the consensus its contig had built by then."""
+    matched record must be a match the reference's search_match accepts on the consensus its contig had built by then.
+    reference_update: the consensus is kept by the REFERENCE'S OWN updaterefcount<N> (oracle/_ref/libref_units.so) instead of
+    the restatement (slower: strings, heap); raises if that library is not built."""
     read = np.ascontiguousarray(read, dtype=np.uint64)
     ln = np.ascontiguousarray(ln, dtype=np.uint16)
     order = np.ascontiguousarray(res["order"], dtype=np.uint32)
@@ -305,12 +307,18 @@ def check_contigs(read, ln, L, res):
     pos = np.ascontiguousarray(res["pos"], dtype=np.int64)
     toff = np.ascontiguousarray(res["tid_off"], dtype=np.uint64)
     out = (C.c_uint64 * 4)()
-    f = lib().orc_check_contigs
+    upd = None
+    if reference_update:
+        U = ref_units()
+        if U is None:
+            raise RuntimeError("oracle/_ref/libref_units.so is not built (make -C oracle ref, needs the reference sources)")
+        upd = C.cast(U.ref_u_updaterefcount, C.c_void_p)
+    f = lib().orc_check_contigs_upd
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                  C.c_void_p, C.c_int, C.c_void_p]
+                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     rcode = f(read.ctypes.data, ln.ctypes.data, len(ln), L, order.ctypes.data, rc.ctypes.data, flag.ctypes.data, pos.ctypes.data,
-              len(order), toff.ctypes.data, len(toff) - 1, out)
+              len(order), toff.ctypes.data, len(toff) - 1, out, upd)
     assert rcode == 0
     return dict(contigs=int(out[0]), matches=int(out[1]), bad=int(out[2]), first_bad=int(out[3]))
 

@@ -1255,7 +1255,14 @@ int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_
  * the first record that does not verify rightwards and, should a later record then fail, tries every other switch point.
  * What it cannot see is global: whether a better-placed candidate was free at the time, and whether a singleton had a match.
  * Returns 0; res: contigs, matched records, contigs that no switch point verifies, index of the first bad record. */
-static int chk_step(const uint64_t *read, const uint16_t *len, int L, int W, int maxshift, const int ds[2], const int de[2],
+/* the consensus update of the replay: the restatement above, or -- upd != NULL -- the REFERENCE'S OWN updaterefcount<N>
+ * (oracle/_ref/libref_units.so::ref_u_updaterefcount, compiled from reorder.h:110-220 where it lies) on the same state */
+static void chk_update(orc_update_fn upd, const uint64_t *cur, cons_t *c, int reset, int rev, int shift, int n, int L, int W,
+                       orc_stats *st) {
+  if (upd) upd(L, cur, &c->cnt[0][0], ORC_MAX_READ_LEN + 1, c->ref, c->revref, &c->ref_len, reset, rev, shift, n);
+  else updaterefcount(cur, c, reset, rev, shift, n, L, W, st);
+}
+static int chk_step(orc_update_fn upd, const uint64_t *read, const uint16_t *len, int L, int W, int maxshift, const int ds[2], const int de[2],
                     cons_t *c, int64_t *ref_pos, int left, uint32_t r, char rcch, int64_t p, orc_stats *st) {
   const int n = len[r], R_old = c->ref_len;
   const int rev = left ? (rcch == 'd') : (rcch == 'r');
@@ -1280,7 +1287,7 @@ static int chk_step(const uint64_t *read, const uint16_t *len, int L, int W, int
   int lo = rev ? shift : 0, m = rev ? R_old + shift : R_old - shift;
   if (n < m) m = n;
   if (hamming_range(x, rd, W, lo, m) > THRESH_REORDER) return 0;
-  updaterefcount(rd, c, 0, rev, shift, n, L, W, st);
+  chk_update(upd, rd, c, 0, rev, shift, n, L, W, st);
   if (!rev) *ref_pos = !left ? p : *ref_pos + R_old - shift - c->ref_len;
   else *ref_pos = !left ? *ref_pos + R_old + shift - c->ref_len : p;
   return 1;
@@ -1288,29 +1295,25 @@ static int chk_step(const uint64_t *read, const uint16_t *len, int L, int W, int
 
 /* replay records [a, b) of one contig with the left search starting at record sw (sw == b: never; sw < 0: at the first
  * record that fails rightwards); returns the index of the first record that does not verify, or -1 */
-static int64_t chk_replay(const uint64_t *read, const uint16_t *len, int L, int W, const int ds[2], const int de[2],
+static int64_t chk_replay(orc_update_fn upd, const uint64_t *read, const uint16_t *len, int L, int W, const int ds[2], const int de[2],
                           const uint32_t *order, const char *rc, const int64_t *pos, int64_t a, int64_t b, int64_t sw,
                           cons_t *c, orc_stats *st) {
   const uint32_t first = order[a];
   int64_t ref_pos = 0;
   int left = 0;
-  updaterefcount(read + (size_t)first * W, c, 1, 0, 0, len[first], L, W, st);
+  chk_update(upd, read + (size_t)first * W, c, 1, 0, 0, len[first], L, W, st);
   for (int64_t i = a + 1; i < b; i++) {
     if (!left && i == sw) {
       left = 1;
-      updaterefcount(read + (size_t)first * W, c, 1, 1, 0, len[first], L, W, st);  /* reorder.h:567 */
+      chk_update(upd, read + (size_t)first * W, c, 1, 1, 0, len[first], L, W, st);  /* reorder.h:567 */
       ref_pos = 0;
     }
-    cons_t save;
-    if (!left && sw < 0) save = *c;
-    int64_t rp = ref_pos;
-    if (chk_step(read, len, L, W, L / 2, ds, de, c, &ref_pos, left, order[i], rc[i], pos[i], st)) continue;
+    if (chk_step(upd, read, len, L, W, L / 2, ds, de, c, &ref_pos, left, order[i], rc[i], pos[i], st)) continue;
     if (left || sw >= 0) return i;
-    *c = save; ref_pos = rp;  /* (a failed step leaves the state untouched, but be explicit) */
-    left = 1;
-    updaterefcount(read + (size_t)first * W, c, 1, 1, 0, len[first], L, W, st);
+    left = 1;  /* (a failed step leaves consensus and ref_pos untouched) */
+    chk_update(upd, read + (size_t)first * W, c, 1, 1, 0, len[first], L, W, st);
     ref_pos = 0;
-    if (!chk_step(read, len, L, W, L / 2, ds, de, c, &ref_pos, left, order[i], rc[i], pos[i], st)) return i;
+    if (!chk_step(upd, read, len, L, W, L / 2, ds, de, c, &ref_pos, left, order[i], rc[i], pos[i], st)) return i;
   }
   return -1;
 }
@@ -1318,7 +1321,17 @@ static int64_t chk_replay(const uint64_t *read, const uint16_t *len, int L, int 
 int orc_check_contigs(const uint64_t *read, const uint16_t *len, uint32_t n, int L, const uint32_t *order, const char *rc,
                       const char *flag, const int64_t *pos, uint64_t nm, const uint64_t *tid_off, int num_thr,
                       uint64_t *res /* [4] */) {
+  return orc_check_contigs_upd(read, len, n, L, order, rc, flag, pos, nm, tid_off, num_thr, res, NULL);
+}
+int orc_check_contigs_upd(const uint64_t *read, const uint16_t *len, uint32_t n, int L, const uint32_t *order, const char *rc,
+                          const char *flag, const int64_t *pos, uint64_t nm, const uint64_t *tid_off, int num_thr,
+                          uint64_t *res /* [4] */, orc_update_fn upd) {
   (void)n;
+  if (upd && nm) {  /* (the reference's tables are built on the first call: make it before the threads start) */
+    cons_t *c0 = (cons_t *)calloc(1, sizeof(cons_t));
+    upd(L, read + (size_t)order[0] * orc_limbs(L), &c0->cnt[0][0], ORC_MAX_READ_LEN + 1, c0->ref, c0->revref, &c0->ref_len, 1, 0, 0, len[order[0]]);
+    free(c0);
+  }
   const int W = orc_limbs(L);
   int ds[2], de[2];
   orc_dict_windows(L, ds, de);
@@ -1340,7 +1353,7 @@ int orc_check_contigs(const uint64_t *read, const uint16_t *len, uint32_t n, int
   uint64_t bad = bad_structure, first_bad = ~0ULL, matches = 0;
 #pragma omp parallel
   {
-    cons_t *c = (cons_t *)malloc(sizeof(cons_t));
+    cons_t *c = (cons_t *)calloc(1, sizeof(cons_t));
     orc_stats st;
     memset(&st, 0, sizeof(st));
 #pragma omp for schedule(dynamic, 256) reduction(+ : bad, matches) reduction(min : first_bad)
@@ -1350,9 +1363,9 @@ int orc_check_contigs(const uint64_t *read, const uint16_t *len, uint32_t n, int
       int ok = rc[a] == 'd' && pos[a] == 0 && b - a >= 2;
       int64_t f = a;
       if (ok) {
-        f = chk_replay(read, len, L, W, ds, de, order, rc, pos, a, b, -1, c, &st);
+        f = chk_replay(upd, read, len, L, W, ds, de, order, rc, pos, a, b, -1, c, &st);
         for (int64_t sw = a + 1; f >= 0 && sw <= b; sw++)  /* (rare: the greedy switch point was a coincidence) */
-          if (chk_replay(read, len, L, W, ds, de, order, rc, pos, a, b, sw, c, &st) < 0) f = -1;
+          if (chk_replay(upd, read, len, L, W, ds, de, order, rc, pos, a, b, sw, c, &st) < 0) f = -1;
         ok = f < 0;
       }
       if (!ok) { bad++; if ((uint64_t)f < first_bad) first_bad = (uint64_t)f; }

@@ -109,6 +109,13 @@ int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_
  * records, contigs that do not verify, index of the first bad record (~0: none). */
 int orc_check_contigs(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen, const uint32_t *order, const char *rc,
                       const char *flag, const int64_t *pos, uint64_t n_matched, const uint64_t *tid_off, int num_thr, uint64_t *res);
+/* ... with the consensus kept by `upd` instead of the restatement: the reference's own updaterefcount<N> compiled in place
+ * (oracle/_ref/libref_units.so::ref_u_updaterefcount has this signature; cnt = int32 [4][stride], rows A C T G) */
+typedef int (*orc_update_fn)(int L, const uint64_t *cur, int32_t *cnt, int stride, uint64_t *ref, uint64_t *revref, int *ref_len,
+                             int reset, int rev, int shift, int cur_readlen);
+int orc_check_contigs_upd(const uint64_t *read, const uint16_t *len, uint32_t n, int max_readlen, const uint32_t *order, const char *rc,
+                          const char *flag, const int64_t *pos, uint64_t n_matched, const uint64_t *tid_off, int num_thr, uint64_t *res,
+                          orc_update_fn upd);
 
 /* CPU-baseline port: T free-running OpenMP threads like the reference's `-t T`; NOT deterministic
  * for T > 1 (like the reference).  Outputs laid out per thread (tid_off has T+1 entries). */

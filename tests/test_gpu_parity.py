@@ -325,6 +325,8 @@ def test_full_size_properties_100M_150bp():
     # its recorded orientation and position, is one search_match accepts on the consensus its contig had built by then
     c = po.check_contigs(read, ln, L, a)
     assert c["bad"] == 0 and c["contigs"] == int(f0.sum()) and c["matches"] == len(a["order"]) - c["contigs"], c
+    if po.ref_units() is not None:  # ... and once more with the consensus kept by the reference's own updaterefcount<N>
+        assert po.check_contigs(read, ln, L, a, reference_update=True) == c
 
 
 @pytest.mark.parametrize("pool", ["6400x", "25600x", "phix", "genomic"])

@@ -199,6 +199,8 @@ def test_replay_check_accepts_every_schedule(name):
         c = po.check_contigs(read, ln, L, r)
         assert c["bad"] == 0, (name, what, c)
         assert c["contigs"] == int((r["flag"] == ord("0")).sum()) and c["matches"] == len(r["order"]) - c["contigs"]
+        if po.ref_units() is not None:  # the same replay with the consensus kept by the reference's own updaterefcount<N>
+            assert po.check_contigs(read, ln, L, r, reference_update=True) == c, (name, what)
 
 
 def test_replay_check_rejects_corrupted_outputs():
@@ -225,3 +227,5 @@ def test_replay_check_rejects_corrupted_outputs():
         check_invariants(r, read, ln, L, n)  # (still a permutation with consistent flags)
         c = po.check_contigs(read, ln, L, r)
         assert c["bad"] >= 1, (trial, kind, i, j, c)
+        if po.ref_units() is not None:
+            assert po.check_contigs(read, ln, L, r, reference_update=True)["bad"] >= 1, (trial, kind)
