@@ -384,6 +384,8 @@ void spring_reorder_destroy(spring_reorder_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->dev);
   if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+  if (ctx->st2) (void)hipStreamSynchronize(ctx->st2);  // (the second chain group's stream and the host's look at the running
+  if (ctx->st3) (void)hipStreamSynchronize(ctx->st3);  //  chains: idle unless run_chains failed half way)
   for (void *p : ctx->allocs) pool_free(ctx->dev, p);
   if (ctx->ev_ok) for (auto &e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->st) (void)hipStreamDestroy(ctx->st);
