@@ -275,7 +275,10 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
                 s1.close()
                 t1 = time.perf_counter() - t0
                 single = {"value": round(n / t1 / 1e6, 3), "unit": "Mreads/s", "seconds": round(t1, 3), "rounds": s1s["rounds"],
-                          "what": "the same pool and chain count on rank 0's GPU alone (one pass incl. allocations)"}
+                          "chain_groups": int(s1s.get("phases", 1)),
+                          "what": "the same pool and chain count on rank 0's GPU alone (one pass incl. allocations), with the "
+                                  "library's choice of the schedule: one GPU alone runs the chains in two groups whose rounds "
+                                  "alternate (DESIGN.md section 2), the pool one group (section 7)"}
             except Exception as e:  # noqa: BLE001
                 single = {"error": repr(e)}
         lanes.barrier()

@@ -62,7 +62,8 @@ typedef struct {
    * runs on `device` alone and rejects num_devices >= 2):
    * num_devices >= 2 runs the stage on devices[0 .. num_devices) -- one host thread and one context per entry inside
    * the library, the reads loaded on every device, the chains sharded, one RCCL all-gather per round -- and writes the
-   * merged per-tid file set.  The output equals the single-device output with the same num_chains (the default chain
+   * merged per-tid file set.  The output equals the single-device output with the same num_chains and phases = 1 -- the
+   * pool runs the chains as one group, stats.phases says so -- (the default chain
    * count is rounded up to a multiple of num_devices).  0 / 1: `device` alone.  An entry may repeat a device (tests on a
    * one-GPU box): the exchange then goes through host memory, as it does with mg_host_transport = 1. */
   int32_t num_devices;
