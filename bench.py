@@ -170,7 +170,11 @@ def roofline_block(alg_bytes, kernel_ms, launches, traffic, busy_ms=None):
             "launches": launches, "avg_launch_us": round(kernel_ms * 1e3 / launches, 2),
             "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
             "concurrent_launches": round(kernel_ms / busy, 3) if busy > 0 else None, "busy_ms": round(busy, 2),
-            "achieved_per_launch_alone": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None}
+            "achieved_per_launch_alone": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None,
+            "achieved_basis": ("algorithmic bytes of all launches / busy_ms = algorithmic_bytes_per_launch / avg_launch_us x "
+                               "concurrent_launches: launches of this kernel overlap (two chain groups on two streams), busy_ms is "
+                               "the union of the launches' intervals from the same HIP events"
+                               if busy > 0 and kernel_ms / busy > 1.01 else "algorithmic_bytes_per_launch / avg_launch_us")}
 
 
 def kernels_sha():
