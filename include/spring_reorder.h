@@ -55,7 +55,7 @@ typedef struct {
   int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
   int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (apply + search) + mark.  0: the mapping
                              is chosen from the run (four chains per wavefront, k_round_mc, on shallow dictionaries with at
-                             least 49 152 chains; else one chain per wavefront, k_round); 2: always one chain per wavefront;
+                             least 32 768 chains -- 49 152 when the chains run as one group --; else one chain per wavefront, k_round); 2: always one chain per wavefront;
                              3: four chains per wavefront wherever that kernel applies, whatever the chain count (tests) */
   int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
   /* ---- spring_reorder_run on several GPUs of one node (one read pool; spring_reorder_encode_run
@@ -106,9 +106,9 @@ typedef struct {
                              was after its own last round and loses a read the other group took in between; group 0 takes its
                              contig seeds from the upper half of the read ids, group 1 from the lower half.  The OUTPUT DEPENDS on
                              it for num_chains > 1 (both are legal `-t K` interleavings).  0 = the library's choice, reported in
-                             stats.phases: 2 from 49 152 chains on where it can run, else 1.  2 needs the fused round without the
-                             deep-bin machinery (a shallow dictionary), one GPU, one candidate per proposal, at least 4 096 chains and
-                             8 192 .. 2^31 - 1 reads */
+                             stats.phases: 2 from 16 384 chains on where it can run (not where the long searches of a pool go to the
+                             long-search kernels: pools of very deep bins, genome-like pools), else 1.  2 needs the fused round, one GPU
+                             (a device list / a multi-GPU pool runs one group), at least 4 096 chains and 8 192 .. 2^31 - 1 reads */
 } spring_reorder_opts;
 
 typedef struct {
