@@ -106,8 +106,8 @@ typedef struct {
                              was after its own last round and loses a read the other group took in between; group 0 takes its
                              contig seeds from the upper half of the read ids, group 1 from the lower half.  The OUTPUT DEPENDS on
                              it for num_chains > 1 (both are legal `-t K` interleavings).  0 = the library's choice, reported in
-                             stats.phases: 2 from 16 384 chains on where it can run (not where the long searches of a pool go to the
-                             long-search kernels: pools of very deep bins, genome-like pools), else 1.  2 needs the fused round, one GPU
+                             stats.phases: 2 from 16 384 chains on for shallow dictionaries, at 131 072 chains for deep-coverage pools (not on
+                             contended ones, and not where the long searches of a pool go to the long-search kernels), else 1.  2 needs the fused round, one GPU
                              (a device list / a multi-GPU pool runs one group), at least 4 096 chains and 8 192 .. 2^31 - 1 reads */
 } spring_reorder_opts;
 

@@ -1464,12 +1464,16 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)K / 2 + 1024) / 2048) * 2048, 2048);  // group 0: chains [0, half): K / 2 to the nearest multiple of 2048
     const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
     const bool can = allow_phases && fused && Ktot == K && c0 == 0 && !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
-    // (deep-bin pools, 20 M reads, one group / two: 400x 112 / 102 ms, 1 600x 122 / 115, 6 400x 136 / 131, 25 600x 151 / 150 -- the
-    // round kernel's own throughput is what is left there; pools whose long searches go to the k_long kernels stay with one
-    // group: PhiX-like 150 / 165 ms, genome-like 100 M reads 1 475 / 1 619 -- blocks of 4-8 wavefronts starve beside the
-    // other group's one-wavefront workgroups)
+    // Deep-bin pools (one chain per wavefront, up to 131 072 chains), one group / two, chains stage in ms: 20 M reads (131 072 chains)
+    // 400x 112 / 102, 1 600x 122 / 115, 6 400x 136 / 131, 25 600x (two candidates per proposal) 151 / 150; 10 M reads (78 125 chains)
+    // 400x 60 / 58, 6 400x 74 / 79, 25 600x 85 / 90; 5 M reads (39 062) 34 / 35, 44 / 50, 55 / 59; 2.5 M reads (19 531) 21 / 26,
+    // 29 / 38, 37 / 45 -- what is left on these pools is the round kernel's own throughput, and a group's launch has to fill the
+    // chip on its own: two groups only at the cap of 131 072 chains, and not on contended pools (two candidates per proposal).
+    // Pools whose long searches go to the k_long kernels stay with one group: PhiX-like 150 / 165 ms, genome-like 100 M reads
+    // 1 475 / 1 619 -- blocks of 4-8 wavefronts starve beside the other group's one-wavefront workgroups.
     const bool long_kernels = P.deep_bins && P.long_budget > 0;
-    const int want = ctx->o.phases > 0 ? ctx->o.phases : ((K >= 16384 && !long_kernels) ? 2 : 1);
+    const bool pays = P.deep_bins ? (K >= 131072 && P.alts == 1 && !long_kernels) : K >= 16384;
+    const int want = ctx->o.phases > 0 ? ctx->o.phases : (pays ? 2 : 1);
     if (ctx->o.phases == 2 && !can)
       return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path), one GPU, at least 4096 "
                   "chains and 8192 .. 2^31 - 1 reads");
