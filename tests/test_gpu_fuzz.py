@@ -62,6 +62,7 @@ def test_fuzz_gpu_equals_oracle(block):
         for k in ("probes", "keyok", "cands", "hits", "iterations", "lost", "unmatched"):
             assert got["stats"][k] == want["stats"][k], ("seed", seed, k, got["stats"][k], want["stats"][k])
         check_invariants(got, read, ln, L, n)
+        assert po.check_contigs(read, ln, L, got)["bad"] == 0, ("seed", seed, "replay check")
         if K == 1:
             ser = po.reorder_serial(read, ln, L)
             for k in KEYS:

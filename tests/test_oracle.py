@@ -229,3 +229,18 @@ def test_replay_check_rejects_corrupted_outputs():
         assert c["bad"] >= 1, (trial, kind, i, j, c)
         if po.ref_units() is not None:
             assert po.check_contigs(read, ln, L, r, reference_update=True)["bad"] >= 1, (trial, kind)
+
+
+def test_replay_check_random_geometries():
+    """The replay check on the fuzz generator's read sets (read lengths 20 .. 511, fixed / variable, duplicates, repeats, reads
+    outside one or both dictionaries, 1 .. 4 096 chains): nothing to object to in the rounds oracle's outputs, with the
+    restated and with the reference's own updaterefcount."""
+    from test_gpu_fuzz import _random_case
+    for seed in range(1000, 1060):
+        dna, n, L, K, T = _random_case(seed)
+        read, ln = po.load_dna(dna, n, L)
+        r = po.reorder_rounds(read, ln, L, K, T)
+        c = po.check_contigs(read, ln, L, r)
+        assert c["bad"] == 0, (seed, n, L, K, c)
+        if po.ref_units() is not None:
+            assert po.check_contigs(read, ln, L, r, reference_update=True) == c, (seed, n, L, K)
