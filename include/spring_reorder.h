@@ -108,7 +108,8 @@ typedef struct {
                              it for num_chains > 1 (both are legal `-t K` interleavings).  0 = the library's choice, reported in
                              stats.phases: 2 from 16 384 chains on for shallow dictionaries, at 131 072 chains for deep-coverage pools (not on
                              contended ones, and not where the long searches of a pool go to the long-search kernels), else 1.  2 needs the fused round, one GPU
-                             (a device list / a multi-GPU pool runs one group), at least 4 096 chains and 8 192 .. 2^31 - 1 reads */
+                             (a device list / a multi-GPU pool runs one group), at least 4 096 chains and 8 192 .. 2^31 - 1 reads, not fewer reads
+                             than chains */
 } spring_reorder_opts;
 
 typedef struct {

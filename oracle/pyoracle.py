@@ -290,7 +290,7 @@ def reorder_rounds_ph(read, ln, L, num_chains, num_thr=1, alternatives=1):
     st = OrcStats()
     rc = lib().orc_reorder_rounds_ph_alt(read.ctypes.data, ln.ctypes.data, n, L, num_chains, num_thr, alternatives,
                                          C.byref(o), C.byref(st))
-    assert rc == 0, "orc_reorder_rounds_ph: needs num_chains >= 4096 and n >= 8192"
+    assert rc == 0, "orc_reorder_rounds_ph: needs num_chains >= 4096 and n >= max(8192, num_chains)"
     return _finish(o, arrs, st)
 
 

@@ -1000,7 +1000,8 @@ int orc_reorder_rounds_alt(const uint64_t *read, const uint16_t *len, uint32_t n
  *     group claimed in half-step h - 1 is lost (the chain retries, as after losing to a lower chain id).
  *   Seeds: group 0 takes the (r+1)-th highest untaken read of [nmid, n) at or below its cursor, group 1 of [0, nmid),
  *   nmid = n/2 rounded down to a multiple of 4096, r = the chain's rank among its group's seed-needing chains; a group
- *   whose range is used up lets its chains finish (reorder.h:593-599) while the other carries on.
+ *   whose range is used up lets its chains finish (reorder.h:593-599) while the other carries on.  (Needs n >= K: every chain
+ *   starts on a seed of its own, so either group has chains to use up its range.)
  * One candidate per proposal.  Every read is still claimed exactly once, by a chain whose search saw it untaken and
  * within Hamming distance: a legal interleaving of the reference's `-t K` run like the rounds schedule.
  */
@@ -1075,7 +1076,7 @@ int orc_reorder_rounds_ph(const uint64_t *read, const uint16_t *len, uint32_t n,
 int orc_reorder_rounds_ph_alt(const uint64_t *read, const uint16_t *len, uint32_t n, int L, uint32_t K,
                               int num_thr, int A, orc_out *out, orc_stats *st) {
   const uint32_t Kh = orc_phase_split(K), nmid = (n / 2) & ~4095u;
-  if (K < 4096 || Kh >= K || num_thr <= 0 || nmid == 0 || A < 1 || A > 8) return -1;
+  if (K < 4096 || Kh >= K || num_thr <= 0 || nmid == 0 || A < 1 || A > 8 || n < K) return -1; /* (n < K: only chain 0 would run) */
   rctx_t x;
   memset(&x, 0, sizeof(x));
   memset(st, 0, sizeof(*st));

@@ -1463,7 +1463,9 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   {
     const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)K / 2 + 1024) / 2048) * 2048, 2048);  // group 0: chains [0, half): K / 2 to the nearest multiple of 2048
     const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
-    const bool can = allow_phases && fused && Ktot == K && c0 == 0 && !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0;
+    // (n >= K: every chain starts with a seed of its own, reorder.h:405-421 -- with fewer reads than chains only chain 0 runs, the
+    // second group would have no chain at all and nobody would ever pick the seeds of its range)
+    const bool can = allow_phases && fused && Ktot == K && c0 == 0 && !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0 && n >= K;
     // Deep-bin pools (one chain per wavefront, up to 131 072 chains), one group / two, chains stage in ms: 20 M reads (131 072 chains)
     // 400x 112 / 102, 1 600x 122 / 115, 6 400x 136 / 131, 25 600x (two candidates per proposal) 151 / 150; 10 M reads (78 125 chains)
     // 400x 60 / 58, 6 400x 74 / 79, 25 600x 85 / 90; 5 M reads (39 062) 34 / 35, 44 / 50, 55 / 59; 2.5 M reads (19 531) 21 / 26,
@@ -1476,7 +1478,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     const int want = ctx->o.phases > 0 ? ctx->o.phases : (pays ? 2 : 1);
     if (ctx->o.phases == 2 && !can)
       return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path), one GPU, at least 4096 "
-                  "chains and 8192 .. 2^31 - 1 reads");
+                  "chains and 8192 .. 2^31 - 1 reads, at least as many reads as chains");
     if (ctx->o.phases > 2) return fail(SPRING_REORDER_E_ARG, "phases: 0 (library's choice), 1 or 2");
     P.phases = (want == 2 && can) ? 2 : 1;
     ctx->Kh = half; ctx->nmid = nmid;

@@ -107,6 +107,16 @@ def test_fuzz_two_chain_groups(block):
         dna, n, L, K, T = _random_case(seed, 8192, 30000, (4096, 4100, 5000, 6144, 8192, 12288))
         if n < 8192:  # (the duplicate-heavy generator rounds n down)
             continue
+        if n < K:  # fewer reads than chains: only chain 0 would run -- the schedule is refused (one group is what runs then)
+            with pytest.raises(spring_amd.ReorderError):
+                spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, phases=2))
+            auto = spring_amd.reorder_dna(dna, n, L, spring_amd.ReorderOpts(num_chains=K, num_thr=T, phases=-1))
+            assert auto["stats"]["phases"] == 1
+            read, ln = po.load_dna(dna, n, L)
+            want = po.reorder_rounds(read, ln, L, K, T)
+            for k in KEYS:
+                assert np.array_equal(auto[k], want[k]), ("seed", seed, "fewer reads than chains", k)
+            continue
         rng = np.random.default_rng(seed + 5)
         A = int(rng.choice([1, 1, 2]))
         deep = 1 if A == 2 else int(rng.choice([1, -1, -1]))

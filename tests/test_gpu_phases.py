@@ -144,7 +144,8 @@ def test_one_group_schedule_untouched_and_library_choice():
 
 def test_refused_where_it_cannot_run():
     sa = _sa()
-    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=-1), dict(num_chains=4096, force_literal_update=True)):
+    for kw in (dict(num_chains=1024, fused=3), dict(num_chains=4096, fused=-1), dict(num_chains=4096, force_literal_update=True),
+               dict(num_chains=65536)):  # (the last: fewer reads than chains -- only chain 0 would run, the second group none)
         with sa.ReorderStage(sa.ReorderOpts(num_thr=1, phases=2, **kw)) as st:
             st.load_synth(50_000, 100, 200_000, 5, 10000)
             st.build_dict()
