@@ -110,6 +110,9 @@ typedef struct {
                              contended ones, and not where the long searches of a pool go to the long-search kernels), else 1.  2 needs the fused round, one GPU
                              (a device list / a multi-GPU pool runs one group), at least 4 096 chains and 8 192 .. 2^31 - 1 reads, not fewer reads
                              than chains */
+  int32_t known_absent;   /* four-chain round kernel, reads up to 192 bases: a chain remembers which windows of its consensus are
+                             known to be absent from the dictionaries (the table is immutable, so the answer holds while the
+                             bases under a window do) and later searches skip them.  0 = on, -1 = off.  Same results either way */
 } spring_reorder_opts;
 
 typedef struct {

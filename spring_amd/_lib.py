@@ -34,7 +34,7 @@ class Opts(C.Structure):
                 ("num_devices", C.c_int32), ("devices", C.c_int32 * 8), ("mg_host_transport", C.c_int32),
                 ("table_mode", C.c_int32), ("plan0", C.c_int32 * 6), ("plan1", C.c_int32 * 6), ("long_min", C.c_int32),
                 ("long_blocks", C.c_int32), ("debug", C.c_int32), ("long_split", C.c_int32), ("entry_flags", C.c_int32),
-                ("out_writers", C.c_int32), ("alternatives", C.c_int32), ("phases", C.c_int32)]
+                ("out_writers", C.c_int32), ("alternatives", C.c_int32), ("phases", C.c_int32), ("known_absent", C.c_int32)]
 
 
 class FastqInfo(C.Structure):

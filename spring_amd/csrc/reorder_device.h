@@ -162,6 +162,8 @@ struct DevParams {
   int fused;                 // 1: k_round (apply + search in one kernel)
   int alts;                  // candidates per match proposal: 1, or 2 (the alternatives schedule; deep-bin kernel variants, fused rounds)
   int mc;                    // 1: four chains per wavefront (k_round_mc) where it applies
+  int ka, ka_lo;             // ka = 1: k_round_mc's chains keep known-absent window masks (reorder_round_mc.h: search_ka); four limbs per
+                             // strand live in Chain::revref[8..15] between rounds, the forward strand's from limb ka_lo
   // k_round_mc runs chains of one class per wavefront (the four chains of a wavefront take the union of their
   // paths): k_mg_mark sorts the running local chains of every block of MARK_BLOCK consecutive chain ids by what the
   // next round will ask of them -- 0 left search after a failed right search, 1 first search of a new seed, 2 search

@@ -3227,8 +3227,12 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
     const uint32_t nseg = (P.c0 + P.g0 + P.Kg + MARK_BLOCK - 1) / MARK_BLOCK - (P.c0 + P.g0) / MARK_BLOCK;
     const dim3 g4(nseg * MC_WAVES_PER_BLOCK);
     if (P.Lpad <= 192) {
-      if (mg) hipLaunchKernelGGL((k_round_mc<3, true>), g4, b, 0, st, P);
-      else hipLaunchKernelGGL((k_round_mc<3, false>), g4, b, 0, st, P);
+      // (P.ka: the chains remember which windows of their consensus are known absent -- search_ka, reorder_round_mc.h)
+      if (P.ka) {
+        if (mg) hipLaunchKernelGGL((k_round_mc<3, true, true>), g4, b, 0, st, P);
+        else hipLaunchKernelGGL((k_round_mc<3, false, true>), g4, b, 0, st, P);
+      } else if (mg) hipLaunchKernelGGL((k_round_mc<3, true, false>), g4, b, 0, st, P);
+      else hipLaunchKernelGGL((k_round_mc<3, false, false>), g4, b, 0, st, P);
     } else {
       if (mg) hipLaunchKernelGGL((k_round_mc_long<true>), g4, b, 0, st, P);
       else hipLaunchKernelGGL((k_round_mc_long<false>), g4, b, 0, st, P);

@@ -1492,6 +1492,16 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // kernel's lead below 40 000 chains is 5-16 %)
   if (K < (P.phases == 2 ? 32768u : 49152u) && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
   if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
+  // known-absent window masks (reorder_round_mc.h: search_ka): reads up to 192 bases -- four limbs per strand in the spare
+  // half of Chain::revref, the forward strand's from the limb of its first window (offsets dstart[0] .. L - wl)
+  P.ka = 0; P.ka_lo = 0;
+  if (P.mc && P.Lpad <= 192 && ctx->o.known_absent >= 0) {
+    const int wlen = ctx->dict[0].end - ctx->dict[0].start + 1, lo = ctx->dict[0].start >> 5;
+    if (wlen <= 32 && ctx->dict[1].start == ctx->dict[0].end + 1 && ctx->dict[1].end - ctx->dict[1].start + 1 == wlen &&
+        2 * (ctx->L - wlen) + 2 <= 64 * (lo + 4) && 2 * ctx->dict[1].start + 2 <= 256 && lo + 4 <= 6) {
+      P.ka = 1; P.ka_lo = lo;
+    }
+  }
   if (ctx->minz && !(fused && P.mc && !ctx->o.collect_stats && !P.deep_bins))
     return fail(SPRING_REORDER_E_ARG, "table_mode = 2 (minimizer-addressed table) is an experiment of the four-chain round kernel: "
                 "shallow dictionary, at least 49152 chains or fused = 3, no work counters");

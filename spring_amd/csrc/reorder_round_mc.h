@@ -32,7 +32,13 @@ struct GLds {
   uint64_t refs[2][LIMBS];          // ref / revref
   uint64_t rd[WMAX + 2];            // the read being merged, one zero limb either side
   uint64_t nref[WMAX];              // the speculative update's consensus, 4 bases per byte (= the limb format)
-  uint8_t pres[128];                // probe_tail: "the other dictionary may hold this window", by probe code
+  union {
+    uint8_t pres[128];              // tail_mc: "the other dictionary may hold this window", by probe code
+    // search_ka (k_round_mc<.., KA = true>): known-absent windows, the layout of refs -- bit 2 o + l of ka[s] says "the window
+    // at offset o of ref (s = 0) / revref (s = 1) is absent from dictionary l".  The table never changes, so the bit
+    // holds for as long as the bases under the window do: commit_consensus_ka moves it with them.
+    uint64_t ka[2][NQ <= 3 ? LIMBS : 2];  // (reads up to 192 bases only)
+  };
   uint32_t best;                    // lowest priority code that has hit in the running batch (eval_probe)
   uint32_t pad[3];
   uint32_t mz[MZ];                  // mz[w] = minz value of the consensus window at offset w (minz_mc)
@@ -83,7 +89,7 @@ typedef uint32_t u32x4a_t __attribute__((ext_vector_type(4), aligned(4)));
 template <int NQ>
 __device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<NQ> &S, uint32_t rid, int n, bool reset,
                                          bool rev, int shift, int R, int cb, bool cur_wide, bool out_wide,
-                                         bool &overflow, int gl) {
+                                         bool &overflow, int gl, int *o_src = nullptr, int *o_cpy = nullptr, bool *o_alias = nullptr) {
   const int M = P.L, W = P.W;
   const int4 *__restrict__ cur = P.cnt + ((uint64_t)li * 2 + cb) * P.Lpad;
   int4 *__restrict__ nxt = P.cnt + ((uint64_t)li * 2 + (cb ^ 1)) * P.Lpad;
@@ -97,6 +103,7 @@ __device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<N
   else if (R + shift <= M) { Rn = R + shift; hiP = Rn; cpy_hi = R; src_off = 0; add_lo = R - n + shift; add_hi = Rn; }
   else { Rn = M; hiP = M; cpy_hi = M - shift; src_off = R + shift - M; add_lo = M - n; add_hi = M; }
   const bool fast = !alias && !cur_wide && !out_wide;
+  if (o_src) { *o_src = src_off; *o_cpy = cpy_hi; *o_alias = alias; }  // new position p < cpy_hi = old position p + src_off
 
   // issue the loads first: the read's limbs and (fast path) this lane's source quads
   const uint64_t myl = gl < W ? P.reads[(uint64_t)rid * P.S + gl] : 0ull;
@@ -208,6 +215,84 @@ __device__ __forceinline__ void commit_consensus(const DevParams &P, GLds<NQ> &S
   wave_sync();
 }
 
+// ---- known-absent windows (k_round_mc<.., KA = true>; reads up to 192 bases).  99 % of a search's probes are for keys the
+// dictionaries do not hold, and the table never changes: "the 32-mer under this window is absent" stays true for as long as
+// the bases under the window do.  A chain keeps two bits per window offset and strand (GLds::ka), sets them when the tags of
+// a fetched bucket prove a key absent (search_ka), moves them with the consensus when a read is merged and drops those of
+// every window that covers a position whose consensus base changed or is new (below), swaps the strands when a lone seed
+// turns round for its left search (its consensus is exactly the old reverse consensus), and clears them on a new seed.
+// A later search skips the windows it knows about BEFORE a key or an address is formed: the first batch of the search
+// that follows a match at shift s has already seen all but s of its shifts, a failing search repeated after a lost
+// proposal fetches nothing.  Exactness is untouched: a skipped probe is one whose answer was "absent".
+// Between rounds the masks live in the unused half of the chain record (Chain::revref[8..15]: four limbs of either
+// strand, from limb DevParams::ka_lo of the forward one -- the offsets a search can ask about, reorder.h:262-270).
+__device__ __forceinline__ uint64_t gshfl_down1_u64(uint64_t v) {
+  const uint32_t lo = __shfl_down((uint32_t)v, 1, G), hi = __shfl_down((uint32_t)(v >> 32), 1, G);
+  return ((uint64_t)hi << 32) | lo;
+}
+// d / dn: changed positions (both bits of a position set) of this limb and the next one -> the windows of this limb (32
+// offsets, 2 bits each) that cover one of them: a window spans the positions [o, o + 31] (shorter windows: conservative)
+__device__ __forceinline__ uint64_t ka_stale(uint64_t d, uint64_t dn) {
+  return (d ? ~0ull >> __clzll(d) : 0ull) | (dn ? (~0ull << (__ffsll((unsigned long long)dn) - 1)) << 2 : 0ull);
+}
+// mode 0: the update kept old position p + src_off at new position p < cpy_hi; 1: nothing is known about the new
+// consensus; 2: ref and revref change places
+template <int NQ>
+__device__ __forceinline__ void commit_consensus_ka(const DevParams &P, GLds<NQ> &S, Chain *c, int R_old, int R, int src_off,
+                                                    int cpy_hi, int mode, int gl) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD, WM = GLds<NQ>::WMAX;
+  constexpr uint64_t EVEN = 0x5555555555555555ull;
+  const int dlt = R_old - R - src_off;  // revref_new[j] = revref_old[j + dlt] for j >= -dlt (dlt <= 0: reorder.h:144-200)
+  if (mode == 0 && (src_off > 32 * (LDS_PAD - 1) || dlt < -32 * (LDS_PAD - 1) || dlt > 0)) mode = 1;
+  wave_sync();
+  const bool in = gl < P.W;
+  const uint64_t limb = in ? S.nref[gl] : 0ull;
+  uint64_t kf = 0, kr = 0, df = ~0ull, dr = ~0ull;
+  if (gl < WM) {
+    if (mode == 0) {
+      uint64_t x = limb ^ lds_window(S.refs[0] + LDS_PAD, 64 * gl + 2 * src_off);
+      x = (x | (x >> 1)) & EVEN;
+      x |= x << 1;
+      const int b = 2 * cpy_hi - 64 * gl;  // positions >= cpy_hi are new
+      if (b < 64) x |= b <= 0 ? ~0ull : ~0ull << b;
+      df = x;
+      kf = lds_window(S.ka[0] + LDS_PAD, 64 * gl + 2 * src_off);
+    } else if (mode == 2) {
+      kf = S.ka[1][LDS_PAD + gl];
+      kr = S.ka[0][LDS_PAD + gl];
+    }
+  }
+  if (mode == 0) kf &= ~ka_stale(df, gshfl_down1_u64(df));
+  wave_sync();
+  if (gl < WM) { S.refs[0][LDS_PAD + gl] = limb; S.ka[0][LDS_PAD + gl] = kf; }
+  if (in) c->ref[gl] = limb;
+  wave_sync();
+  uint64_t rl = 0;
+  if (in && 32 * gl < R) {
+    const uint64_t w = lds_window(S.refs[0] + LDS_PAD, 2 * (R - 32 - 32 * gl));
+    uint64_t x = __builtin_bitreverse64(w);
+    x = ((x >> 1) & EVEN) | ((x & EVEN) << 1);
+    const int nv = R - 32 * gl;
+    rl = ~x & (nv >= 32 ? ~0ull : ((1ull << (2 * nv)) - 1));
+  }
+  if (mode == 0) {
+    if (gl < WM) {
+      uint64_t x = rl ^ lds_window(S.refs[1] + LDS_PAD, 64 * gl + 2 * dlt);
+      x = (x | (x >> 1)) & EVEN;
+      x |= x << 1;
+      const int b = -2 * dlt - 64 * gl;  // positions < -dlt are new
+      if (b > 0) x |= b >= 64 ? ~0ull : ~(~0ull << b);
+      dr = x;
+      kr = lds_window(S.ka[1] + LDS_PAD, 64 * gl + 2 * dlt);
+    }
+    kr &= ~ka_stale(dr, gshfl_down1_u64(dr));
+  }
+  wave_sync();
+  if (gl < WM) { S.refs[1][LDS_PAD + gl] = rl; S.ka[1][LDS_PAD + gl] = kr; }
+  if (in) c->revref[gl] = rl;
+  wave_sync();
+}
+
 __device__ __forceinline__ uint32_t take_slot_mc(uint32_t &slot, uint32_t *alloc, uint2 *chunk, uint32_t li, uint32_t next_seq, int gl) {
   const uint32_t s0 = slot;
   uint32_t nx = s0 + 1;
@@ -243,7 +328,7 @@ __device__ __forceinline__ void emit_single_mc(const DevParams &P, ChainHot &h, 
 }
 
 // phase B of one chain (apply_step with the shared state deferred to k_mg_mark).  false: the chain is done.
-template <int NQ>
+template <int NQ, bool KA>
 __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, GLds<NQ> &S, int gl) {
   const int kind = h.prop_kind;
   if (kind == PROP_FRESH) return true;  // first round: nothing proposed yet
@@ -263,10 +348,12 @@ __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t 
   else if (fail_path && !h.left_search) { do_upd = true; urid = h.first_rid; ureset = true; urev = true; }  // reorder.h:567
   int n = P.L, R_new = h.ref_len;
   const int R_old = h.ref_len;
-  bool nw = false;
+  bool nw = false, ualias = false;
+  int usrc = 0, ucpy = 0;
   if (do_upd) {
     if (!P.uniform_len) n = (int)P.lens[urid];
-    R_new = update_mc<NQ>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, false, nw, gl);
+    R_new = update_mc<NQ>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, false, nw, gl,
+                          &usrc, &ucpy, &ualias);
     if (nw) {  // a count would pass 255: redo in the wide format
       bool o2;
       wave_sync();
@@ -280,7 +367,12 @@ __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t 
     return true;
   }
   if (do_upd) {
-    commit_consensus<NQ>(P, S, c, R_new, gl);
+    if constexpr (KA) {
+      // what the chain knows of its windows after this update: carried along (a merged read), turned round (a lone seed
+      // starts its left search: the new consensus is the old reverse consensus, reorder.h:562-571), or nothing
+      const int kmode = kind == PROP_MATCH ? (ualias ? 1 : 0) : (kind != PROP_SEED && h.prev_unmatched) ? 2 : 1;
+      commit_consensus_ka<NQ>(P, S, c, R_old, R_new, usrc, ucpy, kmode, gl);
+    } else commit_consensus<NQ>(P, S, c, R_new, gl);
     h.ref_len = R_new;
     h.cnt_buf ^= 1;
     h.cnt_wide = nw;
@@ -722,8 +814,232 @@ __device__ __forceinline__ void tail_mc(const DevParams &P, GLds<NQ> &S, lds_u32
   wrid = (uint32_t)__shfl((int)brid, __ffs((int)wm) - 1, G);
 }
 
+// ---- the search with known-absent windows (KA = true).  Probe codes in priority order (code = shift << 2 | rev << 1 |
+// dict, reorder.h:479-558), and which lane of a chain's 16 owns which:
+//   part 1, shifts below the window length wl: every code is a window of its own; lane gl owns the codes 16 i + gl
+//     (stream gl & 3 = rev << 1 | dict, shifts 4 i + (gl >> 2)) -- bit i of its need word;
+//   part 2, shifts wl .. maxshift - 1: the window of (forward, dictionary 0) at shift s is the window of (forward,
+//     dictionary 1) at s - wl, that of (reverse, 1) at s the one of (reverse, 0) at s - wl (the dictionaries' windows are
+//     adjacent and equally long, reorder.h:751-759) -- it has been fetched earlier in the search, and a fetch settles both
+//     dictionaries.  So only the streams (forward, 1) and (reverse, 0) fetch here: lane gl owns stream gl & 1 at the
+//     shifts wl + 8 i + (gl >> 1), bit 8 + i of its need word -- windows no code of part 1 touches, so the word is
+//     complete when the search starts;
+//   part 3: the codes of the other two streams at shifts >= wl whose window is STILL not known absent after all that (the
+//     tags showed a slot of that dictionary: 1-2 % of the windows) -- bits 16 + i, same mapping, built after part 2.
+// A lane takes its needed codes lowest first, m = 1, 2, 4, 4 ... per batch (DevParams::plan in units of four shifts):
+// the tag quads of a batch are fetched together, judged on the tags alone (every proven absence goes into GLds::ka, for
+// both dictionaries of the window), and only slots with the key's fingerprint get a closer look (eval_probe).  The winner
+// is the lowest code that hit; a lane drops its codes above the best hit so far, so the search ends when every lower
+// code has been looked at or was known absent -- whatever order the lanes got to them in.
+__device__ __forceinline__ uint32_t ka_pack8_up(uint64_t w) {  // bit 8 i of w -> bit i
+  const uint32_t lo = (uint32_t)w & 0x01010101u, hi = (uint32_t)(w >> 32) & 0x01010101u;
+  return (((lo * 0x01020408u) >> 24) & 15u) | ((((hi * 0x01020408u) >> 24) & 15u) << 4);
+}
+__device__ __forceinline__ uint32_t ka_pack8_down(uint64_t w) {  // bit 56 - 8 i of w -> bit i
+  const uint32_t lo = (uint32_t)w & 0x01010101u, hi = (uint32_t)(w >> 32) & 0x01010101u;
+  return (((hi * 0x08040201u) >> 24) & 15u) | ((((lo * 0x08040201u) >> 24) & 15u) << 4);
+}
+__device__ __forceinline__ uint32_t ka_pack16_up(uint64_t w) {  // bit 16 i of w -> bit i (i < 4)
+  const uint32_t lo = (uint32_t)w & 0x00010001u, hi = (uint32_t)(w >> 32) & 0x00010001u;
+  return ((lo | (lo >> 15)) & 3u) | (((hi | (hi >> 15)) & 3u) << 2);
+}
+__device__ __forceinline__ uint32_t ka_pack16_down(uint64_t w) {  // bit 48 - 16 i of w -> bit i (i < 4)
+  const uint32_t lo = (uint32_t)w & 0x00010001u, hi = (uint32_t)(w >> 32) & 0x00010001u;
+  return ((hi >> 16) & 1u) | ((hi & 1u) << 1) | (((lo >> 16) & 1u) << 2) | ((lo & 1u) << 3);
+}
+__device__ __forceinline__ uint32_t ka_bits_range(int lo, int hi) {  // bits [lo, hi) of a byte, any lo / hi
+  lo = max(lo, 0);
+  hi = min(hi, 8);
+  return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+}
+// valid shifts of stream (rev, l): [lo, hi) (probe_valid, reorder.h:264-268)
+__device__ __forceinline__ void ka_valid_shifts(const DevParams &P, int l, int rev, int ref_len, int &lo, int &hi) {
+  const int de = l ? uni_i32(P.dend[1]) : uni_i32(P.dend[0]), ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+  lo = rev ? max(0, de - ref_len + 1) : 0;
+  hi = min(P.maxshift, rev ? ds : ref_len - de);
+}
+// need bits of part 1 (bits 0..7) for this lane
+template <int NQ>
+__device__ __forceinline__ uint32_t ka_need1(const DevParams &P, GLds<NQ> &S, int ref_len, int gl) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD;
+  const int l = gl & 1, rev = (gl >> 1) & 1, r = gl >> 2;
+  const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+  int lo, hi;
+  ka_valid_shifts(P, l, rev, ref_len, lo, hi);
+  hi = min(hi, P.wl);
+  const uint32_t valid = ka_bits_range((lo - r + 3) >> 2, (hi - r + 3) >> 2);
+  const int b0 = 2 * (rev ? ds - r : ds + r) + l;
+  const uint32_t known = rev ? ka_pack8_down(lds_window(S.ka[1] + LDS_PAD, b0 - 56)) : ka_pack8_up(lds_window(S.ka[0] + LDS_PAD, b0));
+  return valid & ~known;
+}
+// need bits of part 2 (second = false: the streams that fetch) or part 3 (second = true: the streams that ride along), at bit 0
+template <int NQ>
+__device__ __forceinline__ uint32_t ka_need2(const DevParams &P, GLds<NQ> &S, int ref_len, int gl, bool second) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD;
+  const int rev = gl & 1, l = second ? rev : 1 - rev, r = gl >> 1;
+  const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
+  int lo, hi;
+  ka_valid_shifts(P, l, rev, ref_len, lo, hi);
+  const int wl = P.wl;
+  const uint32_t valid = ka_bits_range((lo - wl - r + 7) >> 3, (hi - wl - r + 7) >> 3);
+  const int b0 = 2 * (rev ? ds - wl - r : ds + wl + r) + l;
+  uint32_t known;
+  if (rev) known = ka_pack16_down(lds_window(S.ka[1] + LDS_PAD, b0 - 48)) | (ka_pack16_down(lds_window(S.ka[1] + LDS_PAD, b0 - 112)) << 4);
+  else known = ka_pack16_up(lds_window(S.ka[0] + LDS_PAD, b0)) | (ka_pack16_up(lds_window(S.ka[0] + LDS_PAD, b0 + 64)) << 4);
+  return valid & ~known;
+}
+// probe code of need bit b of lane gl
+__device__ __forceinline__ int ka_code_of_bit(int b, int gl, int wl) {
+  if (b < 8) return 16 * b + gl;
+  const int rev = gl & 1, l = b < 16 ? 1 - rev : rev;
+  return ((wl + 8 * (b & 7) + (gl >> 1)) << 2) | (rev << 1) | l;
+}
+// this lane's need bits whose code is below `cur`
+__device__ __forceinline__ uint32_t ka_keep_below(int cur, int gl, int wl) {
+  if (cur == INF_CODE) return 0xffffffu;
+  const uint32_t k1 = ka_bits_range(0, (cur - gl + 15) >> 4);
+  const int rev = gl & 1, base = ((wl + (gl >> 1)) << 2) | (rev << 1);
+  const uint32_t k2 = ka_bits_range(0, (cur - (base | (1 - rev)) + 31) >> 5), k3 = ka_bits_range(0, (cur - (base | rev) + 31) >> 5);
+  return k1 | (k2 << 8) | (k3 << 16);
+}
+
+// one batch: up to m <= 4 of this lane's needed codes (lowest first) -- tag quads, verdict on the tags, closer looks
+template <int NQ>
+__device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, uint32_t &need, int m, int ref_len,
+                                         int lane, int gl, int &best, uint32_t &brid) {
+  constexpr int LDS_PAD = GLds<NQ>::PAD;
+  const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
+  const bool minz = P.tab.minz != 0;
+  const int wl = P.wl, klen2 = 2 * wl;
+  const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
+  lds_u32_t *s_best = (lds_u32_t *)&S.best;
+  const uint32_t bmask = (uint32_t)bucket_mask(P.tab.bshift);
+  uint4 tg[4];
+  uint64_t key[4];
+  uint32_t bk[4];
+  int code[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    code[i] = -1;
+    key[i] = 0;
+    bk[i] = 0;
+    tg[i] = make_uint4(0, 0, 0, 0);
+    if (i < m && need) {
+      const int b = __ffs((int)need) - 1;
+      need &= need - 1;
+      const int cd = ka_code_of_bit(b, gl, wl);
+      code[i] = cd;
+      const int l = cd & 1, rev = (cd >> 1) & 1, shift = cd >> 2;
+      const int ds = l ? P.dstart[1] : P.dstart[0];
+      const int o = rev ? ds - shift : ds + shift;  // the window's offset in its strand
+      key[i] = lds_window(rev ? srev : sref, 2 * o) & kmask;
+      bk[i] = (uint32_t)tab_home(P.tab, mix64(key[i]), minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u);
+      tg[i] = P.tab.buck[2 * (uint64_t)bk[i]];
+    }
+  }
+  // verdict on the tags alone (batch_mc): pend = a slot with the key's fingerprint, cont = the bucket is full without
+  // one (the chain goes on), oth = the other dictionary may hold the window's key; pre as in batch_mc
+  uint32_t pend = 0, cont = 0, redir = 0, oth = 0, pre = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (code[i] < 0) continue;
+    if (minz && tg[i].x == TAG_MARK) { cont |= 1u << i; redir |= 1u << i; continue; }
+    bool other = false;
+    int slot = 0;
+    const int st = tags_step(tg[i], mix64(key[i]), code[i] & 1, other, slot);
+    if (other) oth |= 1u << i;
+    if (st == 1) { pend |= 1u << i; pre |= (uint32_t)((1 + ((slot >> 2) & 1)) | ((slot & 3) << 2)) << (4 * i); }
+    else if (st == 2) cont |= 1u << i;
+  }
+  for (int hop = 0; hop < QUICK_HOPS && __ballot(cont != 0); hop++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if ((cont >> i) & 1u) {
+        bk[i] = ((redir >> i) & 1u) ? (uint32_t)tab_redirect(P.tab, mix64(key[i])) : ((bk[i] + 1u) & bmask);
+        tg[i] = P.tab.buck[2 * (uint64_t)bk[i]];
+      }
+    redir = 0;
+    const uint32_t c2 = cont;
+    cont = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if ((c2 >> i) & 1u) {
+        bool other = false;
+        int slot = 0;
+        const int st = tags_step(tg[i], mix64(key[i]), code[i] & 1, other, slot);
+        if (other) oth |= 1u << i;
+        if (st == 1) pend |= 1u << i;  // (past the home bucket: eval_probe walks the chain itself)
+        else if (st == 2) cont |= 1u << i;
+      }
+  }
+  pend |= cont;  // chains longer than that: eval_probe walks them
+  oth |= cont;
+  // what the tags have proven absent: this code's dictionary (no slot of the key, the chain ended) and / or the other one
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (code[i] < 0) continue;
+    const int cd = code[i], l = cd & 1, rev = (cd >> 1) & 1, shift = cd >> 2;
+    const uint32_t own = ((pend >> i) & 1u) ^ 1u, other = ((oth >> i) & 1u) ^ 1u;
+    const uint32_t bits = (own << l) | (other << (1 - l));
+    if (bits) {
+      const int ds = l ? P.dstart[1] : P.dstart[0];
+      const int o = rev ? ds - shift : ds + shift;
+      lds_u32_t *w = (lds_u32_t *)(S.ka[rev] + LDS_PAD) + (o >> 4);
+      __hip_atomic_fetch_or(w, bits << (2 * (o & 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+  // the closer looks of all lanes run together, one per lane and pass, lowest code first
+  while (__ballot(pend != 0)) {
+    if (pend) {
+      const int i = __ffs((int)pend) - 1;
+      pend &= pend - 1;
+      const int cd = i == 0 ? code[0] : i == 1 ? code[1] : i == 2 ? code[2] : code[3];
+      const int l = cd & 1, rev = (cd >> 1) & 1, shift = cd >> 2;
+      if (cd < best && !(*(volatile lds_u32_t *)s_best < (uint32_t)cd)) {
+        bool hit = false, keyok = false, other = false;
+        uint32_t rid = 0, ncand = 0;
+        const int ds = l ? P.dstart[1] : P.dstart[0], o = rev ? ds - shift : ds + shift;
+        const uint64_t k = lds_window(rev ? srev : sref, 2 * o) & kmask;
+        eval_probe<false, false, false, true>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k),
+                                       minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u, hit, rid, keyok, ncand, other, s_best, stage,
+                                       lane, nullptr, nullptr, (int)((pre >> (4 * i)) & 15u));
+        if (hit) { best = cd; brid = rid; }
+      }
+    }
+  }
+}
+
+template <int NQ>
+__device__ __forceinline__ void search_ka(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, int ref_len, int wide, int lane, int gl,
+                                          int &wcode, uint32_t &wrid) {
+  lds_u32_t *s_best = (lds_u32_t *)&S.best;
+  if (gl == 0) *s_best = (uint32_t)INF_CODE;
+  wave_sync();
+  const int wl = P.wl;
+  uint32_t need = ka_need1<NQ>(P, S, ref_len, gl) | (ka_need2<NQ>(P, S, ref_len, gl, false) << 8);
+  int best = INF_CODE;
+  uint32_t brid = 0;
+  for (int b = 0; __ballot(need != 0); b++) {
+    const int w = b < 6 ? (wide ? P.plan[1][b] : P.plan[0][b]) : 0;
+    const int m = w > 0 ? min(4, (w + 3) >> 2) : 4;
+    batch_ka<NQ>(P, S, stage, need, m, ref_len, lane, gl, best, brid);
+    need &= ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
+  }
+  wave_sync();  // ka
+  if ((int)*(volatile lds_u32_t *)s_best > 4 * wl) {  // the codes that rode along: only where a window is still not known absent
+    need = (ka_need2<NQ>(P, S, ref_len, gl, true) << 16) & ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
+    while (__ballot(need != 0)) {
+      batch_ka<NQ>(P, S, stage, need, 4, ref_len, lane, gl, best, brid);
+      need &= ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
+    }
+  }
+  wcode = gmin_i(best);
+  const uint32_t wm = gballot(best == wcode, lane);
+  wrid = (uint32_t)__shfl((int)brid, __ffs((int)wm) - 1, G);
+}
+
 // phase A of one chain (search_step: proposal word + direct reservation of the read)
-template <int NQ, bool MG>
+template <int NQ, bool MG, bool KA>
 __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds<NQ> &S, lds_u32_t *stage,
                                           int lane, int gl) {
   if (h.mode == MODE_NEED_SEED) {
@@ -766,7 +1082,8 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
   PT(18);
   int wcode = INF_CODE, t0 = 0;
   uint32_t wrid = 0;
-  for (int ph = 0; ph < 6 && t0 < P.maxshift; ph++) {
+  if constexpr (KA) search_ka<NQ>(P, S, stage, ref_len, wide, lane, gl, wcode, wrid);
+  else for (int ph = 0; ph < 6 && t0 < P.maxshift; ph++) {
     const int w = wide ? P.plan[1][ph] : P.plan[0][ph];
     if (w <= 0) break;
     batch_mc<NQ>(P, S, stage, 4 * t0, 4 * (t0 + w), ref_len, lane, gl, wcode, wrid);
@@ -774,7 +1091,7 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
     t0 += w;
     if (wcode != INF_CODE) break;
   }
-  if (wcode == INF_CODE && t0 < P.maxshift) {
+  if (!KA && wcode == INF_CODE && t0 < P.maxshift) {
     wave_sync();  // pres
     tail_mc<NQ>(P, S, stage, t0, ref_len, lane, gl, wcode, wrid);
     PT(22);
@@ -802,8 +1119,9 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
 #ifndef SR_MC_WAVES
 #define SR_MC_WAVES 5  // waves per SIMD the kernel is compiled for (512 / SR_MC_WAVES VGPRs)
 #endif
-template <int NQ, bool MG>
+template <int NQ, bool MG, bool KA>
 __device__ __forceinline__ void round_mc_body(const DevParams &P) {
+  static_assert(!KA || NQ <= 3, "known-absent masks: reads up to 192 bases (the spare half of Chain::revref)");
   typedef mc::GLds<NQ> GL;
   __shared__ GL s_g[mc::CPW];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
@@ -840,6 +1158,13 @@ __device__ __forceinline__ void round_mc_body(const DevParams &P) {
   {
     const uint4 *hq = reinterpret_cast<const uint4 *>(&c->h);
     const uint4 q0 = hq[0], q1 = hq[1], q2 = hq[2], q3 = hq[3];
+    if constexpr (KA) {  // the chain's known-absent masks: four limbs of either strand (commit_consensus_ka); the rest is zero
+      static_assert(GL::LIMBS <= mc::G, "one limb per lane");
+      const uint64_t kav = gl < 8 ? c->revref[8 + gl] : 0ull;
+      if (gl < GL::LIMBS) { S.ka[0][gl] = 0ull; S.ka[1][gl] = 0ull; }
+      wave_sync();
+      if (gl < 8) S.ka[gl >> 2][GL::PAD + (gl < 4 ? P.ka_lo : 0) + (gl & 3)] = kav;
+    }
     for (int i = gl; i < GL::LIMBS; i += mc::G) {
       const int k = i - GL::PAD;
       const bool in = k >= 0 && k < P.W;
@@ -861,12 +1186,16 @@ __device__ __forceinline__ void round_mc_body(const DevParams &P) {
     return;
   }
   PTW(16);
-  if (!mc::apply_mc<NQ>(P, c, cid, li, h, S, gl)) {
+  if (!mc::apply_mc<NQ, KA>(P, c, cid, li, h, S, gl)) {
     if (gl == 0) P.prop[cid] = (unsigned long long)PK_DONE << 32;
     return;
   }
   PT(17);
-  mc::search_mc<NQ, MG>(P, c, cid, h, S, (lds_u32_t *)s_stage, lane, gl);
+  mc::search_mc<NQ, MG, KA>(P, c, cid, h, S, (lds_u32_t *)s_stage, lane, gl);
+  if constexpr (KA) if (h.mode == MODE_SEARCH) {  // what the chain knows now, for its next round
+    wave_sync();
+    if (gl < 8) c->revref[8 + gl] = S.ka[gl >> 2][GL::PAD + (gl < 4 ? P.ka_lo : 0) + (gl & 3)];
+  }
   PTW(24);
 #ifdef SR_PHASE_TIMING  // (experiment builds) the wavefront's table goes to the chain of its first lane still here
   {
@@ -879,14 +1208,14 @@ __device__ __forceinline__ void round_mc_body(const DevParams &P) {
 }
 // reads up to 192 bases: 5 waves per SIMD (96 VGPRs); longer reads (eight position quads per lane in the update) spill 14
 // VGPRs there and get 4 (128 VGPRs): no chain kernel uses scratch memory
-template <int NQ, bool MG>
+template <int NQ, bool MG, bool KA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_MC_WAVES, SR_MC_WAVES))) void k_round_mc(DevParams P) {
   static_assert(NQ <= 3, "long reads: k_round_mc_long");
-  round_mc_body<NQ, MG>(P);
+  round_mc_body<NQ, MG, KA>(P);
 }
 template <bool MG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round_mc_long(DevParams P) {
-  round_mc_body<8, MG>(P);
+  round_mc_body<8, MG, false>(P);
 }
 
 #endif

@@ -52,6 +52,7 @@ class ReorderOpts:
     alternatives: int = 0     # candidates per match proposal: 1, 2 (a loser takes the next passing read of the bin), 0 = library's choice
     table_mode: int = 0       # 2: dictionary table addressed by the key's minimizer where that applies (experiment; 0 / 1 = by its hash)
     phases: int = 0           # chain schedule: 1 lock-step rounds, 2 two chain groups whose rounds alternate (the output depends on it), 0 = library's choice
+    known_absent: int = 0     # four-chain round kernel: chains remember known-absent windows (0 on, -1 off; same results)
 
     def to_c(self):
         o = _lib.Opts()
@@ -75,6 +76,7 @@ class ReorderOpts:
         o.out_writers = self.out_writers
         o.alternatives = self.alternatives
         o.phases = self.phases
+        o.known_absent = self.known_absent
         o.num_devices = len(self.devices)
         for i, d in enumerate(self.devices):
             o.devices[i] = d
