@@ -1048,7 +1048,7 @@ __device__ __forceinline__ int cmp_candidate(const DevParams &P, const uint64_t 
     const int ihi = min(i0 + STAGE_LIMBS - 1, last);
     // unrolled (all LDS reads of a chunk issued first) the round kernels spill: 420 -> 569 ms at the headline size;
     // k_long has the registers (UNROLL: every limb of the chunk, the ones outside [first, last] masked to nothing)
-#pragma unroll(UNROLL ? STAGE_LIMBS : 1)
+#pragma unroll UNROLL ? STAGE_LIMBS : 1
     for (int i = UNROLL ? i0 : max(i0, first); i <= (UNROLL ? min(i0 + STAGE_LIMBS, W) - 1 : ihi); i++) {
       if (UNROLL && (i < first || i > last)) continue;
       const int u = i - i0;
@@ -1695,7 +1695,8 @@ __device__ __forceinline__ int search_step(const DevParams &P, Chain *c, uint32_
 // ------------------------------------------------------------ K4 search (phase A of the two-kernel round)
 // WPB = chains (wavefronts) per block.
 template <bool STATS, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_search(DevParams P) {  // (7: no scratch)
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(STATS ? (WPB == 4 ? 5 : 6) : 7, STATS ? (WPB == 4 ? 5 : 6) : 7)))
+void k_search(DevParams P) {  // (7: no scratch; the counting builds carry the work counters: 6 / 5)
   __shared__ uint64_t s_refs[WPB][2][LDS_LIMBS];
   __shared__ uint16_t s_list[WPB][TAIL_CAP];
   __shared__ uint16_t s_stat[STATS ? WPB : 1][STATS ? 2 * TAIL_CAP : 2];
@@ -2000,7 +2001,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_ROUND_WAV
   round_body<NP, STATS, MG, false, false>(P);
 }
 template <int NP, bool STATS, bool MG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_TRIM_WAVES, SR_TRIM_WAVES))) void k_round_t(DevParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STATS ? 5 : SR_TRIM_WAVES, STATS ? 5 : SR_TRIM_WAVES))) void k_round_t(DevParams P) {
   round_body<NP, STATS, MG, true, false>(P);
 }
 template <int NP, bool MG>
@@ -2009,7 +2010,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_LONG_WAVE
 }
 
 template <int NP, bool STATS, bool MG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SR_ROUND_WAVES, SR_ROUND_WAVES))) void k_round_nt(DevParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(STATS ? 5 : SR_ROUND_WAVES, STATS ? 5 : SR_ROUND_WAVES))) void k_round_nt(DevParams P) {
   round_body<NP, STATS, MG, false, false>(P);
 }
 

@@ -1495,7 +1495,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // known-absent window masks (reorder_round_mc.h: search_ka): reads up to 192 bases -- four limbs per strand in the spare
   // half of Chain::revref, the forward strand's from the limb of its first window (offsets dstart[0] .. L - wl)
   P.ka = 0; P.ka_lo = 0;
-  if (P.mc && P.Lpad <= 192 && ctx->o.known_absent >= 0) {
+  if (P.mc && P.Lpad <= 192 && ctx->o.known_absent >= 0 && !ctx->minz) {
     const int wlen = ctx->dict[0].end - ctx->dict[0].start + 1, lo = ctx->dict[0].start >> 5;
     if (wlen <= 32 && ctx->dict[1].start == ctx->dict[0].end + 1 && ctx->dict[1].end - ctx->dict[1].start + 1 == wlen &&
         2 * (ctx->L - wlen) + 2 <= 64 * (lo + 4) && 2 * ctx->dict[1].start + 2 <= 256 && lo + 4 <= 6) {

@@ -23,12 +23,12 @@ constexpr int CPW = 64 / G;  // chains per wavefront
 
 // per chain; sized by the instantiation (NQ = 3: reads up to 192 bases, 6 limbs, shifts up to 96 -> 4 pad limbs) so that
 // the block stays inside 6 LDS granules of 1280 bytes = 20 blocks per CU at 5 waves per SIMD with the minimizer array
-template <int NQ>
+template <int NQ, bool KA>
 struct GLds {
   static constexpr int WMAX = NQ <= 3 ? 6 : 16;      // limbs of a read
   static constexpr int PAD = NQ <= 3 ? 4 : LDS_PAD;  // zero limbs either side of ref / revref (lds_window)
   static constexpr int LIMBS = WMAX + 2 * PAD;
-  static constexpr int MZ = NQ <= 3 ? 164 : 4;       // window minimizers (TabView::minz: reads up to 192 bases only)
+  static constexpr int MZ = NQ <= 3 && !KA ? 164 : 4;  // window minimizers (TabView::minz: reads up to 192 bases, not with the known-absent masks)
   uint64_t refs[2][LIMBS];          // ref / revref
   uint64_t rd[WMAX + 2];            // the read being merged, one zero limb either side
   uint64_t nref[WMAX];              // the speculative update's consensus, 4 bases per byte (= the limb format)
@@ -37,7 +37,7 @@ struct GLds {
     // search_ka (k_round_mc<.., KA = true>): known-absent windows, the layout of refs -- bit 2 o + l of ka[s] says "the window
     // at offset o of ref (s = 0) / revref (s = 1) is absent from dictionary l".  The table never changes, so the bit
     // holds for as long as the bases under the window do: commit_consensus_ka moves it with them.
-    uint64_t ka[2][NQ <= 3 ? LIMBS : 2];  // (reads up to 192 bases only)
+    uint64_t ka[2][KA ? LIMBS : 2];
   };
   uint32_t best;                    // lowest priority code that has hit in the running batch (eval_probe)
   uint32_t pad[3];
@@ -86,8 +86,8 @@ typedef uint32_t u32x4a_t __attribute__((ext_vector_type(4), aligned(4)));
 // out, no in-place aliasing): one 16-byte load (at the shifted source position), four packed-byte additions, one
 // 16-byte store per quad; the new consensus goes to S.nref four bases per byte -- the limb format itself.
 // Anything else (wide counts, the aliasing case of the reference) takes the generic per-position path.
-template <int NQ>
-__device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<NQ> &S, uint32_t rid, int n, bool reset,
+template <int NQ, bool KA>
+__device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<NQ, KA> &S, uint32_t rid, int n, bool reset,
                                          bool rev, int shift, int R, int cb, bool cur_wide, bool out_wide,
                                          bool &overflow, int gl, int *o_src = nullptr, int *o_cpy = nullptr, bool *o_alias = nullptr) {
   const int M = P.L, W = P.W;
@@ -114,7 +114,7 @@ __device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<N
     old[k] = (u32x4a_t)(0u);
     if (fast && p0 < cpy_hi) old[k] = *reinterpret_cast<const u32x4a_t *>(cur8 + p0 + src_off);
   }
-  if (gl < GLds<NQ>::WMAX) S.rd[1 + gl] = myl;
+  if (gl < GLds<NQ, KA>::WMAX) S.rd[1 + gl] = myl;
   wave_sync();
   const uint64_t *rd = S.rd;
 
@@ -185,20 +185,20 @@ __device__ __forceinline__ int update_mc(const DevParams &P, uint32_t li, GLds<N
       }
 #undef MC_LOAD_CNT
     }
-    if (q < 8 * GLds<NQ>::WMAX) reinterpret_cast<uint8_t *>(S.nref)[q] = (uint8_t)codes;
+    if (q < 8 * GLds<NQ, KA>::WMAX) reinterpret_cast<uint8_t *>(S.nref)[q] = (uint8_t)codes;
   }
   overflow = gballot(ovf, (int)threadIdx.x) != 0;
   return Rn;
 }
 
 // commit of a speculative update: S.nref -> ref (LDS + global), revref = its reverse complement (LDS + global)
-template <int NQ>
-__device__ __forceinline__ void commit_consensus(const DevParams &P, GLds<NQ> &S, Chain *c, int R, int gl) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD;
+template <int NQ, bool KA>
+__device__ __forceinline__ void commit_consensus(const DevParams &P, GLds<NQ, KA> &S, Chain *c, int R, int gl) {
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD;
   wave_sync();
   const bool in = gl < P.W;
   const uint64_t limb = in ? S.nref[gl] : 0ull;
-  if (gl < GLds<NQ>::WMAX) S.refs[0][LDS_PAD + gl] = limb;
+  if (gl < GLds<NQ, KA>::WMAX) S.refs[0][LDS_PAD + gl] = limb;
   if (in) c->ref[gl] = limb;
   wave_sync();
   uint64_t rl = 0;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void commit_consensus(const DevParams &P, GLds<NQ> &S
     const int nv = R - 32 * gl;
     rl = ~x & (nv >= 32 ? ~0ull : ((1ull << (2 * nv)) - 1));
   }
-  if (gl < GLds<NQ>::WMAX) S.refs[1][LDS_PAD + gl] = rl;
+  if (gl < GLds<NQ, KA>::WMAX) S.refs[1][LDS_PAD + gl] = rl;
   if (in) c->revref[gl] = rl;
   wave_sync();
 }
@@ -237,10 +237,10 @@ __device__ __forceinline__ uint64_t ka_stale(uint64_t d, uint64_t dn) {
 }
 // mode 0: the update kept old position p + src_off at new position p < cpy_hi; 1: nothing is known about the new
 // consensus; 2: ref and revref change places
-template <int NQ>
-__device__ __forceinline__ void commit_consensus_ka(const DevParams &P, GLds<NQ> &S, Chain *c, int R_old, int R, int src_off,
+template <int NQ, bool KA>
+__device__ __forceinline__ void commit_consensus_ka(const DevParams &P, GLds<NQ, KA> &S, Chain *c, int R_old, int R, int src_off,
                                                     int cpy_hi, int mode, int gl) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD, WM = GLds<NQ>::WMAX;
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD, WM = GLds<NQ, KA>::WMAX;
   constexpr uint64_t EVEN = 0x5555555555555555ull;
   const int dlt = R_old - R - src_off;  // revref_new[j] = revref_old[j + dlt] for j >= -dlt (dlt <= 0: reorder.h:144-200)
   if (mode == 0 && (src_off > 32 * (LDS_PAD - 1) || dlt < -32 * (LDS_PAD - 1) || dlt > 0)) mode = 1;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void emit_single_mc(const DevParams &P, ChainHot &h, 
 
 // phase B of one chain (apply_step with the shared state deferred to k_mg_mark).  false: the chain is done.
 template <int NQ, bool KA>
-__device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, GLds<NQ> &S, int gl) {
+__device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t cid, uint32_t li, ChainHot &h, GLds<NQ, KA> &S, int gl) {
   const int kind = h.prop_kind;
   if (kind == PROP_FRESH) return true;  // first round: nothing proposed yet
   if (h.finishing) {  // seed-needing chain found the pool empty
@@ -352,12 +352,12 @@ __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t 
   int usrc = 0, ucpy = 0;
   if (do_upd) {
     if (!P.uniform_len) n = (int)P.lens[urid];
-    R_new = update_mc<NQ>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, false, nw, gl,
+    R_new = update_mc<NQ, KA>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, false, nw, gl,
                           &usrc, &ucpy, &ualias);
     if (nw) {  // a count would pass 255: redo in the wide format
       bool o2;
       wave_sync();
-      R_new = update_mc<NQ>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, true, o2, gl);
+      R_new = update_mc<NQ, KA>(P, li, S, urid, n, ureset, urev, ushift, R_old, (int)h.cnt_buf, h.cnt_wide != 0, true, o2, gl);
     }
   }
   if (owner != cid) {  // lost the read: retry, nothing committed
@@ -371,8 +371,8 @@ __device__ __forceinline__ bool apply_mc(const DevParams &P, Chain *c, uint32_t 
       // what the chain knows of its windows after this update: carried along (a merged read), turned round (a lone seed
       // starts its left search: the new consensus is the old reverse consensus, reorder.h:562-571), or nothing
       const int kmode = kind == PROP_MATCH ? (ualias ? 1 : 0) : (kind != PROP_SEED && h.prev_unmatched) ? 2 : 1;
-      commit_consensus_ka<NQ>(P, S, c, R_old, R_new, usrc, ucpy, kmode, gl);
-    } else commit_consensus<NQ>(P, S, c, R_new, gl);
+      commit_consensus_ka<NQ, KA>(P, S, c, R_old, R_new, usrc, ucpy, kmode, gl);
+    } else commit_consensus<NQ, KA>(P, S, c, R_new, gl);
     h.ref_len = R_new;
     h.cnt_buf ^= 1;
     h.cnt_wide = nw;
@@ -523,10 +523,10 @@ constexpr int QUICK_HOPS = 2;  // buckets past the home bucket (or the redirect 
 // at offset o of revref has the k-mers of the ref window at offset R - 32 - o.  Lane g of row j holds the order
 // value of the k-mer at q = 16 j + g; a window has 17 = 16 + 1 k-mers, so its minimum is the suffix minimum of one row
 // from lane g on and the prefix minimum of the next row up to lane g: two 4-step scans per row, no LDS round trip.
-template <int NQ>
-__device__ __forceinline__ void minz_mc(GLds<NQ> &S, int R, int gl) {
+template <int NQ, bool KA>
+__device__ __forceinline__ void minz_mc(GLds<NQ, KA> &S, int R, int gl) {
   static_assert(MINZ_WL - MINZ_K + 1 == G + 1, "a window's k-mers = one row of lanes + 1");
-  const uint64_t *sref = S.refs[0] + GLds<NQ>::PAD;
+  const uint64_t *sref = S.refs[0] + GLds<NQ, KA>::PAD;
   uint32_t sfx_prev = 0xffffffffu;
   for (int j = 0; j == 0 || G * (j - 1) + MINZ_WL <= R; j++) {
     const int q = G * j + gl;
@@ -540,7 +540,7 @@ __device__ __forceinline__ void minz_mc(GLds<NQ> &S, int R, int gl) {
     MC_DPP_MIN(sfx, 0x101); MC_DPP_MIN(sfx, 0x102); MC_DPP_MIN(sfx, 0x104); MC_DPP_MIN(sfx, 0x108);  // row_shl:1,2,4,8
 #undef MC_DPP_MIN
     const int w = G * (j - 1) + gl;
-    if (j > 0 && w + MINZ_WL <= R && w < GLds<NQ>::MZ) S.mz[w] = fmix32(min(sfx_prev, pfx));
+    if (j > 0 && w + MINZ_WL <= R && w < GLds<NQ, KA>::MZ) S.mz[w] = fmix32(min(sfx_prev, pfx));
     sfx_prev = sfx;
   }
 }
@@ -548,10 +548,10 @@ __device__ __forceinline__ void minz_mc(GLds<NQ> &S, int R, int gl) {
 // probes with priority codes [c_lo, c_hi) (code = shift << 2 | rev << 1 | dict; at most 4 * G of them): lane gl takes
 // codes c_lo + gl + 16 i, fetches the tag quads of all of them first, and only walks into eval_probe where the
 // quad does not already prove the key absent (2 % of the probes).  Winner = lowest code that hit.
-template <int NQ>
-__device__ __forceinline__ void batch_mc(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, int c_lo, int c_hi, int ref_len,
+template <int NQ, bool KA>
+__device__ __forceinline__ void batch_mc(const DevParams &P, GLds<NQ, KA> &S, lds_u32_t *stage, int c_lo, int c_hi, int ref_len,
                                          int lane, int gl, int &wcode, uint32_t &wrid) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD;
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD;
   const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
   const bool minz = P.tab.minz != 0;
   const int klen2 = 2 * P.wl;
@@ -668,10 +668,10 @@ __device__ __forceinline__ void batch_mc(const DevParams &P, GLds<NQ> &S, lds_u3
 }
 
 // every remaining probe (shifts [t0, maxshift)), one table fetch per distinct consensus window (see probe_tail)
-template <int NQ>
-__device__ __forceinline__ void tail_mc(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, int t0, int ref_len, int lane, int gl,
+template <int NQ, bool KA>
+__device__ __forceinline__ void tail_mc(const DevParams &P, GLds<NQ, KA> &S, lds_u32_t *stage, int t0, int ref_len, int lane, int gl,
                                         int &wcode, uint32_t &wrid) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD;
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD;
   const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
   const bool minz = P.tab.minz != 0;
   const int wl = P.wl, s0 = P.dstart[0], s1 = P.dstart[1], ms = P.maxshift;
@@ -859,9 +859,9 @@ __device__ __forceinline__ void ka_valid_shifts(const DevParams &P, int l, int r
   hi = min(P.maxshift, rev ? ds : ref_len - de);
 }
 // need bits of part 1 (bits 0..7) for this lane
-template <int NQ>
-__device__ __forceinline__ uint32_t ka_need1(const DevParams &P, GLds<NQ> &S, int ref_len, int gl) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD;
+template <int NQ, bool KA>
+__device__ __forceinline__ uint32_t ka_need1(const DevParams &P, GLds<NQ, KA> &S, int ref_len, int gl) {
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD;
   const int l = gl & 1, rev = (gl >> 1) & 1, r = gl >> 2;
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   int lo, hi;
@@ -873,9 +873,9 @@ __device__ __forceinline__ uint32_t ka_need1(const DevParams &P, GLds<NQ> &S, in
   return valid & ~known;
 }
 // need bits of part 2 (second = false: the streams that fetch) or part 3 (second = true: the streams that ride along), at bit 0
-template <int NQ>
-__device__ __forceinline__ uint32_t ka_need2(const DevParams &P, GLds<NQ> &S, int ref_len, int gl, bool second) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD;
+template <int NQ, bool KA>
+__device__ __forceinline__ uint32_t ka_need2(const DevParams &P, GLds<NQ, KA> &S, int ref_len, int gl, bool second) {
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD;
   const int rev = gl & 1, l = second ? rev : 1 - rev, r = gl >> 1;
   const int ds = l ? uni_i32(P.dstart[1]) : uni_i32(P.dstart[0]);
   int lo, hi;
@@ -904,22 +904,25 @@ __device__ __forceinline__ uint32_t ka_keep_below(int cur, int gl, int wl) {
 }
 
 // one batch: up to m <= 4 of this lane's needed codes (lowest first) -- tag quads, verdict on the tags, closer looks
-template <int NQ>
-__device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, uint32_t &need, int m, int ref_len,
+#ifndef SR_KA_M
+#define SR_KA_M 4
+#endif
+constexpr int KA_M = SR_KA_M;  // probes a lane has in flight per batch (registers: 8 per probe)
+template <int NQ, bool KA>
+__device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ, KA> &S, lds_u32_t *stage, uint32_t &need, int m, int ref_len,
                                          int lane, int gl, int &best, uint32_t &brid) {
-  constexpr int LDS_PAD = GLds<NQ>::PAD;
+  constexpr int LDS_PAD = GLds<NQ, KA>::PAD;
   const uint64_t *sref = S.refs[0] + LDS_PAD, *srev = S.refs[1] + LDS_PAD;
-  const bool minz = P.tab.minz != 0;
   const int wl = P.wl, klen2 = 2 * wl;
   const uint64_t kmask = klen2 < 64 ? ((1ull << klen2) - 1) : ~0ull;
   lds_u32_t *s_best = (lds_u32_t *)&S.best;
   const uint32_t bmask = (uint32_t)bucket_mask(P.tab.bshift);
-  uint4 tg[4];
-  uint64_t key[4];
-  uint32_t bk[4];
-  int code[4];
+  uint4 tg[KA_M];
+  uint64_t key[KA_M];
+  uint32_t bk[KA_M];
+  int code[KA_M];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < KA_M; i++) {
     code[i] = -1;
     key[i] = 0;
     bk[i] = 0;
@@ -933,17 +936,16 @@ __device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u3
       const int ds = l ? P.dstart[1] : P.dstart[0];
       const int o = rev ? ds - shift : ds + shift;  // the window's offset in its strand
       key[i] = lds_window(rev ? srev : sref, 2 * o) & kmask;
-      bk[i] = (uint32_t)tab_home(P.tab, mix64(key[i]), minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u);
+      bk[i] = (uint32_t)bucket_of(mix64(key[i]), P.tab.bshift);  // (hash-addressed tables only: DevParams::ka)
       tg[i] = P.tab.buck[2 * (uint64_t)bk[i]];
     }
   }
   // verdict on the tags alone (batch_mc): pend = a slot with the key's fingerprint, cont = the bucket is full without
   // one (the chain goes on), oth = the other dictionary may hold the window's key; pre as in batch_mc
-  uint32_t pend = 0, cont = 0, redir = 0, oth = 0, pre = 0;
+  uint32_t pend = 0, cont = 0, oth = 0, pre = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < KA_M; i++) {
     if (code[i] < 0) continue;
-    if (minz && tg[i].x == TAG_MARK) { cont |= 1u << i; redir |= 1u << i; continue; }
     bool other = false;
     int slot = 0;
     const int st = tags_step(tg[i], mix64(key[i]), code[i] & 1, other, slot);
@@ -953,16 +955,15 @@ __device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u3
   }
   for (int hop = 0; hop < QUICK_HOPS && __ballot(cont != 0); hop++) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < KA_M; i++)
       if ((cont >> i) & 1u) {
-        bk[i] = ((redir >> i) & 1u) ? (uint32_t)tab_redirect(P.tab, mix64(key[i])) : ((bk[i] + 1u) & bmask);
+        bk[i] = (bk[i] + 1u) & bmask;
         tg[i] = P.tab.buck[2 * (uint64_t)bk[i]];
       }
-    redir = 0;
     const uint32_t c2 = cont;
     cont = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < KA_M; i++)
       if ((c2 >> i) & 1u) {
         bool other = false;
         int slot = 0;
@@ -976,7 +977,7 @@ __device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u3
   oth |= cont;
   // what the tags have proven absent: this code's dictionary (no slot of the key, the chain ended) and / or the other one
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < KA_M; i++) {
     if (code[i] < 0) continue;
     const int cd = code[i], l = cd & 1, rev = (cd >> 1) & 1, shift = cd >> 2;
     const uint32_t own = ((pend >> i) & 1u) ^ 1u, other = ((oth >> i) & 1u) ^ 1u;
@@ -993,7 +994,9 @@ __device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u3
     if (pend) {
       const int i = __ffs((int)pend) - 1;
       pend &= pend - 1;
-      const int cd = i == 0 ? code[0] : i == 1 ? code[1] : i == 2 ? code[2] : code[3];
+      int cd = code[0];
+#pragma unroll
+      for (int q = 1; q < KA_M; q++) cd = i == q ? code[q] : cd;
       const int l = cd & 1, rev = (cd >> 1) & 1, shift = cd >> 2;
       if (cd < best && !(*(volatile lds_u32_t *)s_best < (uint32_t)cd)) {
         bool hit = false, keyok = false, other = false;
@@ -1001,7 +1004,7 @@ __device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u3
         const int ds = l ? P.dstart[1] : P.dstart[0], o = rev ? ds - shift : ds + shift;
         const uint64_t k = lds_window(rev ? srev : sref, 2 * o) & kmask;
         eval_probe<false, false, false, true>(P, rev ? srev : sref, l, rev, shift, ref_len, k, mix64(k),
-                                       minz ? S.mz[rev ? ref_len - MINZ_WL - o : o] : 0u, hit, rid, keyok, ncand, other, s_best, stage,
+                                       0u, hit, rid, keyok, ncand, other, s_best, stage,
                                        lane, nullptr, nullptr, (int)((pre >> (4 * i)) & 15u));
         if (hit) { best = cd; brid = rid; }
       }
@@ -1009,27 +1012,27 @@ __device__ __forceinline__ void batch_ka(const DevParams &P, GLds<NQ> &S, lds_u3
   }
 }
 
-template <int NQ>
-__device__ __forceinline__ void search_ka(const DevParams &P, GLds<NQ> &S, lds_u32_t *stage, int ref_len, int wide, int lane, int gl,
+template <int NQ, bool KA>
+__device__ __forceinline__ void search_ka(const DevParams &P, GLds<NQ, KA> &S, lds_u32_t *stage, int ref_len, int wide, int lane, int gl,
                                           int &wcode, uint32_t &wrid) {
   lds_u32_t *s_best = (lds_u32_t *)&S.best;
   if (gl == 0) *s_best = (uint32_t)INF_CODE;
   wave_sync();
   const int wl = P.wl;
-  uint32_t need = ka_need1<NQ>(P, S, ref_len, gl) | (ka_need2<NQ>(P, S, ref_len, gl, false) << 8);
+  uint32_t need = ka_need1<NQ, KA>(P, S, ref_len, gl) | (ka_need2<NQ, KA>(P, S, ref_len, gl, false) << 8);
   int best = INF_CODE;
   uint32_t brid = 0;
   for (int b = 0; __ballot(need != 0); b++) {
     const int w = b < 6 ? (wide ? P.plan[1][b] : P.plan[0][b]) : 0;
-    const int m = w > 0 ? min(4, (w + 3) >> 2) : 4;
-    batch_ka<NQ>(P, S, stage, need, m, ref_len, lane, gl, best, brid);
+    const int m = w > 0 ? min(KA_M, (w + 3) >> 2) : KA_M;
+    batch_ka<NQ, KA>(P, S, stage, need, m, ref_len, lane, gl, best, brid);
     need &= ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
   }
   wave_sync();  // ka
   if ((int)*(volatile lds_u32_t *)s_best > 4 * wl) {  // the codes that rode along: only where a window is still not known absent
-    need = (ka_need2<NQ>(P, S, ref_len, gl, true) << 16) & ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
+    need = (ka_need2<NQ, KA>(P, S, ref_len, gl, true) << 16) & ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
     while (__ballot(need != 0)) {
-      batch_ka<NQ>(P, S, stage, need, 4, ref_len, lane, gl, best, brid);
+      batch_ka<NQ, KA>(P, S, stage, need, KA_M, ref_len, lane, gl, best, brid);
       need &= ka_keep_below((int)*(volatile lds_u32_t *)s_best, gl, wl);
     }
   }
@@ -1040,7 +1043,7 @@ __device__ __forceinline__ void search_ka(const DevParams &P, GLds<NQ> &S, lds_u
 
 // phase A of one chain (search_step: proposal word + direct reservation of the read)
 template <int NQ, bool MG, bool KA>
-__device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds<NQ> &S, lds_u32_t *stage,
+__device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t cid, ChainHot &h, GLds<NQ, KA> &S, lds_u32_t *stage,
                                           int lane, int gl) {
   if (h.mode == MODE_NEED_SEED) {
     bool is_last;
@@ -1078,22 +1081,22 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
   }
   const int ref_len = h.ref_len;
   const int wide = (h.prev_unmatched && P.seed_wide) ? 1 : 0;
-  if (P.tab.minz) minz_mc<NQ>(S, ref_len, gl);  // (batch_mc synchronises before it reads S.mz)
+  if (!KA && P.tab.minz) minz_mc<NQ, KA>(S, ref_len, gl);  // (batch_mc synchronises before it reads S.mz)
   PT(18);
   int wcode = INF_CODE, t0 = 0;
   uint32_t wrid = 0;
-  if constexpr (KA) search_ka<NQ>(P, S, stage, ref_len, wide, lane, gl, wcode, wrid);
+  if constexpr (KA) search_ka<NQ, KA>(P, S, stage, ref_len, wide, lane, gl, wcode, wrid);
   else for (int ph = 0; ph < 6 && t0 < P.maxshift; ph++) {
     const int w = wide ? P.plan[1][ph] : P.plan[0][ph];
     if (w <= 0) break;
-    batch_mc<NQ>(P, S, stage, 4 * t0, 4 * (t0 + w), ref_len, lane, gl, wcode, wrid);
+    batch_mc<NQ, KA>(P, S, stage, 4 * t0, 4 * (t0 + w), ref_len, lane, gl, wcode, wrid);
     if (ph == 0) PT(19); else if (ph == 1) PT(20); else PT(21);
     t0 += w;
     if (wcode != INF_CODE) break;
   }
   if (!KA && wcode == INF_CODE && t0 < P.maxshift) {
     wave_sync();  // pres
-    tail_mc<NQ>(P, S, stage, t0, ref_len, lane, gl, wcode, wrid);
+    tail_mc<NQ, KA>(P, S, stage, t0, ref_len, lane, gl, wcode, wrid);
     PT(22);
   }
   if (wcode != INF_CODE) {
@@ -1122,7 +1125,7 @@ __device__ __forceinline__ void search_mc(const DevParams &P, Chain *c, uint32_t
 template <int NQ, bool MG, bool KA>
 __device__ __forceinline__ void round_mc_body(const DevParams &P) {
   static_assert(!KA || NQ <= 3, "known-absent masks: reads up to 192 bases (the spare half of Chain::revref)");
-  typedef mc::GLds<NQ> GL;
+  typedef mc::GLds<NQ, KA> GL;
   __shared__ GL s_g[mc::CPW];
   __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];  // candidate limbs, one row per lane (cmp_candidate)
   const int lane = threadIdx.x, g = lane >> 4, gl = lane & (mc::G - 1);

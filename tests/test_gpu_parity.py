@@ -416,7 +416,7 @@ def test_single_pool_1M_4_virtual_ranks():
                                 dict(first_shifts=3, seed_wide=-1, tab_scale=1, search_wpb=4, fused=-1),
                                 dict(table_mode=1, tab_scale=4), dict(plan0=(4, 4, 8, 16)), dict(plan0=(16,), plan1=(2, 2, 4), fused=3),
                                 dict(plan0=(1, 1, 2, 4, 8, 16), deep_bins=1), dict(long_min=64, long_blocks=7, long_budget=2, deep_bins=1),
-                                dict(deep_bins=1, entry_flags=-1)])
+                                dict(deep_bins=1, entry_flags=-1), dict(known_absent=-1, fused=3, deep_bins=-1)])
 @pytest.mark.parametrize("name,K,T", [("syn5k_150", 64, 3), ("var2k", 7, 2), ("heavy", 16, 1), ("tandem", 32, 2)])
 def test_tuning_opts_do_not_change_results(name, K, T, kw):
     """Every tuning / experiment field of spring_reorder_opts at a non-default value: same streams, same per-tid
@@ -430,6 +430,39 @@ def test_tuning_opts_do_not_change_results(name, K, T, kw):
     assert np.array_equal(got["tid_off"], want["tid_off"])
     for k in ("probes", "keyok", "cands", "hits", "unmatched"):
         assert got["stats"][k] == want["stats"][k], (k, kw)
+
+
+@pytest.mark.parametrize("name", ["syn5k_150", "syn2k_100", "syn3k_64", "syn2k_20", "var2k", "var_short", "heavy", "tandem", "repeat10k", "dups", "test_1+2"])
+@pytest.mark.parametrize("K,T", [(1, 1), (32, 2), (300, 3)])
+def test_known_absent_windows_do_not_change_results(name, K, T):
+    """The four-chain round kernel with and without the chains' known-absent window masks (opts.known_absent; reads up to
+    192 bases: fixed and variable length, windows of 32 bases and shorter, lone seeds that turn round, contended pools where
+    most proposals are lost and the search is repeated): the same streams as the rounds oracle either way -- a skipped probe
+    is one whose answer was "absent" (the table never changes)."""
+    dna, n, L = named_set(name)
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_serial(read, ln, L) if K == 1 else po.reorder_rounds(read, ln, L, K, T)
+    for ka in (0, -1):
+        _same(_gpu(name, K, T, fused=3, deep_bins=-1, known_absent=ka), want, (name, K, ka))
+
+
+@pytest.mark.parametrize("L", [101, 127, 128, 160, 191, 192])
+def test_known_absent_windows_read_lengths(L):
+    """... at the read lengths where the masks' place in the chain record moves (the forward strand's four limbs start at
+    limb dstart[0] / 32) and at the longest reads the kernel takes: fixed-length pools and the same reads cut to random
+    lengths (the reverse cases of updaterefcount, reorder.h:157-200, move the masks by other amounts than the shift)."""
+    sa = _sa()
+    n = 4000
+    a = rs.np_reads(500 + L, n * L // 25, n, L, 0.01)
+    rng = np.random.default_rng(L)
+    cut = [bytes(r[:int(k)]) for r, k in zip(a, rng.integers(L // 2, L + 1, n))]
+    cut[0] = bytes(a[0])  # (the pool's maximum read length stays L)
+    for dna in (rs.pack_fixed(a), rs.pack_var(cut)):
+        read, ln = po.load_dna(dna, n, L)
+        want = po.reorder_rounds(read, ln, L, 48, 2)
+        for ka in (0, -1):
+            got = sa.reorder_dna(dna, n, L, sa.ReorderOpts(num_chains=48, num_thr=2, fused=3, deep_bins=-1, known_absent=ka))
+            _same(got, want, (L, ka))
 
 
 @pytest.mark.parametrize("n,L,G,K", [(60_000, 100, 300, 256), (40_000, 150, 2_000, 500), (30_000, 150, 400, 37)])

@@ -18,7 +18,7 @@ def main():
     G = max(n * L // cov, 2 * L)
     for spec in sys.argv[2:]:
         name, _, kv = spec.partition("=")
-        kw = {k: int(v) for k, v in (p.split(":") for p in kv.split(",") if p)}
+        kw = {k: (tuple(int(x) for x in v.split("/")) if "/" in v else int(v)) for k, v in (p.split(":") for p in kv.split(",") if p)}  # plan0:4/8/16
         best = None
         for it in range(3):
             with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=K, num_thr=8, time_search=(it == 2), **kw)) as s:
