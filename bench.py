@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--err-ppm", type=int, default=10000)
     ap.add_argument("--chains", type=int, default=0, help="0 = library default")
     ap.add_argument("--num-thr", type=int, default=8, help="per-tid output sets (reference default -t 8)")
-    ap.add_argument("--cpu-sample", type=int, default=32_000_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000,
+                    help="reads in the CPU-baseline sample (0 = skip); the default is the whole workload (~105 s at 32 threads)")
+    ap.add_argument("--cpu-files-sample", type=int, default=16_000_000, help="reads in the CPU twin of stage_incl_files")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(32, cpus))")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--lanes", action="store_true",
@@ -57,6 +59,8 @@ def parse():
                          "ncclAllGather on a single-GPU box")
     ap.add_argument("--sweep-sample", type=int, default=20_000_000,
                     help="reads per pool of the coverage_sweep leg (deep-coverage / contended pools, library defaults; 0 = skip)")
+    ap.add_argument("--choice-sample", type=int, default=20_000_000,
+                    help="reads in the pools of compression_cost.output_changing_choices (0 = skip)")
     ap.add_argument("--files-sample", type=int, default=100_000_000,
                     help="reads in the file-contract leg (stage_incl_files): the whole workload by default; 0 = skip")
     return ap.parse_args()
@@ -79,9 +83,13 @@ def algorithmic_bytes_apply(st):
 def compression_cost(spring_amd, a, dev, reads_per_chain, phases=1):
     """bits per base of the reorder + encoder output after BSC (the reference's, oracle/_ref/ref_bsc) for K = default
     and K = num_thr on a sample with the workload's coverage and error rate (encoder.cpp:111-156 is where SPRING
-    hands these streams to BSC)."""
+    hands these streams to BSC); one chain group against two on the headline's pool; and `output_changing_choices`: the
+    four cells {one group, two groups} x {one candidate per proposal, two} on the pools where the library makes those
+    choices from the dictionary (6 400x, PhiX-like, genome-like), at the library's chain count.  The BSC processes of
+    all cells run side by side on the host's cores while the GPU runs the next cell."""
     import subprocess
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     import numpy as np
     from oracle import pyoracle as po
     from spring_amd.encoder import EncoderStage
@@ -89,6 +97,7 @@ def compression_cost(spring_amd, a, dev, reads_per_chain, phases=1):
     if not bsc_bin:
         return {"error": "oracle/_ref/ref_bsc is not built (make -C oracle ref, needs the reference sources)"}
     n, L = a.cost_sample, a.readlen
+    pool = ThreadPoolExecutor(max_workers=max(4, min(48, (os.cpu_count() or 8) // 4)))
 
     def bsc(b):
         if not len(b):
@@ -99,10 +108,11 @@ def compression_cost(spring_amd, a, dev, reads_per_chain, phases=1):
             subprocess.run([bsc_bin, fi, fo], check=True, stdout=subprocess.DEVNULL)
             return os.path.getsize(fo)
 
-    def sized(n, K, **kw):
-        G = max(n * L // a.coverage, 2 * L)
+    def sized(n, K, G=None, flags=0, **kw):
+        """-> a cell whose "bytes" is still a list of futures (finish() turns it into the sum)"""
+        G = G or max(n * L // a.coverage, 2 * L)
         with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=dev, num_chains=K, num_thr=1, **kw)) as st:
-            st.load_synth(n, L, G, 5, a.err_ppm)
+            st.load_synth(n, L, G, 5, a.err_ppm | flags)
             st.run()
             sst = st.stats()
             with EncoderStage(dev) as enc:
@@ -110,27 +120,72 @@ def compression_cost(spring_amd, a, dev, reads_per_chain, phases=1):
                 e = enc.streams()
                 packed, _ = enc.seq_packed()
         dpos = np.diff(e["pos"].astype(np.int64), prepend=0).astype(np.int32)
-        tot = (bsc(packed) + bsc(dpos.tobytes()) + bsc(bytes(e["noise"])) + bsc(e["noisepos"].tobytes())
-               + bsc(e["rc"].tobytes()) + bsc(bytes(e["unaligned"])))
-        return {"chains": int(sst["chains"]), "chain_groups": int(sst.get("phases", 1)), "contigs": int(info["num_contigs"]), "bytes": int(tot),
-                "bits_per_base": round(tot * 8.0 / (n * L), 4), "chains_stage_ms": round(sst["ms_chains"], 1)}
+        futs = [pool.submit(bsc, b) for b in (packed, dpos.tobytes(), bytes(e["noise"]), e["noisepos"].tobytes(), e["rc"].tobytes(), bytes(e["unaligned"]))]
+        return {"chains": int(sst["chains"]), "chain_groups": int(sst.get("phases", 1)), "candidates_per_proposal": int(sst.get("alternatives", 1)),
+                "contigs": int(info["num_contigs"]), "bytes": futs, "reads": n, "chains_stage_ms": round(sst["ms_chains"], 1)}
+
+    def finish(c):
+        if isinstance(c, dict) and isinstance(c.get("bytes"), list):
+            tot = sum(f.result() for f in c["bytes"])
+            c["bytes"] = int(tot)
+            c["bits_per_base"] = round(tot * 8.0 / (c.pop("reads") * L), 4)
+        return c
 
     # the sample runs at the headline run's reads per chain (the default is capped at 65 536 chains: 1 526 reads per
     # chain at 100 M reads; a 4 M-read sample left to the default rule would run at 1 024 and overstate the cost)
     k_same = max(1, int(round(n / max(reads_per_chain, 1.0))))
     d, r = sized(n, k_same, phases=1), sized(n, a.num_thr)
-    out = {"sample_reads": n, "read_len": L, "coverage": a.coverage, "default_chains": d, "reference_granularity": r,
-           "size_ratio_default_vs_num_thr": round(d["bytes"] / r["bytes"], 4),
-           "what": "read streams (consensus, positions, noise, noise positions, orientation, unaligned) after the reference's "
-                   "BSC; reads per chain %d (as in the headline run) vs %d (K = num_thr = %d)" % (n // max(d["chains"], 1), n // max(r["chains"], 1), a.num_thr)}
+    g1 = g2 = None
     if phases == 2:
         # the headline run's schedule (two chain groups) needs 4 096 chains: a larger sample at the same reads per chain,
         # one group against two (the K = num_thr run above would take a minute on it)
         n2 = max(n, int(4200 * reads_per_chain))
         k2 = max(4096, int(round(n2 / max(reads_per_chain, 1.0))))
         g1, g2 = sized(n2, k2, phases=1), sized(n2, k2, phases=2)
+    # where the library itself chooses the schedule (two groups at the cap of 131 072 chains on deep pools) and the number
+    # of candidates per proposal (two on contended pools): all four cells on each of those pools, library's chain count
+    cells = []
+    if a.choice_sample > 0:
+        ns = a.choice_sample
+        for name, pn, flags, pG in (("6400x", ns, 0, max(ns * L // 6400, 4 * L)), ("PhiX-like", ns // 2, 0, 5400),
+                                    ("genome-like 25x", ns, 0x20000000, max(ns * L // 25, 4 * L))):
+            row = {"pool": name, "reads": pn}
+            try:
+                row["library_choice"] = sized(pn, 0, G=pG, flags=flags)
+                kk = row["library_choice"]["chains"]
+                for ph in (1, 2):
+                    for al in (1, 2):
+                        try:
+                            row["groups_%d_candidates_%d" % (ph, al)] = sized(pn, kk, G=pG, flags=flags, phases=ph, alternatives=al)
+                        except Exception as e:  # noqa: BLE001  (a combination the library refuses on this pool)
+                            row["groups_%d_candidates_%d" % (ph, al)] = {"refused": str(e)[:160]}
+            except Exception as e:  # noqa: BLE001
+                row["error"] = repr(e)
+            cells.append(row)
+    d, r = finish(d), finish(r)
+    out = {"sample_reads": n, "read_len": L, "coverage": a.coverage, "default_chains": d, "reference_granularity": r,
+           "size_ratio_default_vs_num_thr": round(d["bytes"] / r["bytes"], 4),
+           "what": "read streams (consensus, positions, noise, noise positions, orientation, unaligned) after the reference's "
+                   "BSC; reads per chain %d (as in the headline run) vs %d (K = num_thr = %d)" % (n // max(d["chains"], 1), n // max(r["chains"], 1), a.num_thr)}
+    if g1 is not None:
+        g1, g2 = finish(g1), finish(g2)
         out["two_chain_groups"] = {"sample_reads": n2, "one_group": g1, "two_groups": g2,
                                    "size_ratio_two_groups_vs_one": round(g2["bytes"] / g1["bytes"], 4)}
+    for row in cells:
+        for k in list(row):
+            finish(row[k])
+        base = row.get("groups_1_candidates_1")
+        if isinstance(base, dict) and base.get("bytes"):
+            row["size_ratio_vs_one_group_one_candidate"] = {k[7:]: round(v["bytes"] / base["bytes"], 4) for k, v in row.items()
+                                                            if k.startswith("groups_") and isinstance(v, dict) and v.get("bytes")}
+            lc = row.get("library_choice")
+            if isinstance(lc, dict) and lc.get("bytes"):
+                row["size_ratio_library_choice"] = round(lc["bytes"] / base["bytes"], 4)
+    if cells:
+        out["output_changing_choices"] = {"pools": cells, "what": "the same read streams after the reference's BSC for {one chain group, two} x {one candidate "
+                                          "per proposal, two} at the chain count the library picks for the pool; library_choice = what "
+                                          "opts.phases = 0, opts.alternatives = 0 run (chain_groups / candidates_per_proposal say which cell that is)"}
+    pool.shutdown()
     return out
 
 
@@ -175,6 +230,20 @@ def roofline_block(alg_bytes, kernel_ms, launches, traffic, busy_ms=None):
                                "concurrent_launches: launches of this kernel overlap (two chain groups on two streams), busy_ms is "
                                "the union of the launches' intervals from the same HIP events"
                                if busy > 0 and kernel_ms / busy > 1.01 else "algorithmic_bytes_per_launch / avg_launch_us")}
+
+
+def physical_cores():
+    """distinct (socket, core) pairs of /proc/cpuinfo (None when the file does not say)"""
+    try:
+        seen, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((phys, ln.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 def kernels_sha():
@@ -393,7 +462,18 @@ def main():
         except Exception:
             req = None
         out["roofline"] = roofline_block(alg, ms, launches, traffic, busy)
+        pmc_fields = ["traffic", "random_request_ceiling", "valu_issue_frac", "l1_requests_per_chain_round", "l1_request_latency_clocks",
+                      "l1_requests_in_flight_per_cu", "insts_per_wavefront", "hbm_write_bytes_per_launch"]
         out["roofline"].update({
+            # where each field comes from: the PMC-derived ones are REPLAYED from the committed summary of builder-side
+            # rocprofv3 --pmc passes over this same command (rocprofv3 cannot run inside this process), accepted only when
+            # the summary's kernel-source hash equals the hash of the kernels this run executes; everything else is measured here
+            "traffic_source": ("profiles/pmc_latest.json -- builder-side rocprofv3 --pmc passes (tools/pmc_probe.sh, separate runs per "
+                               "counter group, kernels serialised by the collection), kernels_sha %s; replayed, not measured in this run"
+                               % kernels_sha()) if traffic is not None else "none (no PMC summary for these kernels / this workload)",
+            "pmc_derived_fields": pmc_fields,
+            "measured_in_this_run": ["achieved", "frac", "avg_launch_us", "busy_ms", "launches", "concurrent_launches",
+                                     "algorithmic_bytes_per_launch", "work", "search_kernel_alone"],
             "traffic_kernels_sha": kernels_sha(),
             "kernel": "sr::k_round_mc (four chains per wavefront: apply of the last proposal + Hamming search)"
                       + ("; two chain groups: a launch covers half of the chains and runs beside the other group's launch" if phases == 2 else ""),
@@ -560,14 +640,14 @@ def main():
         tm = time.perf_counter() - t0
         ph_dict, ph_chains = po.last_omp_phases()
         # the reference's default thread count (-t 8, main.cpp:70) on a quarter of the sample
-        ns8 = min(max(ns // 8, 200_000), ns)
+        ns8 = min(max(min(ns, 32_000_000) // 8, 200_000), ns)
         dna8 = sample(ns8)
         t0 = time.perf_counter()
         read8, ln8 = po.load_dna(dna8, ns8, L)
         po.reorder_omp(read8, ln8, L, 8)
         t8 = time.perf_counter() - t0
         del read8, ln8, dna8
-        ns1 = min(max(ns // 16, 200_000), ns)
+        ns1 = min(max(min(ns, 32_000_000) // 32, 200_000), ns)
         dna1 = sample(ns1)
         t0 = time.perf_counter()
         read1, ln1 = po.load_dna(dna1, ns1, L)
@@ -575,18 +655,18 @@ def main():
         t1 = time.perf_counter() - t0
         out["cpu_baseline"] = {
             "value": round(ns / tm / 1e6, 4), "unit": "Mreads/s", "cores": T, "kind": "port",
-            "sample": "%d x %d bp reads, same generator/coverage/error rate; C port of the reference with %d "
+            "sample": ("the whole workload: " if ns == n else "") + "%d x %d bp reads, same generator/coverage/error rate; C port of the reference with %d "
                       "free-running OpenMP threads (load + dictionaries + reorder), %.1f s" % (ns, L, T, tm),
             "phases_s": {"dictionaries": round(ph_dict, 2), "chains": round(ph_chains, 2)},
             "chains_only_value": round(ns / ph_chains / 1e6, 4) if ph_chains > 0 else None,
             "threads_8": {"value": round(ns8 / t8 / 1e6, 4), "sample_reads": ns8, "seconds": round(t8, 1)},
             "single_thread": {"value": round(ns1 / t1 / 1e6, 4), "sample_reads": ns1, "seconds": round(t1, 1)},
-            "host_cpus": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
         }
         # the same port on a genome-like pool (SPRING_SYNTH_GENOMIC: repeat families, tandem repeats; coverage_sweep has the
         # GPU's figure): what realistic repeat structure costs the CPU algorithm
         try:
-            nsg = min(max(ns // 4, 200_000), ns)  # (large enough for the repeat families to make deep bins: the cost grows with the pool)
+            nsg = min(max(min(ns, 32_000_000) // 4, 200_000), ns)  # (large enough for the repeat families to make deep bins: the cost grows with the pool)
             Gg = max(nsg * L // a.coverage, 2 * L)
             bg = torch.empty(L_.spring_synth_dna_bytes(nsg, L), dtype=torch.uint8, device="cuda")
             assert L_.spring_synth_dna_device(C.c_void_p(bg.data_ptr()), nsg, L, Gg, 11, a.err_ppm | 0x20000000) == 0
@@ -608,13 +688,14 @@ def main():
             import tempfile
             td = tempfile.mkdtemp(prefix="spring_bench_cpu_")
             fn = os.path.join(td, "input_clean_1.dna")
+            nsf = min(a.cpu_files_sample, ns)
             with open(fn, "wb") as f:
-                f.write(dna)
+                f.write(dna[:L_.spring_synth_dna_bytes(nsf, L)])  # (fixed-length records: the first nsf reads of the sample)
             os.sync()
             t0 = time.perf_counter()
             raw = np.fromfile(fn, np.uint8).tobytes()
             os.remove(fn)
-            readf, lnf = po.load_dna(raw, ns, L)
+            readf, lnf = po.load_dna(raw, nsf, L)
             res = po.reorder_omp(readf, lnf, L, T)
             toff = res["tid_off"]
             for t in range(len(toff) - 1):
@@ -629,10 +710,10 @@ def main():
             res["order_s"].tofile(os.path.join(td, "read_order.bin.singleton"))
             tf = time.perf_counter() - t0
             shutil.rmtree(td, ignore_errors=True)
-            out["cpu_baseline"]["stage_incl_files_value"] = round(ns / tf / 1e6, 4)
+            out["cpu_baseline"]["stage_incl_files_value"] = round(nsf / tf / 1e6, 4)
             out["cpu_baseline"]["stage_incl_files_what"] = (
-                "the same port and sample through the reference's span: read + delete input_clean_1.dna, load, dictionaries, "
-                "reorder at %d threads, write the per-tid and singleton files (uncompressed), %.1f s" % (T, tf))
+                "the same port on the first %d reads of the sample through the reference's span: read + delete input_clean_1.dna, load, "
+                "dictionaries, reorder at %d threads, write the per-tid and singleton files (uncompressed), %.1f s" % (nsf, T, tf))
             del res, readf, lnf, raw
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"]["stage_incl_files_value"] = None

@@ -280,6 +280,12 @@ int spring_reorder_get_stats(spring_reorder_ctx *ctx, spring_reorder_stats *st);
  * (concatenated in tid order) and read_order.bin.singleton.  Any pointer may be NULL. */
 int spring_reorder_download(spring_reorder_ctx *ctx, uint32_t *order, char *rc, char *flag, int64_t *pos,
                             uint16_t *rlen, uint32_t *order_s, uint64_t *tid_off, uint64_t *tid_off_s);
+/* A rank of a multi-GPU pool that ran the chains as two groups (stats.phases = 2) owns a slice of each group: inside tid t
+ * its records [tid_off[t], mid[t]) belong to chains of the first group, [mid[t], tid_off[t + 1]) to chains of the second
+ * (likewise mid_s for the singleton stream).  The merged tid-t stream of the pool -- chain ids ascending -- is every rank's
+ * first part, ranks ascending, then every rank's second part.  mid / mid_s: num_thr entries, either may be NULL.  With one
+ * group mid[t] = tid_off[t + 1]. */
+int spring_reorder_tid_split(spring_reorder_ctx *ctx, uint64_t *mid, uint64_t *mid_s);
 
 /* temp.dna.<tid> (tid >= 0) or temp.dna.singleton (tid = -1) byte stream, built
  * on the device (reverse complement + 2-bit repack, reorder.h:667-687,

@@ -13,7 +13,7 @@ EXPORTS = [
     "spring_reorder_mg_end", "spring_reorder_mg_exchange_virtual", "spring_reorder_debug_check_seed_state",
     "spring_mg_rccl_unique_id", "spring_mg_comm_create_rccl", "spring_mg_comm_create_host", "spring_mg_comm_destroy",
     "spring_reorder_mg_run",
-    "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_emit_dna",
+    "spring_reorder_get_stats", "spring_reorder_download", "spring_reorder_tid_split", "spring_reorder_emit_dna",
     "spring_reorder_dict_lookup", "spring_reorder_download_reads", "spring_synth_dna_bytes",
     "spring_reorder_load_fastq", "spring_reorder_fastq_N",
     "spring_order_invert_se", "spring_order_invert_pe", "spring_order_correct", "spring_order_pe_encode",
@@ -121,6 +121,7 @@ def lib():
     L.spring_reorder_mg_run.argtypes = [vp, vp, C.c_uint32]
     L.spring_reorder_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.spring_reorder_download.argtypes = [vp] + [vp] * 8
+    L.spring_reorder_tid_split.argtypes = [vp, vp, vp]
     L.spring_reorder_emit_dna.argtypes = [vp, C.c_int32, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.spring_reorder_dict_lookup.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp, vp, C.c_size_t]
     L.spring_reorder_download_reads.argtypes = [vp, vp, vp]

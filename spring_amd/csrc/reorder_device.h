@@ -200,12 +200,17 @@ struct DevParams {
   // group never reads what a launch of the other group that may run beside it writes, and the two round kernels fill each
   // other's drain.  Seeds: group 0 from reads [seed_lo, n) downwards, group 1 from [0, seed_lo of group 0).
   // A launch covers the chains [g0, g0 + Kg) (phases = 1: all of them).
+  // In a multi-GPU pool a rank owns a slice of EACH group (the groups are the same whatever the number of ranks): its local
+  // chains [g0, g0 + Kg) are the global chains [c0 + g0, c0 + g0 + Kg) -- c0 is per launch, so that `cid = c0 + li` holds in
+  // every kernel -- of the group's global range [gg0, gg0 + gKg) (one GPU: c0 = 0, gg0 = g0, gKg = Kg; one group: gg0 = 0,
+  // gKg = Ktot).  The mark step runs over the group's global range on every rank (replicated, as k_mg_mark does).
   int phases;
   uint32_t g0, Kg, g0_other, Kg_other;
+  uint32_t gg0, gKg, gKg_other;
   uint32_t seed_lo, seed_hi;   // this group's seeds are reads [seed_lo, seed_hi) (phases = 1: [0, n))
   uint32_t nb_lo, nb_hi;       // ... and its chains the blocks [nb_lo, nb_hi) of 2048 chains (needy_cnt)
   const uint64_t *taken_other; // the other group's view (k_ph_mark only)
-  uint32_t *won, *won_other;   // [Kg] / [Kg_other]: read a chain secured in its group's last mark step | kind << 31 (1: a match), 0xffffffff none
+  uint32_t *won, *won_other;   // [gKg] / [gKg_other]: read a chain secured in its group's last mark step | kind << 31 (1: a match), 0xffffffff none
   unsigned long long *prop;   // [Ktot] proposals of the round (multi-GPU mode only, else null)
   uint32_t *alive_wave;       // [ceil(Ktot / 64)] chains not done per 64 chains, rewritten every round by k_mg_mark
   Chain *chains;
@@ -255,7 +260,7 @@ void launch_dict_lookup(hipStream_t st, TabView tab, const ulonglong2 *urec, int
                         uint32_t *start, uint32_t *count);
 void launch_fill_u32(hipStream_t st, uint32_t *p, uint64_t n, uint32_t v);
 void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_t n, uint32_t *ublk);
-void launch_init_chains(hipStream_t st, const DevParams &P);
+void launch_init_chains(hipStream_t st, const DevParams &P, bool seeds = true);
 void launch_check_seed_state(hipStream_t st, const DevParams &P, uint64_t nwords, unsigned long long *bad);
 // two-kernel round (one GPU): search -> apply
 void launch_search(hipStream_t st, const DevParams &P, bool stats);

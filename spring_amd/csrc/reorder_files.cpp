@@ -795,11 +795,14 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
       OutFile f;
       f.path = base + "/" + name + "." + std::to_string(t);
       f.gz = gz;
-      for (int k = 0; k < world; k++) {
-        const sr::ReorderView &vk = v[(size_t)k];
-        const uint64_t a = vk.tid_off[t], c = vk.tid_off[t + 1] - a;
-        if (c) f.segs.push_back({vk.dev, vk.st, (const uint8_t *)ptr_of(vk) + a * elem, (size_t)(c * elem)});
-      }
+      // (chain ids ascending inside a tid: every rank's chains of the first chain group, then every rank's of the second --
+      // one part per rank unless the pool ran two groups, tid_mid)
+      for (int part = 0; part < 2; part++)
+        for (int k = 0; k < world; k++) {
+          const sr::ReorderView &vk = v[(size_t)k];
+          const uint64_t a = part ? vk.tid_mid[t] : vk.tid_off[t], c = (part ? vk.tid_off[t + 1] : vk.tid_mid[t]) - a;
+          if (c) f.segs.push_back({vk.dev, vk.st, (const uint8_t *)ptr_of(vk) + a * elem, (size_t)(c * elem)});
+        }
       files.push_back(std::move(f));
     };
     for (int t = 0; t < num_thr; t++) {  // all six files must exist for every tid (encoder.h:147-175)
@@ -810,13 +813,17 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
       stream_of(t, "read_lengths.bin", true, 2, [](const sr::ReorderView &x) { return (const void *)x.f_len; });
       OutFile f;
       f.path = base + "/temp.dna." + std::to_string(t);
+      std::vector<uint8_t *> dk((size_t)world, nullptr);
+      std::vector<size_t> nbk((size_t)world, 0), midk((size_t)world, 0);
       for (int k = 0; k < world; k++) {
-        uint8_t *d = nullptr;
-        size_t nb = 0;
-        if ((r = sr::emit_dna_device(g[(size_t)k].c, t, &d, &nb))) return r;
-        if (d) emitted.v.push_back({g[(size_t)k].c, d});
-        if (nb) f.segs.push_back({v[(size_t)k].dev, v[(size_t)k].st, d, nb});
+        if ((r = sr::emit_dna_device(g[(size_t)k].c, t, &dk[(size_t)k], &nbk[(size_t)k], 0, ~0ull, &midk[(size_t)k]))) return r;
+        if (dk[(size_t)k]) emitted.v.push_back({g[(size_t)k].c, dk[(size_t)k]});
       }
+      for (int part = 0; part < 2; part++)
+        for (int k = 0; k < world; k++) {
+          const size_t a = part ? midk[(size_t)k] : 0, c = (part ? nbk[(size_t)k] : midk[(size_t)k]) - a;
+          if (c) f.segs.push_back({v[(size_t)k].dev, v[(size_t)k].st, dk[(size_t)k] + a, c});
+        }
       files.push_back(std::move(f));
     }
     {  // reorder.h:699-728; the singleton streams are in tid order too (rank by rank inside a tid)
@@ -825,9 +832,10 @@ extern "C" int spring_reorder_run(const char *temp_dir, uint32_t max_readlen, in
       fo.path = base + "/read_order.bin.singleton";
       fc.path = base + "/temp.dna.singleton.count";
       for (int t = 0; t < num_thr; t++)
+        for (int part = 0; part < 2; part++)
         for (int k = 0; k < world; k++) {
           const sr::ReorderView &vk = v[(size_t)k];
-          const uint64_t a = vk.tid_off_s[t], c = vk.tid_off_s[t + 1] - a;
+          const uint64_t a = part ? vk.tid_mid_s[t] : vk.tid_off_s[t], c = (part ? vk.tid_off_s[t + 1] : vk.tid_mid_s[t]) - a;
           if (!c) continue;
           uint8_t *d = nullptr;
           size_t nb = 0;

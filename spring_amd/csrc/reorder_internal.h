@@ -25,6 +25,8 @@ struct ReorderView {
   const uint16_t *f_len;
   const uint64_t *tid_off;   // host, num_thr + 1
   const uint64_t *tid_off_s; // host, num_thr + 1: the singletons of tid t are f_order_s[tid_off_s[t] .. tid_off_s[t + 1])
+  const uint64_t *tid_mid, *tid_mid_s;  // host, num_thr: inside tid t, where the records of the second chain group's chains begin (a pool
+                                        // that runs two groups: the merge over ranks takes every rank's first part, then every second part)
   int num_thr;
   // reads with N of the two input files when the context was loaded through the FASTQ front end (device)
   const uint8_t *N_dna[2];
@@ -61,7 +63,7 @@ int load_dna_source(spring_reorder_ctx *ctx, const DnaSource &src, uint32_t n, u
 // *d_out is a pooled device buffer of *nbytes bytes that the caller hands back with emit_dna_free (null when empty).
 // tid = -1 with s_cnt != ~0: only singletons [s_first, s_first + s_cnt) (one tid's share, tid_off_s).
 int emit_dna_device(spring_reorder_ctx *ctx, int32_t tid, uint8_t **d_out, size_t *nbytes, uint64_t s_first = 0,
-                    uint64_t s_cnt = ~0ull);
+                    uint64_t s_cnt = ~0ull, size_t *mid_bytes = nullptr /* tid >= 0: byte offset of record tid_mid[tid] */);
 void emit_dna_free(spring_reorder_ctx *ctx, uint8_t *d);
 
 void mg_comm_abort(spring_mg_comm *c);  // a failed rank of an in-process pool unblocks its peers (ncclCommAbort)

@@ -797,8 +797,8 @@ template <int NP>
 __global__ __launch_bounds__(256) void k_init_chains(DevParams P) {
   __shared__ WaveLds lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t li = blockIdx.x * 4 + wave;
-  if (li >= P.K) return;
+  const uint32_t li = P.g0 + blockIdx.x * 4 + wave;  // (the launch's local chains [g0, g0 + Kg): all of them unless a pool runs two groups)
+  if (li >= P.g0 + P.Kg) return;
   const uint32_t cid = P.c0 + li;  // global chain id
   Chain *c = &P.chains[li];
   WaveLds *ws = &lds[wave];
@@ -2610,10 +2610,11 @@ __global__ __launch_bounds__(256) void k_long_fin(DevParams P, int direct) {
 
 // lowest chain id wins a contested read
 // (the OTHER ranks' words only: a rank settles its own proposals in its round kernel, as a single GPU does)
+// (the launch's group: global chains [gg0, gg0 + gKg) less this rank's slice [c0 + g0, c0 + g0 + Kg); one group: all of them)
 __global__ void k_mg_resolve(DevParams P) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P.Ktot - P.K) return;
-  const uint32_t cid = t < P.c0 ? t : t + P.K;
+  if (t >= P.gKg - P.Kg) return;
+  const uint32_t cid = P.gg0 + (t < P.c0 + P.g0 - P.gg0 ? t : t + P.Kg);
   const unsigned long long pv = P.prop[cid];
   const int pk = (int)(pv >> 32) & 7;
   if (pk == PK_MATCH || pk == PK_SEED) atomicMin(&P.resv[(uint32_t)pv], cid);
@@ -2724,8 +2725,8 @@ constexpr uint32_t RESV_LOST = 0xfffffffeu;
 __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
   constexpr int CPL = MARK_BLOCK / 64;  // chains per lane
   const int lane = threadIdx.x;
-  const uint32_t gend = P.g0 + P.Kg;
-  const uint32_t cbase = P.g0 + blockIdx.x * MARK_BLOCK;  // sub-block j holds chains cbase + 64 j + lane
+  const uint32_t gend = P.gg0 + P.gKg;  // (global chain ids: a multi-GPU pool runs this step over the whole group on every rank)
+  const uint32_t cbase = P.gg0 + blockIdx.x * MARK_BLOCK;  // sub-block j holds chains cbase + 64 j + lane
   unsigned long long pv[CPL];
   uint32_t rs[CPL];
   bool inr[CPL];
@@ -2750,7 +2751,7 @@ __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
     cls[j] = -1;
     if (inr[j]) {
       uint32_t wonv = 0xffffffffu;
-      if (alive) cls[j] = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv[j] & PK_WILLNEED_BIT) ? 3 : 0) : 3;
+      if (alive && cid - P.c0 - P.g0 < P.Kg) cls[j] = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv[j] & PK_WILLNEED_BIT) ? 3 : 0) : 3;  // (this rank's chains)
       if (pk == PK_MATCH || pk == PK_SEED) {
         uint32_t rid = (uint32_t)pv[j];
         bool won = rs[j] == cid;
@@ -2775,7 +2776,7 @@ __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
       } else if (pk == PK_NOSEED && (pv[j] & PK_CURSOR_BIT)) {
         *P.cursor = -1;
       }
-      P.won[cid - P.g0] = wonv;
+      P.won[cid - P.gg0] = wonv;
     }
     const uint64_t nb = __ballot(needy);
     const uint32_t na = (uint32_t)__popcll(__ballot(alive && inr[j]));
@@ -2788,7 +2789,7 @@ __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
     }
   }
   const uint32_t t = blockIdx.x * 64 + lane;  // (one thread per ...)
-  for (uint32_t j = t; j < P.Kg_other; j += gridDim.x * 64) {  // the other group's last winners: into this group's view
+  for (uint32_t j = t; j < P.gKg_other; j += gridDim.x * 64) {  // the other group's last winners: into this group's view
     const uint32_t w = P.won_other[j];
     if (w == 0xffffffffu) continue;
     const uint32_t rid = w & 0x7fffffffu;
@@ -2800,7 +2801,7 @@ __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
   if (P.longq && t < 2) P.lctl[t] = 0;
   if (t < P.nb_hi - P.nb_lo) P.needy_cnt[P.nb_lo + t] = 0;  // what this group's NEXT mark step accumulates into
   {  // class lists of this block's chains (k_round_mc; the order of k_mg_mark: class 0 first, chain ids ascending in a class)
-    const uint32_t segi = P.g0 / MARK_BLOCK + blockIdx.x;
+    const uint32_t segi = P.gg0 / MARK_BLOCK + blockIdx.x;
     uint32_t tot[4], base = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -2808,7 +2809,7 @@ __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
 #pragma unroll
       for (int j = 0; j < CPL; j++) {
         const uint64_t m = __ballot(cls[j] == k);
-        if (cls[j] == k) P.ord[(size_t)segi * MARK_BLOCK + run + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = cbase + 64 * j + lane;
+        if (cls[j] == k) P.ord[(size_t)segi * MARK_BLOCK + run + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = cbase + 64 * j + lane - P.c0;
         run += (uint32_t)__popcll(m);
       }
       tot[k] = run - base;
@@ -2823,7 +2824,7 @@ __global__ __launch_bounds__(64) void k_ph_mark(DevParams P) {
 // (100 M x 150 bp: chains stage 335 ms with this kernel, 353 with the one above) --, so shallow pools run this one.
 __global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t cid = P.g0 + t, gend = P.g0 + P.Kg;
+  const uint32_t cid = P.gg0 + t, gend = P.gg0 + P.gKg;  // (global chain ids, as in k_ph_mark)
   const int lane = threadIdx.x & 63;
   bool needy = false, alive = false;
   int cls = -1;
@@ -2832,7 +2833,7 @@ __global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
     const int pk = (int)(pv >> 32) & 7;
     uint32_t wonv = 0xffffffffu;
     alive = pk != PK_DONE;
-    if (alive) cls = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv & PK_WILLNEED_BIT) ? 3 : 0) : 3;
+    if (alive && cid - P.c0 - P.g0 < P.Kg) cls = pk == PK_MATCH ? 2 : pk == PK_NONE ? ((pv & PK_WILLNEED_BIT) ? 3 : 0) : 3;
     if (pk == PK_MATCH || pk == PK_SEED) {
       uint32_t rid = (uint32_t)pv;
       bool won = P.resv[rid] == cid;
@@ -2859,7 +2860,7 @@ __global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
     }
     P.won[t] = wonv;
   }
-  for (uint32_t j = t; j < P.Kg_other; j += gridDim.x * blockDim.x) {
+  for (uint32_t j = t; j < P.gKg_other; j += gridDim.x * blockDim.x) {
     const uint32_t w = P.won_other[j];
     if (w == 0xffffffffu) continue;
     const uint32_t rid = w & 0x7fffffffu;
@@ -2882,7 +2883,7 @@ __global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
   {  // class lists of this block's chains (k_round_mc; as in k_mg_mark)
     __shared__ uint32_t s_wc[4][4];  // [wave][class]
     const int wv = threadIdx.x >> 6;
-    const uint32_t segi = P.g0 / MARK_BLOCK + blockIdx.x;
+    const uint32_t segi = P.gg0 / MARK_BLOCK + blockIdx.x;
     uint32_t mypos = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -2895,7 +2896,7 @@ __global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
       uint32_t base = 0;
       for (int k = 0; k < cls; k++) base += s_wc[0][k] + s_wc[1][k] + s_wc[2][k] + s_wc[3][k];
       for (int w = 0; w < wv; w++) base += s_wc[w][cls];
-      P.ord[(size_t)segi * MARK_BLOCK + base + mypos] = cid;
+      P.ord[(size_t)segi * MARK_BLOCK + base + mypos] = cid - P.c0;
     }
     if (threadIdx.x == 0)
       P.ord_cnt[segi] = make_uint4(s_wc[0][0] + s_wc[1][0] + s_wc[2][0] + s_wc[3][0], s_wc[0][1] + s_wc[1][1] + s_wc[2][1] + s_wc[3][1],
@@ -2907,8 +2908,8 @@ __global__ __launch_bounds__(256) void k_ph_mark_wide(DevParams P) {
 // other group since the search -- proposes its second one
 __global__ void k_ph_alt_resolve(DevParams P) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P.Kg) return;
-  const uint32_t cid = P.g0 + t;
+  if (t >= P.gKg) return;
+  const uint32_t cid = P.gg0 + t;
   const unsigned long long pv = P.prop[cid];
   if (((int)(pv >> 32) & 7) != PK_MATCH || !(pv >> PK_ALT_SHIFT)) return;
   const uint32_t rid = (uint32_t)pv;
@@ -2921,19 +2922,21 @@ __global__ void k_delay(uint32_t us) {
   while (wall_clock64() - t0 < (uint64_t)us * 100u) __builtin_amdgcn_s_sleep(64);
 }
 // first round: every local chain in class 2
+// (over the global chains [gg0, gg0 + gKg) of the launch's group, gg0 a multiple of MARK_BLOCK; this rank's are [c0 + g0, c0 + g0 + Kg))
 __global__ void k_init_ord(DevParams P) {
-  const uint32_t cid = blockIdx.x * blockDim.x + threadIdx.x;  // global chain id; block = k_mg_mark's block
+  const uint32_t cid = P.gg0 + blockIdx.x * blockDim.x + threadIdx.x;  // global chain id; block = the mark step's block
+  const uint32_t blk = P.gg0 / MARK_BLOCK + blockIdx.x;
   __shared__ uint32_t s_n;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  const bool local = cid >= P.c0 && cid - P.c0 < P.K;
+  const bool local = cid < P.gg0 + P.gKg && cid - P.c0 - P.g0 < P.Kg;
   const uint64_t m = __ballot(local);
   uint32_t wbase = 0;
   if ((threadIdx.x & 63) == 0 && m) wbase = atomicAdd(&s_n, (uint32_t)__popcll(m));
   wbase = (uint32_t)__shfl((int)wbase, 0, 64);
-  if (local) P.ord[(size_t)blockIdx.x * MARK_BLOCK + wbase + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = cid - P.c0;
+  if (local) P.ord[(size_t)blk * MARK_BLOCK + wbase + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = cid - P.c0;
   __syncthreads();
-  if (threadIdx.x == 0) P.ord_cnt[blockIdx.x] = make_uint4(0u, 0u, s_n, 0u);
+  if (threadIdx.x == 0) P.ord_cnt[blk] = make_uint4(0u, 0u, s_n, 0u);
 }
 
 // per chain: {records emitted, singletons}; totals of the per-chain counters (finalize reads 8 bytes per chain
@@ -3178,11 +3181,12 @@ void launch_init_taken(hipStream_t st, uint64_t *taken, uint64_t nwords, uint32_
     else if (np_ == 4) { CALL(4); } else { CALL(8); }      \
   } while (0)
 
-void launch_init_chains(hipStream_t st, const DevParams &P) {
-  if (P.Ktot) hipLaunchKernelGGL(k_init_seeds, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
-  if (!P.K) return;
-  if (P.ord) hipLaunchKernelGGL(k_init_ord, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
-#define CALL(N) hipLaunchKernelGGL(k_init_chains<N>, dim3((P.K + 3) / 4), dim3(256), 0, st, P)
+// seeds: once per context (every chain of the pool); the rest for the local chains [g0, g0 + Kg) of the group [gg0, gg0 + gKg)
+void launch_init_chains(hipStream_t st, const DevParams &P, bool seeds) {
+  if (seeds && P.Ktot) hipLaunchKernelGGL(k_init_seeds, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
+  if (!P.Kg) return;
+  if (P.ord) hipLaunchKernelGGL(k_init_ord, GRID1(P.gKg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
+#define CALL(N) hipLaunchKernelGGL(k_init_chains<N>, dim3((P.Kg + 3) / 4), dim3(256), 0, st, P)
   NP_DISPATCH(CALL);
 #undef CALL
 }
@@ -3273,18 +3277,18 @@ void launch_round(hipStream_t st, const DevParams &P, bool stats, bool mg) {
 #endif
 }
 void launch_mg_resolve(hipStream_t st, const DevParams &P) {
-  if (P.Ktot == P.K) return;  // one rank: nothing foreign
-  hipLaunchKernelGGL(k_mg_resolve, GRID1(P.Ktot - P.K, 256), dim3(256), 0, st, P);
+  if (P.gKg == P.Kg) return;  // one rank: nothing foreign
+  hipLaunchKernelGGL(k_mg_resolve, GRID1(P.gKg - P.Kg, 256), dim3(256), 0, st, P);
 }
 void launch_mg_mark(hipStream_t st, const DevParams &P) {
   if (P.alts == 2) hipLaunchKernelGGL(k_alt_resolve, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
   hipLaunchKernelGGL(k_mg_mark, GRID1(P.Ktot, 256), dim3(256), 0, st, P);
 }
 void launch_ph_mark(hipStream_t st, const DevParams &P) {
-  if (!P.Kg) return;
-  if (P.alts == 2) hipLaunchKernelGGL(k_ph_alt_resolve, GRID1(P.Kg, 64), dim3(64), 0, st, P);   // (one-wavefront workgroups: see k_ph_mark)
-  if (P.deep_bins) hipLaunchKernelGGL(k_ph_mark, GRID1(P.Kg, MARK_BLOCK), dim3(64), 0, st, P);
-  else hipLaunchKernelGGL(k_ph_mark_wide, GRID1(P.Kg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
+  if (!P.gKg) return;
+  if (P.alts == 2) hipLaunchKernelGGL(k_ph_alt_resolve, GRID1(P.gKg, 64), dim3(64), 0, st, P);   // (one-wavefront workgroups: see k_ph_mark)
+  if (P.deep_bins) hipLaunchKernelGGL(k_ph_mark, GRID1(P.gKg, MARK_BLOCK), dim3(64), 0, st, P);
+  else hipLaunchKernelGGL(k_ph_mark_wide, GRID1(P.gKg, MARK_BLOCK), dim3(MARK_BLOCK), 0, st, P);
 }
 void launch_delay(hipStream_t st, uint32_t microseconds) { hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, microseconds); }
 void launch_chain_summary(hipStream_t st, const DevParams &P, uint2 *sum, unsigned long long *tot) {

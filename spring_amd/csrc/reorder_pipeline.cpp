@@ -156,6 +156,9 @@ struct spring_reorder_ctx {
   uint64_t *taken2 = nullptr;
   uint32_t *resv2 = nullptr, *won = nullptr;
   uint32_t Kh = 0, nmid = 0;
+  // geometry of the chain groups for this context (DevParams: g0 / Kg / c0 / gg0 / gKg): one group = every local chain; two
+  // groups = a slice of each (one GPU: the slices are the groups)
+  struct GroupGeom { uint32_t g0 = 0, Kg = 0, c0 = 0, gg0 = 0, gKg = 0; } grp[2];
   struct LongBufs { uint32_t *longq = nullptr, *lctl = nullptr, *lparts = nullptr; LongHead *lhead = nullptr; uint2 *lbin = nullptr; uint16_t *lbcode = nullptr; } lb2;  // group 1's (DevParams::longq ...)
   bool in_source_fallback = false;  // load_dna <-> load_dna_source recursion guard
   // FASTQ front end (f1): reads with N, per input file
@@ -166,6 +169,7 @@ struct spring_reorder_ctx {
   spring_fastq_info fq;
   double fq_ms = 0;
   std::vector<uint64_t> tid_off, tid_off_s;
+  std::vector<uint64_t> tid_mid, tid_mid_s;  // inside tid t: where the records of the second group's chains begin (= tid_off[t + 1] with one group)
   spring_reorder_stats stats;
   hipEvent_t ev[8];
   bool ev_ok = false;
@@ -207,6 +211,7 @@ int reorder_view_any(spring_reorder_ctx *ctx, ReorderView *v) {
   v->f_order = ctx->P.f_order; v->f_order_s = ctx->P.f_order_s; v->f_rc = ctx->P.f_rc; v->f_flag = ctx->P.f_flag;
   v->f_pos = ctx->P.f_pos; v->f_len = ctx->P.f_len; v->tid_off = ctx->tid_off.data(); v->num_thr = ctx->o.num_thr;
   v->tid_off_s = ctx->tid_off_s.data();
+  v->tid_mid = ctx->tid_mid.data(); v->tid_mid_s = ctx->tid_mid_s.data();
   for (int j = 0; j < 2; j++) {  // reads with N kept by the FASTQ front end (none when the reads came as .dna records)
     v->N_dna[j] = ctx->d_N[j]; v->N_off[j] = ctx->d_offN[j]; v->N_order[j] = ctx->d_orderN[j];
     v->N_count[j] = ctx->fq.num_reads_N[j]; v->N_bytes[j] = ctx->N_bytes[j];
@@ -1404,6 +1409,9 @@ static uint32_t auto_chains(uint32_t n, bool deep, bool very_deep, bool heavy_ta
   const uint64_t cap = ((deep && !very_deep) || (heavy_tail && !deep)) ? 131072 : 65536;
   if (k < 1) k = 1;
   if (k > cap) k = cap;
+  // from the chain count at which the chains run as two groups: a multiple of 2048, so that the same default applies -- and
+  // cuts into the same two groups -- on one GPU and on a pool of 2, 4 or 8 (setup_chains)
+  if (k >= 16384) k &= ~2047ull;
   return (uint32_t)k;
 }
 
@@ -1461,11 +1469,16 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // 398 / - / 335; 5 M and 10 M reads are slower with two groups (47 -> 59, 65 -> 70: a group's launch no longer fills
   // the chip).  So: two groups from 16 384 chains on, four chains per wavefront from 32 768 on (with one group: 49 152).
   {
-    const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)K / 2 + 1024) / 2048) * 2048, 2048);  // group 0: chains [0, half): K / 2 to the nearest multiple of 2048
+    // (the groups are cut from the GLOBAL chain ids, so a pool's output does not depend on the number of ranks: group 0 = chains
+    // [0, half), half = Ktot / 2 to the nearest multiple of 2048; a rank of a pool owns an equal slice of each group)
+    const uint32_t world = K ? Ktot / K : 1, rank = K ? c0 / K : 0;
+    const uint32_t half = (uint32_t)std::max<uint64_t>((((uint64_t)Ktot / 2 + 1024) / 2048) * 2048, 2048);
     const uint32_t nmid = (uint32_t)(((uint64_t)n / 2) >> UBLK_SHIFT << UBLK_SHIFT);  // group 1's seeds: reads [0, nmid)
-    // (n >= K: every chain starts with a seed of its own, reorder.h:405-421 -- with fewer reads than chains only chain 0 runs, the
+    // (n >= Ktot: every chain starts with a seed of its own, reorder.h:405-421 -- with fewer reads than chains only chain 0 runs, the
     // second group would have no chain at all and nobody would ever pick the seeds of its range)
-    const bool can = allow_phases && fused && Ktot == K && c0 == 0 && !d_prop && K >= 4096 && half < K && n < 0x80000000u && nmid > 0 && n >= K;
+    const bool pool_ok = world == 1 ? (c0 == 0 && !d_prop)
+                                    : ((uint64_t)K * world == Ktot && half % (MARK_BLOCK * world) == 0 && (Ktot - half) % (MARK_BLOCK * world) == 0);
+    const bool can = allow_phases && fused && K > 0 && pool_ok && Ktot >= 4096 && half < Ktot && n < 0x80000000u && nmid > 0 && n >= Ktot;
     // Deep-bin pools (one chain per wavefront, up to 131 072 chains), one group / two, chains stage in ms: 20 M reads (131 072 chains)
     // 400x 112 / 102, 1 600x 122 / 115, 6 400x 136 / 131, 25 600x (two candidates per proposal) 151 / 150; 10 M reads (78 125 chains)
     // 400x 60 / 58, 6 400x 74 / 79, 25 600x 85 / 90; 5 M reads (39 062) 34 / 35, 44 / 50, 55 / 59; 2.5 M reads (19 531) 21 / 26,
@@ -1473,15 +1486,31 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     // chip on its own: two groups only at the cap of 131 072 chains, and not on contended pools (two candidates per proposal).
     // Pools whose long searches go to the k_long kernels stay with one group: PhiX-like 150 / 165 ms, genome-like 100 M reads
     // 1 475 / 1 619 -- blocks of 4-8 wavefronts starve beside the other group's one-wavefront workgroups.
+    // (the rule looks at the pool -- Ktot, the dictionary --, never at a rank's share: the choice changes the output)
     const bool long_kernels = P.deep_bins && P.long_budget > 0;
-    const bool pays = P.deep_bins ? (K >= 131072 && P.alts == 1 && !long_kernels) : K >= 16384;
-    const int want = ctx->o.phases > 0 ? ctx->o.phases : (pays ? 2 : 1);
-    if (ctx->o.phases == 2 && !can)
-      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path), one GPU, at least 4096 "
-                  "chains and 8192 .. 2^31 - 1 reads, at least as many reads as chains");
+    const bool pays = P.deep_bins ? (Ktot >= 131072 && P.alts == 1 && !long_kernels) : Ktot >= 16384;
+    // (the library's own choice also asks for a multiple of 2048 chains -- which the default chain count is from 16 384 on --
+    // whatever the number of ranks: both groups then split evenly over 1, 2, 4 or 8 ranks into slices of whole mark-step
+    // blocks, and the choice -- one group or two -- is the same for all of them)
+    const int want = ctx->o.phases > 0 ? ctx->o.phases : (pays && Ktot % 2048 == 0 ? 2 : 1);
     if (ctx->o.phases > 2) return fail(SPRING_REORDER_E_ARG, "phases: 0 (library's choice), 1 or 2");
+    if (ctx->o.phases == 2 && !can)
+      return fail(SPRING_REORDER_E_ARG, "phases = 2 needs the fused round (fused >= 0, no literal consensus path), at least 4096 "
+                  "chains and 8192 .. 2^31 - 1 reads, at least as many reads as chains; in a pool over G GPUs both groups' chain "
+                  "counts must be multiples of %u x G", MARK_BLOCK);
     P.phases = (want == 2 && can) ? 2 : 1;
-    ctx->Kh = half; ctx->nmid = nmid;
+    ctx->nmid = nmid;
+    if (P.phases == 2) {
+      const uint32_t sA = half / world, sB = (Ktot - half) / world;
+      ctx->grp[0].g0 = 0; ctx->grp[0].Kg = sA; ctx->grp[0].c0 = rank * sA; ctx->grp[0].gg0 = 0; ctx->grp[0].gKg = half;
+      ctx->grp[1].g0 = sA; ctx->grp[1].Kg = sB; ctx->grp[1].c0 = half + rank * sB - sA; ctx->grp[1].gg0 = half; ctx->grp[1].gKg = Ktot - half;
+      ctx->Kh = sA;
+    } else {
+      ctx->grp[0].g0 = 0; ctx->grp[0].Kg = K; ctx->grp[0].c0 = c0; ctx->grp[0].gg0 = 0; ctx->grp[0].gKg = Ktot;
+      ctx->grp[1] = spring_reorder_ctx::GroupGeom();
+      ctx->grp[1].g0 = K; ctx->grp[1].gg0 = Ktot;
+      ctx->Kh = K;
+    }
     ctx->stats.phases = (uint64_t)P.phases;
   }
   P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
@@ -1510,6 +1539,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     P.plan[0][0] = 8; P.plan[0][1] = 16;
   }
   P.g0 = 0; P.Kg = K; P.g0_other = 0; P.Kg_other = 0;
+  P.gg0 = 0; P.gKg = Ktot; P.gKg_other = 0;
   P.seed_lo = 0; P.seed_hi = n;
   P.nb_lo = 0; P.nb_hi = (Ktot + 2047) / 2048;
   P.taken_other = nullptr; P.won = P.won_other = nullptr;
@@ -1518,7 +1548,7 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   if (P.phases == 2) {
     DMALLOC(ctx->taken2, nwords * 8);
     DMALLOC(ctx->resv2, nn * 4);
-    DMALLOC(ctx->won, (size_t)K * 4);
+    DMALLOC(ctx->won, (size_t)Ktot * 4);  // (every chain of the pool: the mark steps are replicated)
   }
   P.prop = nullptr; P.alive_wave = nullptr; P.needy_cnt = P.needy_cnt_next = nullptr;
   ctx->cnt_buf[0] = ctx->cnt_buf[1] = nullptr;
@@ -1595,12 +1625,18 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   HIPCHK(hipMemsetAsync(P.e_chunk, 0xff, nchunk * sizeof(uint2), st));  // owner 0xffffffff: chunk never handed out
   HIPCHK(hipMemsetAsync(P.s_chunk, 0xff, nchunk * sizeof(uint2), st));
   HIPCHK(hipMemcpyAsync(P.glob, &g, sizeof(g), hipMemcpyHostToDevice, st));
-  launch_init_chains(st, P);
-  if (P.phases == 2) {  // both groups start from the same pool: the chains' first seeds are taken
+  if (P.phases == 2) {
+    for (int g = 0; g < 2; g++) {  // (the chains of either slice: their global ids are c0 + li with the slice's own c0)
+      DevParams Q = P;
+      const auto &a = ctx->grp[g];
+      Q.g0 = a.g0; Q.Kg = a.Kg; Q.c0 = a.c0; Q.gg0 = a.gg0; Q.gKg = a.gKg;
+      launch_init_chains(st, Q, g == 0);
+    }
+    // both groups start from the same pool: the chains' first seeds are taken
     HIPCHK(hipMemcpyAsync(ctx->taken2, P.taken, nwords * 8, hipMemcpyDeviceToDevice, st));
     launch_fill_u32(st, ctx->resv2, n, 0xffffffffu);
-    HIPCHK(hipMemsetAsync(ctx->won, 0xff, (size_t)K * 4, st));
-  }
+    HIPCHK(hipMemsetAsync(ctx->won, 0xff, (size_t)Ktot * 4, st));
+  } else launch_init_chains(st, P);
   HIPCHK(hipGetLastError());
   ctx->round_no = 0;
   return 0;
@@ -1628,6 +1664,28 @@ static int running_chains(spring_reorder_ctx *ctx, std::vector<uint32_t> &buf, u
   return 0;
 }
 
+// DevParams of one chain group's launches in round `round_no` of that group (two-group schedule): the group's slice of this
+// context's chains, its view of the pool, its reservation words, cursor, seed range, winners' list and long-search buffers
+static DevParams group_params(spring_reorder_ctx *ctx, int g, uint64_t round_no) {
+  DevParams Q = ctx->P;
+  const auto &a = ctx->grp[g], &b = ctx->grp[g ^ 1];
+  Q.g0 = a.g0; Q.Kg = a.Kg; Q.c0 = a.c0; Q.gg0 = a.gg0; Q.gKg = a.gKg;
+  Q.g0_other = b.g0; Q.Kg_other = b.Kg; Q.gKg_other = b.gKg;
+  Q.seed_lo = g ? 0u : ctx->nmid; Q.seed_hi = g ? ctx->nmid : ctx->n;
+  Q.nb_lo = a.gg0 / 2048; Q.nb_hi = (a.gg0 + a.gKg + 2047) / 2048;
+  Q.taken = g ? ctx->taken2 : ctx->P.taken; Q.taken_other = g ? ctx->P.taken : ctx->taken2;
+  Q.resv = g ? ctx->resv2 : ctx->P.resv;
+  Q.cursor = g ? &ctx->P.glob->cursor_b : &ctx->P.glob->cursor;
+  Q.won = ctx->won + a.gg0; Q.won_other = ctx->won + b.gg0;
+  if (g == 1 && ctx->P.longq) {
+    Q.longq = ctx->lb2.longq; Q.lctl = ctx->lb2.lctl; Q.lparts = ctx->lb2.lparts; Q.lhead = ctx->lb2.lhead;
+    Q.lbin = ctx->lb2.lbin; Q.lbcode = ctx->lb2.lbcode;
+  }
+  const int w = (int)(round_no & 1);  // (set_round_buffers, per group: the groups touch disjoint blocks of the buffers)
+  Q.needy_cnt = ctx->cnt_buf[w ^ 1]; Q.needy_cnt_next = ctx->cnt_buf[w];
+  return Q;
+}
+
 // The two-group schedule (DevParams::phases = 2).  Group 0 runs on the context's stream, group 1 on
 // a second one; a round of a group = its round kernel, then its mark step, which waits (event) for the other group's
 // last mark step: the mark steps strictly alternate A, B, A, B ..., the round kernels overlap.  A third stream carries the
@@ -1640,25 +1698,8 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
   if (!ctx->st2) HIPCHK(hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking));
   if (!ctx->st3) HIPCHK(hipStreamCreateWithFlags(&ctx->st3, hipStreamNonBlocking));
   hipStream_t sg[2] = {ctx->st, ctx->st2}, sc = ctx->st3;
-  struct Group { uint32_t g0, Kg, seed_lo, seed_hi; uint64_t *taken; uint32_t *resv; long long *cursor; uint64_t round_no; } gp[2];
-  gp[0] = {0u, ctx->Kh, ctx->nmid, ctx->n, P.taken, P.resv, &P.glob->cursor, 0};
-  gp[1] = {ctx->Kh, K - ctx->Kh, 0u, ctx->nmid, ctx->taken2, ctx->resv2, &P.glob->cursor_b, 0};
-  auto params_of = [&](int g) {
-    DevParams Q = P;
-    const Group &a = gp[g], &b = gp[g ^ 1];
-    Q.g0 = a.g0; Q.Kg = a.Kg; Q.g0_other = b.g0; Q.Kg_other = b.Kg;
-    Q.seed_lo = a.seed_lo; Q.seed_hi = a.seed_hi;
-    Q.nb_lo = a.g0 / 2048; Q.nb_hi = (a.g0 + a.Kg + 2047) / 2048;
-    Q.taken = a.taken; Q.taken_other = b.taken; Q.resv = a.resv; Q.cursor = a.cursor;
-    Q.won = ctx->won + a.g0; Q.won_other = ctx->won + b.g0;
-    if (g == 1 && P.longq) {
-      Q.longq = ctx->lb2.longq; Q.lctl = ctx->lb2.lctl; Q.lparts = ctx->lb2.lparts; Q.lhead = ctx->lb2.lhead;
-      Q.lbin = ctx->lb2.lbin; Q.lbcode = ctx->lb2.lbcode;
-    }
-    const int w = (int)(a.round_no & 1);  // (set_round_buffers, per group: the groups touch disjoint blocks of the buffers)
-    Q.needy_cnt = ctx->cnt_buf[w ^ 1]; Q.needy_cnt_next = ctx->cnt_buf[w];
-    return Q;
-  };
+  struct Group { uint64_t *taken; uint64_t round_no; } gp[2] = {{P.taken, 0}, {ctx->taken2, 0}};
+  auto params_of = [&](int g) { return group_params(ctx, g, gp[g].round_no); };
   hipEvent_t ev[2] = {nullptr, nullptr}, bev[2] = {nullptr, nullptr}, ev0 = nullptr, evt = nullptr;
   struct EvFree { hipEvent_t *e; int n; ~EvFree() { for (int i = 0; i < n; i++) if (e[i]) (void)hipEventDestroy(e[i]); } };
   EvFree g1{ev, 2}, g2{bev, 2}, g3{&ev0, 1}, g4{&evt, 1};
@@ -1931,7 +1972,7 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
   const uint32_t K = total_chains / world;
   ctx->stats.chains = total_chains;
   ctx->stats.deep_pool = (dict_is_deep(ctx) ? 1 : 0) | (dict_has_heavy_tail(ctx) ? 2 : 0);
-  int r = setup_chains(ctx, K, rank * K, total_chains, true, d_prop);
+  int r = setup_chains(ctx, K, rank * K, total_chains, true, d_prop, true);
   if (r) return r;
   HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->mg = true;
@@ -1942,8 +1983,15 @@ int spring_reorder_mg_begin(spring_reorder_ctx *ctx, uint32_t rank, uint32_t wor
 int spring_reorder_mg_search(spring_reorder_ctx *ctx) {
   if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_search: mg_begin first");
   HIPCHK(hipSetDevice(ctx->dev));
-  set_round_buffers(ctx);
-  launch_round(ctx->st, ctx->P, ctx->o.collect_stats != 0, true);
+  if (ctx->P.phases == 2) {
+    // two chain groups, step by step: both groups' round kernels, the caller's exchange of both slices, then the mark steps
+    // A, B (mg_apply) -- one of the orders the overlapped schedule of mg_run may take (a group's round kernel needs its own
+    // last mark step only)
+    for (int g = 0; g < 2; g++) launch_round(ctx->st, group_params(ctx, g, ctx->round_no), ctx->o.collect_stats != 0, true);
+  } else {
+    set_round_buffers(ctx);
+    launch_round(ctx->st, ctx->P, ctx->o.collect_stats != 0, true);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->st));  // the caller's exchange reads this rank's slice next
   return 0;
@@ -1952,6 +2000,7 @@ int spring_reorder_mg_search(spring_reorder_ctx *ctx) {
 int spring_reorder_mg_slice(spring_reorder_ctx *ctx, void **d_prop, size_t *slice_off, size_t *slice_bytes,
                             size_t *total_bytes) {
   if (!ctx || !ctx->mg) return fail(SPRING_REORDER_E_STATE, "mg_slice: mg_begin first");
+  if (ctx->P.phases == 2) return fail(SPRING_REORDER_E_STATE, "mg_slice: with two chain groups a rank owns two slices of the proposal words (mg_run / exchange_virtual move both)");
   if (d_prop) *d_prop = ctx->P.prop;
   if (slice_off) *slice_off = (size_t)ctx->P.c0 * 8;
   if (slice_bytes) *slice_bytes = (size_t)ctx->P.K * 8;
@@ -1963,8 +2012,16 @@ int spring_reorder_mg_apply(spring_reorder_ctx *ctx, int32_t check_alive, uint32
   if (!ctx || !ctx->mg || ctx->stage != ST_DICT) return fail(SPRING_REORDER_E_STATE, "mg_apply: mg_begin first");
   HIPCHK(hipSetDevice(ctx->dev));
   hipStream_t st = ctx->st;
-  launch_mg_resolve(st, ctx->P);
-  launch_mg_mark(st, ctx->P);
+  if (ctx->P.phases == 2) {
+    for (int g = 0; g < 2; g++) {
+      const DevParams Q = group_params(ctx, g, ctx->round_no);
+      launch_mg_resolve(st, Q);
+      launch_ph_mark(st, Q);
+    }
+  } else {
+    launch_mg_resolve(st, ctx->P);
+    launch_mg_mark(st, ctx->P);
+  }
   HIPCHK(hipGetLastError());
   ctx->round_no++;
   ctx->stats.rounds++;
@@ -2018,7 +2075,12 @@ int spring_reorder_mg_exchange_virtual(spring_reorder_ctx **ctxs, uint32_t world
       if (s2 == d) continue;
       spring_reorder_ctx *sc = ctxs[s2];
       if (sc->P.prop == dc->P.prop) continue;  // shared buffer
-      HIPCHK(hipMemcpyAsync(dc->P.prop + sc->P.c0, sc->P.prop + sc->P.c0, (size_t)sc->P.K * 8, hipMemcpyDeviceToDevice, dc->st));
+      for (int g = 0; g < 2; g++) {  // (one slice, or one per chain group)
+        const auto &a = sc->grp[g];
+        if (!a.Kg) continue;
+        const size_t o = (size_t)a.c0 + a.g0;  // the slice's first global chain id
+        HIPCHK(hipMemcpyAsync(dc->P.prop + o, sc->P.prop + o, (size_t)a.Kg * 8, hipMemcpyDeviceToDevice, dc->st));
+      }
     }
   }
   for (uint32_t d = 0; d < world; d++) HIPCHK(hipStreamSynchronize(ctxs[d]->st));
@@ -2089,6 +2151,159 @@ void mg_comm_abort(spring_mg_comm *c) {
 }
 extern "C" {
 
+// The pool with two chain groups (DevParams::phases = 2): every rank owns a slice of EACH group, so the
+// groups -- and with them the output -- are the same whatever the number of ranks.  Per group and round: the round kernel over
+// the rank's slice on the group's stream -> the all-gather of the group's proposal words (in place inside the group's range of
+// the buffer; all collectives of the run go through ONE exchange stream in one order, the same on every rank) -> the other
+// ranks' words resolved, the group's mark step over the whole group (replicated), which waits for the other group's last mark
+// step as on one GPU.  So a group's exchange, resolve and mark run beside the other group's round kernel: nothing but round
+// kernels is left on a rank's critical path.
+static int mg_run_phased(spring_reorder_ctx *ctx, spring_mg_comm *comm) {
+  DevParams &P = ctx->P;
+  const bool stats = ctx->o.collect_stats != 0;
+  const int R = ctx->o.rounds_per_sync > 0 ? ctx->o.rounds_per_sync : 8;
+  const bool timed = ctx->o.time_search != 0;
+  if (!ctx->st2) HIPCHK(hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking));
+  if (!ctx->st3) HIPCHK(hipStreamCreateWithFlags(&ctx->st3, hipStreamNonBlocking));
+  hipStream_t sg[2] = {ctx->st, ctx->st2}, sx = ctx->st3;
+  hipEvent_t ev[2] = {nullptr, nullptr}, ek[2] = {nullptr, nullptr}, ex[2] = {nullptr, nullptr}, bev[2] = {nullptr, nullptr}, ev0 = nullptr;
+  struct EvFree { hipEvent_t *e; int n; ~EvFree() { for (int i = 0; i < n; i++) if (e[i]) (void)hipEventDestroy(e[i]); } };
+  EvFree f1{ev, 2}, f2{ek, 2}, f3{ex, 2}, f4{bev, 2}, f5{&ev0, 1};
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ek[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ex[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&bev[i], hipEventDisableTiming));
+  }
+  HIPCHK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+  std::vector<hipEvent_t> tev;  // time_search: per round and group {round kernel start, end, exchange end (on sx), mark end}
+  struct TevFree { std::vector<hipEvent_t> &v; ~TevFree() { for (auto &e : v) if (e) (void)hipEventDestroy(e); } } tev_guard{tev};
+  if (timed) {
+    tev.assign(8 * (size_t)R, nullptr);
+    for (auto &e : tev) HIPCHK(hipEventCreate(&e));
+  }
+  const size_t nw = ((size_t)P.Ktot + 63) / 64;
+  uint32_t *h_aw = nullptr;
+  HIPCHK(hipHostMalloc((void **)&h_aw, 2 * nw * sizeof(uint32_t), hipHostMallocDefault));
+  struct HostFree { void *p; ~HostFree() { if (p) (void)hipHostFree(p); } } h_aw_guard{h_aw};
+  void *h_stage = nullptr;  // host transport: one staging buffer per group's range
+  const size_t gbytes[2] = {(size_t)ctx->grp[0].gKg * 8, (size_t)ctx->grp[1].gKg * 8};
+  if (comm->host_fn) HIPCHK(hipHostMalloc(&h_stage, std::max(gbytes[0], gbytes[1]), hipHostMallocDefault));
+  HostFree h_stage_guard{h_stage};
+  uint64_t round_no[2] = {0, 0};
+  HIPCHK(hipEventRecord(ev0, sg[0]));
+  HIPCHK(hipStreamWaitEvent(sg[1], ev0, 0));
+  HIPCHK(hipStreamWaitEvent(sx, ev0, 0));
+  bool have_b = false;
+  uint64_t rounds = 0, timed_rounds = 0;
+  double ms_round = 0, ms_xchg = 0, ms_mark = 0;
+  auto fail_sync = [&](int code) {  // (nothing of this run may still be queued when the caller tears the context down)
+    (void)hipStreamSynchronize(sg[0]); (void)hipStreamSynchronize(sg[1]); (void)hipStreamSynchronize(sx);
+    return code;
+  };
+  auto enqueue_batch = [&]() -> int {
+    for (int r = 0; r < R; r++) {
+      for (int g = 0; g < 2; g++) {
+        const DevParams Q = group_params(ctx, g, round_no[g]);
+        const auto &a = ctx->grp[g];
+        unsigned long long *grange = P.prop + a.gg0;             // the group's words, all ranks
+        unsigned long long *mine = P.prop + a.c0 + a.g0;         // this rank's slice of them
+        if (timed) HIPCHK(hipEventRecord(tev[8 * r + 4 * g], sg[g]));
+        launch_round(sg[g], Q, stats, true);
+        if (timed) HIPCHK(hipEventRecord(tev[8 * r + 4 * g + 1], sg[g]));
+        HIPCHK(hipEventRecord(ek[g], sg[g]));
+        if (comm->rccl) {
+          HIPCHK(hipStreamWaitEvent(sx, ek[g], 0));
+          const int e = g_rccl.AllGather(mine, grange, a.Kg, RCCL_UINT64, comm->rccl, sx);
+          if (e) return fail(SPRING_REORDER_E_HIP, "ncclAllGather: %s", rccl_err(e));
+          if (timed) HIPCHK(hipEventRecord(tev[8 * r + 4 * g + 2], sx));
+          HIPCHK(hipEventRecord(ex[g], sx));
+          HIPCHK(hipStreamWaitEvent(sg[g], ex[g], 0));
+        } else {  // through the caller's all-gather on host memory (ranks that share a device; tests): synchronous
+          const size_t off = (size_t)(a.c0 + a.g0 - a.gg0) * 8, slice = (size_t)a.Kg * 8;
+          HIPCHK(hipMemcpyAsync((char *)h_stage + off, mine, slice, hipMemcpyDeviceToHost, sg[g]));
+          HIPCHK(hipStreamSynchronize(sg[g]));
+          if (comm->host_fn(h_stage, off, slice, gbytes[g], comm->host_user))
+            return fail(SPRING_REORDER_E_IO, "mg_run: the caller's all-gather reported an error");
+          HIPCHK(hipMemcpyAsync(grange, h_stage, gbytes[g], hipMemcpyHostToDevice, sg[g]));
+          HIPCHK(hipStreamSynchronize(sg[g]));  // (the staging buffer is reused by the other group)
+          if (timed) HIPCHK(hipEventRecord(tev[8 * r + 4 * g + 2], sg[g]));
+        }
+        launch_mg_resolve(sg[g], Q);
+        if (g == 1 || have_b) HIPCHK(hipStreamWaitEvent(sg[g], ev[g ^ 1], 0));  // the other group's last mark step
+        launch_ph_mark(sg[g], Q);
+        if (timed) HIPCHK(hipEventRecord(tev[8 * r + 4 * g + 3], sg[g]));
+        HIPCHK(hipEventRecord(ev[g], sg[g]));
+        round_no[g]++;
+      }
+      have_b = true;
+    }
+    rounds += R;
+    if (P.deep_bins && (ctx->dict[0].ndeep || ctx->dict[1].ndeep)) {  // (as in run_chains_phased: both groups meet)
+      HIPCHK(hipStreamWaitEvent(sg[0], ev[1], 0));
+      for (int l = 0; l < 2; l++)
+        launch_trim_bins(sg[0], ctx->dict[l].deep, ctx->dict[l].d_ndeep, ctx->dict[l].ndeep, ctx->dict[l].urec, ctx->dict[l].ids, P.taken, const_cast<ulonglong2 *>(P.sig[l]), P.epos[l]);
+      HIPCHK(hipEventRecord(ev0, sg[0]));
+      HIPCHK(hipStreamWaitEvent(sg[1], ev0, 0));
+    }
+    return 0;
+  };
+  // the running chains, counted from the mark steps' per-wavefront counts behind both groups' last mark steps of a batch:
+  // every rank marks every chain from the same gathered words, so every rank reads the same count and stops after the same batch
+  auto count_batch = [&](int slot) -> int {
+    HIPCHK(hipStreamWaitEvent(sx, ev[0], 0));
+    HIPCHK(hipStreamWaitEvent(sx, ev[1], 0));
+    HIPCHK(hipMemcpyAsync(h_aw + (size_t)slot * nw, P.alive_wave, nw * 4, hipMemcpyDeviceToHost, sx));
+    HIPCHK(hipEventRecord(bev[slot], sx));
+    return 0;
+  };
+  auto alive_in = [&](int slot) { uint64_t a = 0; for (size_t i = 0; i < nw; i++) a += h_aw[(size_t)slot * nw + i]; return a; };
+  int rr = 0;
+  if (timed || comm->host_fn) {  // a batch at a time
+    for (;;) {
+      if ((rr = enqueue_batch())) return fail_sync(rr);
+      if ((rr = count_batch(0))) return fail_sync(rr);
+      HIPCHK(hipEventSynchronize(bev[0]));
+      HIPCHK(hipStreamSynchronize(sg[0]));
+      HIPCHK(hipStreamSynchronize(sg[1]));
+      if (timed) {
+        for (int i = 0; i < 2 * R; i++) {
+          float a = 0, b = 0, c = 0;
+          (void)hipEventElapsedTime(&a, tev[4 * i], tev[4 * i + 1]);
+          (void)hipEventElapsedTime(&b, tev[4 * i + 1], tev[4 * i + 2]);
+          (void)hipEventElapsedTime(&c, tev[4 * i + 2], tev[4 * i + 3]);
+          ms_round += a; ms_xchg += b; ms_mark += c;
+        }
+        timed_rounds += (uint64_t)R;
+      }
+      if (!alive_in(0)) break;
+    }
+  } else {  // the host looks at the count one batch late: neither group's stream ever waits for it
+    if ((rr = enqueue_batch())) return fail_sync(rr);
+    if ((rr = count_batch(0))) return fail_sync(rr);
+    for (int b = 0;; b ^= 1) {
+      if ((rr = enqueue_batch())) return fail_sync(rr);
+      if ((rr = count_batch(b ^ 1))) return fail_sync(rr);
+      HIPCHK(hipEventSynchronize(bev[b]));
+      const uint64_t a = alive_in(b);
+      HIPCHK(hipGetLastError());
+      if (ctx->o.debug) fprintf(stderr, "[chains] rounds %llu running %llu (pool, two groups)\n", (unsigned long long)(rounds - R), (unsigned long long)a);
+      if (!a) break;
+    }
+  }
+  HIPCHK(hipStreamWaitEvent(sg[0], ev[1], 0));
+  HIPCHK(hipStreamSynchronize(sg[1]));
+  HIPCHK(hipStreamSynchronize(sx));
+  HIPCHK(hipStreamSynchronize(sg[0]));
+  ctx->round_no = round_no[0];
+  ctx->stats.rounds = rounds;
+  if (timed) {  // (per group-round: the pieces of both groups are summed; two round kernels run side by side most of the time)
+    ctx->stats.ms_search_kernel = ms_round; ctx->stats.ms_search_busy = ms_round; ctx->stats.search_launches = 2 * timed_rounds;
+    ctx->stats.ms_exchange = ms_xchg; ctx->stats.ms_resolve_mark = ms_mark;
+  }
+  return 0;
+}
+
 // one pool over the communicator's ranks with the exchange inside the library; see include/spring_reorder.h
 int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_t total_chains) {
   if (!ctx || !comm) return fail(SPRING_REORDER_E_ARG, "mg_run: NULL argument");
@@ -2096,6 +2311,13 @@ int spring_reorder_mg_run(spring_reorder_ctx *ctx, spring_mg_comm *comm, uint32_
     return fail(SPRING_REORDER_E_ARG, "mg_run: the communicator lives on device %d, the context on %d", comm->dev, ctx->dev);
   int r = spring_reorder_mg_begin(ctx, comm->rank, comm->world, total_chains, nullptr);
   if (r) return r;
+  if (ctx->P.phases == 2) {  // two chain groups: a slice of each per rank, the exchanges beside the round kernels
+    const int rp = mg_run_phased(ctx, comm);
+    const std::string keep = g_err;
+    const int re = spring_reorder_mg_end(ctx);
+    if (rp) { g_err = keep; return rp; }
+    return re;
+  }
   hipStream_t st = ctx->st;
   DevParams &P = ctx->P;
   const bool stats = ctx->o.collect_stats != 0;
@@ -2231,13 +2453,24 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   uint64_t am = 0, as = 0;
   spring_reorder_stats &s = ctx->stats;
   s.unmatched = s.probes = s.keyok = s.cands = s.iterations = s.lost = s.hits = 0;
+  ctx->tid_mid.assign(T, 0);
+  ctx->tid_mid_s.assign(T, 0);
   for (int t = 0; t < T; t++) {
     ctx->tid_off[t] = am;
     ctx->tid_off_s[t] = as;
-    // chain id -> tid id % num_thr: the first local chain of tid t, then every T-th
-    for (uint32_t i = (uint32_t)(((uint32_t)t + (uint32_t)T - P.c0 % (uint32_t)T) % (uint32_t)T); i < K; i += (uint32_t)T) {
-      off_m[i] = am; off_s[i] = as;
-      am += hs[i].x; as += hs[i].y;
+    // chain id -> tid id % num_thr, chain ids ascending inside a tid: the local chains of the first group's slice, then those of
+    // the second group's (a pool that runs two groups: the slices' global ids are c0 + i with the slice's own c0; one group:
+    // one slice, the second one empty).  tid_mid: where the second slice's records begin -- the merge over the ranks of a
+    // pool takes every rank's first part, then every rank's second part (pool.py, reorder_files.cpp)
+    for (int g = 0; g < 2; g++) {
+      const auto &a = ctx->grp[g];
+      if (g == 1) { ctx->tid_mid[t] = am; ctx->tid_mid_s[t] = as; }
+      if (!a.Kg) continue;
+      const uint32_t first = (uint32_t)(((uint32_t)t + (uint32_t)T - (a.c0 + a.g0) % (uint32_t)T) % (uint32_t)T);  // first chain of tid t in the slice
+      for (uint32_t i = a.g0 + first; i < a.g0 + a.Kg; i += (uint32_t)T) {
+        off_m[i] = am; off_s[i] = as;
+        am += hs[i].x; as += hs[i].y;
+      }
     }
   }
   ctx->tid_off[T] = am;
@@ -2317,6 +2550,16 @@ int spring_reorder_finalize(spring_reorder_ctx *ctx) {
   return 0;
 }
 
+int spring_reorder_tid_split(spring_reorder_ctx *ctx, uint64_t *mid, uint64_t *mid_s) {
+  if (!ctx || ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "tid_split: finalize first");
+  const int T = (int)ctx->tid_mid.size();
+  for (int t = 0; t < T; t++) {
+    if (mid) mid[t] = ctx->tid_mid[t];
+    if (mid_s) mid_s[t] = ctx->tid_mid_s[t];
+  }
+  return 0;
+}
+
 int spring_reorder_get_stats(spring_reorder_ctx *ctx, spring_reorder_stats *out) {
   if (!ctx || !out) return fail(SPRING_REORDER_E_ARG, "NULL argument");
   HIPCHK(hipSetDevice(ctx->dev));
@@ -2363,7 +2606,7 @@ int spring_reorder_download(spring_reorder_ctx *ctx, uint32_t *order, char *rc, 
 
 extern "C++" {
 namespace sr {
-int emit_dna_device(spring_reorder_ctx *ctx, int32_t tid, uint8_t **d_out, size_t *nbytes, uint64_t s_first, uint64_t s_cnt) {
+int emit_dna_device(spring_reorder_ctx *ctx, int32_t tid, uint8_t **d_out, size_t *nbytes, uint64_t s_first, uint64_t s_cnt, size_t *mid_bytes) {
   if (!ctx || ctx->stage != ST_FINAL) return fail(SPRING_REORDER_E_STATE, "emit_dna: finalize first");
   if (tid < -1 || tid >= ctx->o.num_thr) return fail(SPRING_REORDER_E_ARG, "tid out of range");
   HIPCHK(hipSetDevice(ctx->dev));
@@ -2402,6 +2645,17 @@ int emit_dna_device(spring_reorder_ctx *ctx, int32_t tid, uint8_t **d_out, size_
     HIPCHK(hipMemcpyAsync(&last_sz, d_sz + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     total = last_off + last_sz;
+  }
+  if (mid_bytes) {  // where the records of the second chain group's chains begin in this tid's stream (ctx->tid_mid)
+    const uint64_t idx = tid >= 0 ? ctx->tid_mid[tid] - ctx->tid_off[tid] : 0;
+    if (ctx->uniform || idx == 0) *mid_bytes = idx * rec;
+    else if (idx >= cnt) *mid_bytes = total;
+    else {
+      uint64_t o = 0;
+      HIPCHK(hipMemcpyAsync(&o, d_off + idx, 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      *mid_bytes = o;
+    }
   }
   if (nbytes) *nbytes = total;
   if (d_out) {

@@ -20,18 +20,21 @@ STREAM_KEYS = ("order", "rc", "flag", "pos", "rlen")
 
 
 def merge_rank_streams(per_rank, num_thr):
-    """tid t of the whole job = concatenation over ranks of every rank's tid-t segment (ranks own
-    ascending contiguous chain ranges and chain c belongs to tid c % num_thr)."""
+    """tid t of the whole job = chain ids ascending (chain c belongs to tid c % num_thr): every rank's tid-t records of the
+    chains of the first chain group, ranks ascending, then every rank's of the second group -- a rank owns one contiguous
+    slice of the chains, or (a pool that ran two groups, stats.phases = 2) one slice of each group; tid_mid[t] is where a
+    rank's second part begins (= tid_off[t + 1] with one group)."""
     out = {k: [] for k in STREAM_KEYS}
     out_s = []
     tid_off, tid_off_s = [0], [0]
     for t in range(num_thr):
-        for r in per_rank:
-            a, b = int(r["tid_off"][t]), int(r["tid_off"][t + 1])
-            for k in STREAM_KEYS:
-                out[k].append(r[k][a:b])
-            a, b = int(r["tid_off_s"][t]), int(r["tid_off_s"][t + 1])
-            out_s.append(r["order_s"][a:b])
+        for part in (0, 1):
+            for r in per_rank:
+                a, b = (int(r["tid_off"][t]), int(r["tid_mid"][t])) if part == 0 else (int(r["tid_mid"][t]), int(r["tid_off"][t + 1]))
+                for k in STREAM_KEYS:
+                    out[k].append(r[k][a:b])
+                a, b = (int(r["tid_off_s"][t]), int(r["tid_mid_s"][t])) if part == 0 else (int(r["tid_mid_s"][t]), int(r["tid_off_s"][t + 1]))
+                out_s.append(r["order_s"][a:b])
         tid_off.append(tid_off[-1] + sum(int(r["tid_off"][t + 1] - r["tid_off"][t]) for r in per_rank))
         tid_off_s.append(tid_off_s[-1] + sum(int(r["tid_off_s"][t + 1] - r["tid_off_s"][t]) for r in per_rank))
     res = {k: np.concatenate(v) if v else np.zeros(0) for k, v in out.items()}
@@ -85,6 +88,8 @@ class VirtualPool:
         for r, s in enumerate(self.stages):
             s.mg_begin(r, self.world, self.K)
         arr = (C.c_void_p * self.world)(*[s._h for s in self.stages])
+        # (two chain groups: every group has its own view of the pool and its own seed range; the debug check below knows one)
+        one_group = int(self.stages[0].stats()["phases"]) != 2
         rounds = 0
         while True:
             for s in self.stages:
@@ -92,7 +97,7 @@ class VirtualPool:
             _chk(L_.spring_reorder_mg_exchange_virtual(arr, self.world))
             alive = [s.mg_apply(True) for s in self.stages]
             rounds += 1
-            if rounds % self.check_every == 0:  # what find_seed relies on, on every rank's replica
+            if one_group and rounds % self.check_every == 0:  # what find_seed relies on, on every rank's replica
                 for s in self.stages:
                     assert s.check_seed_state() == (0, 0), "seed-pick invariants broken after round %d" % rounds
             assert len(set(alive)) == 1, "ranks disagree on the number of running chains: %r" % (alive,)
@@ -183,6 +188,28 @@ class PoolComm:
             _chk(self._L.spring_mg_comm_create_host(C.byref(self._h), self._cb, None, self.rank, self.world))
         else:
             raise ValueError("transport must be 'rccl' or 'host'")
+
+    def close(self):
+        if self._h:
+            self._L.spring_mg_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class OneRankComm:
+    """A 1-rank RCCL communicator without torch: the in-library exchange path (spring_reorder_mg_run) on one GPU -- tests,
+    pools that fit one device.  (No torch import: a process that loads this library first and torch later would hold two
+    copies of the ROCm runtime, torch's bundled one and the system's, and RCCL's second HSA handle is not initialised.)"""
+    transport, world, rank = "rccl", 1, 0
+
+    def __init__(self, device_index=0):
+        import types
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self._cb = None
+        idbuf = np.zeros(128, np.uint8)
+        _chk(self._L.spring_mg_rccl_unique_id(idbuf.ctypes.data))
+        _chk(self._L.spring_mg_comm_create_rccl(C.byref(self._h), device_index, idbuf.ctypes.data, 0, 1))
+        self.device = types.SimpleNamespace(index=device_index, type="cuda")
 
     def close(self):
         if self._h:

@@ -200,6 +200,10 @@ class ReorderStage:
         for k in ("order", "rc", "flag", "pos", "rlen"):
             out[k] = out[k][:nm]
         out["order_s"] = out["order_s"][:ns]
+        # inside tid t: where the records of the second chain group's chains begin (a rank of a pool that ran two groups;
+        # = tid_off[t + 1] otherwise) -- pool.merge_rank_streams
+        out["tid_mid"], out["tid_mid_s"] = np.zeros(T, np.uint64), np.zeros(T, np.uint64)
+        _chk(self._L.spring_reorder_tid_split(self._h, out["tid_mid"].ctypes.data, out["tid_mid_s"].ctypes.data))
         out["stats"] = st
         return out
 

@@ -577,6 +577,82 @@ def test_paired_pool_through_pe_encode():
     assert np.array_equal(new[~f1], new[pos_of[order[~f1] - half]] + half)
 
 
+def _perm_and_flags(a, n, L):
+    """size-independent properties of a reorder output at sizes no oracle run reaches (fixed-length pool)"""
+    seen = np.zeros(n, dtype=np.uint8)
+    seen[a["order"]] += 1
+    seen[a["order_s"]] += 1
+    assert len(a["order"]) + len(a["order_s"]) == n and seen.min() == 1 and seen.max() == 1
+    f0 = a["flag"] == ord("0")
+    assert np.all(a["pos"][f0] == 0) and np.all(a["rc"][f0] == ord("d")) and np.all(a["rlen"] == L)
+    toff = [int(x) for x in a["tid_off"]]
+    for lo, hi in zip(toff[:-1], toff[1:]):
+        fl = a["flag"][lo:hi]
+        assert fl[0] == ord("0") and fl[-1] == ord("1")
+        assert not np.any((fl[:-1] == ord("0")) & (fl[1:] == ord("0")))
+    return f0
+
+
+def test_full_size_config4_paired_end_50M_pairs():
+    """BASELINE config 4 at full size: 50 M mate pairs = 100 M reads x 150 bp as ONE pool (file-1 reads, then their mates:
+    reorder.h:233-242) through reorder with the library's defaults -> replay check of every matched record -> encoder stage
+    -> spring_order_pe_encode, with the size-independent properties of pe_encode.cpp:24-84: file-1 reads keep their
+    reordered rank among themselves, every mate sits exactly n / 2 behind its file-1 read."""
+    sa = _sa()
+    from spring_amd import order_ops as oo
+    from spring_amd.encoder import EncoderStage
+    npairs, L, T = 50_000_000, 150, 8
+    n = 2 * npairs
+    with sa.ReorderStage(sa.ReorderOpts(num_thr=T, phases=-1)) as st:
+        st.load_synth(n, L, n * L // 25, 17, 10000 | sa.SYNTH_PAIRED)
+        a = st.run().streams()
+        read, ln = st.download_reads()
+        with EncoderStage() as enc:
+            info = enc.encode(st)
+            order = enc.streams()["order"]
+    assert a["stats"]["phases"] == 2 and a["stats"]["chains"] == 65536
+    f0 = _perm_and_flags(a, n, L)
+    c = po.check_contigs(read, ln, L, a)
+    assert c["bad"] == 0 and c["contigs"] == int(f0.sum()) and c["matches"] == len(a["order"]) - c["contigs"], c
+    del read, ln
+    assert len(order) == n and info["num_contigs"] > 0
+    new, _ = oo.pe_encode(order)
+    pos_of = np.empty(n, np.uint32)
+    pos_of[order] = np.arange(n, dtype=np.uint32)   # (also: the encoder's read_order is a permutation)
+    f1 = order < npairs
+    assert int(f1.sum()) == npairs
+    assert np.array_equal(new[f1], np.arange(npairs, dtype=np.uint32))
+    assert np.array_equal(new[~f1], new[pos_of[order[~f1] - npairs]] + npairs)
+
+
+def test_pool_200M_reads_one_rank_rccl():
+    """Half of BASELINE config 5's pool (200 M x 150 bp, 262 144 chains) through the multi-GPU path -- spring_reorder_mg_run,
+    the per-round exchange an in-place ncclAllGather on a 1-rank RCCL communicator: permutation and flag invariants over the
+    whole output, the replay check on the records of one tid."""
+    from spring_amd.pool import DistPool, OneRankComm
+    sa = _sa()
+    n, L, T, K = 200_000_000, 150, 8, 262_144
+    comm = OneRankComm(0)
+    try:
+        dp = DistPool(comm, K, num_thr=T)
+        try:
+            st = dp.run(lambda s: s.load_synth(n, L, n * L // 25, 13, 10000))
+            a = dp.streams()
+            read, ln = dp.stage.download_reads()
+        finally:
+            dp.close()
+    finally:
+        comm.close()
+    assert st["chains"] == K and st["n_matched"] + st["n_single"] == n
+    _perm_and_flags(a, n, L)
+    toff = [int(x) for x in a["tid_off"]]
+    lo, hi = toff[3], toff[4]
+    one = {k: a[k][lo:hi] for k in ("order", "rc", "flag", "pos")}
+    one["tid_off"] = np.array([0, hi - lo], np.uint64)
+    c = po.check_contigs(read, ln, L, one)
+    assert c["bad"] == 0 and c["matches"] == (hi - lo) - c["contigs"] and c["contigs"] > 0, c
+
+
 @pytest.mark.slow
 def test_parity_10M_reads():
     """10 M x 150 bp (auto chains, 8 output sets): every reorder stream, the per-tid offsets and the reference-

@@ -151,3 +151,70 @@ def test_refused_where_it_cannot_run():
             st.build_dict()
             with pytest.raises(sa.ReorderError):
                 st.run_chains()
+
+
+# ---- two chain groups in the multi-GPU pool path: a rank owns a slice of EACH group, so the groups -- and the output -- are the
+# same whatever the number of ranks ("same K => same output for G = 1, 2, 4, 8").  G virtual ranks on one device.
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+@pytest.mark.parametrize("K,fused,kw", [(8192, 3, dict(phases=2)), (6144, 0, dict(phases=2)), (16384, 3, dict(phases=-1)),
+                                        (16384, 0, dict(phases=-1, collect_stats=True)),
+                                        (8192, 0, dict(phases=2, alternatives=2, deep_bins=1))])
+def test_pool_with_two_groups_is_independent_of_gpu_count(G, K, fused, kw):
+    """phases = 2 asked for, and phases = -1 (the library's choice: two groups from 16 384 chains on -- NOT pinned to one group
+    as the older pool tests are): G ranks == one context == the two-group oracle, every stream and the per-tid offsets; the
+    counting build's work counters add up over the ranks."""
+    from spring_amd.pool import VirtualPool
+    sa = _sa()
+    n, L, T = 60_000, 100, 3
+    A = kw.get("alternatives", 1)
+    gen = n * L // (400 if A == 2 else 25)
+    okw = dict(deep_bins=-1, fused=fused)
+    okw.update(kw)
+    with sa.ReorderStage(sa.ReorderOpts(num_chains=K, num_thr=T, **okw)) as st:
+        st.load_synth(n, L, gen, 23, 10000)
+        single = st.run().streams()
+        dna = st.download_dna()
+    assert single["stats"]["phases"] == 2 and single["stats"]["chains"] == K
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds_ph(read, ln, L, K, T, A)
+    _same(single, want, ("single", K, kw))
+    vp = VirtualPool(G, K, T, **okw)
+    try:
+        got = vp.run(lambda s: s.load_synth(n, L, gen, 23, 10000))
+    finally:
+        vp.close()
+    assert all(int(ps["phases"]) == 2 for ps in got["per_rank_stats"])
+    for k in KEYS:
+        assert np.array_equal(got[k], want[k]), (G, K, k)
+    assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"])
+    if kw.get("collect_stats"):
+        for k in ("probes", "keyok", "cands", "hits", "unmatched", "lost"):
+            assert sum(int(ps[k]) for ps in got["per_rank_stats"]) == want["stats"][k], (k, G)
+
+
+@pytest.mark.parametrize("devices", [(), (0, 0), (0, 0, 0, 0)])
+def test_call_reorder_device_lists_at_the_default_schedule(tmp_path, devices):
+    """The drop-in with the library's own choice of the schedule (phases = -1; two groups at this chain count) on one device
+    and on device lists: ONE file set, the two-group oracle's -- the default output no longer depends on the number of GPUs."""
+    from test_gpu_parity import _check_file_set, _read_file_set
+    from spring_amd.reorder import CompressionParams
+    sa = _sa()
+    n, L, K, T = 200_000, 100, 16384, 5
+    dna = sa.synth_dna_host(n, L, n * L // 25, 31, 10000)
+    (tmp_path / "input_clean_1.dna").write_bytes(dna)
+    sa.call_reorder(str(tmp_path), CompressionParams(L, [n, 0], num_thr=T), sa.ReorderOpts(num_chains=K, num_thr=T, phases=-1, devices=devices))
+    read, ln = po.load_dna(dna, n, L)
+    want = po.reorder_rounds_ph(read, ln, L, K, T)
+    _check_file_set(_read_file_set(tmp_path, T), want, read, ln, L, T)
+
+
+def test_default_chain_count_is_a_multiple_of_2048_where_two_groups_run():
+    """From 16 384 chains on the default chain count is a multiple of 2048, so a pool over 2, 4 or 8 GPUs cuts it into the same
+    two groups as one GPU does (spring_reorder_auto_chains)."""
+    sa = _sa()
+    with sa.ReorderStage(sa.ReorderOpts(phases=-1)) as st:
+        st.load_synth(20_000_000, 100, 20_000_000 * 100 // 25, 5, 10000)
+        st.build_dict()
+        k, _ = st.auto_chains()
+    assert k == (20_000_000 >> 10) // 2048 * 2048

@@ -98,10 +98,10 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n, L, K, T, out = [int(os.environ[k]) for k in ("P_N", "P_L", "P_K", "P_T")] + [os.environ["P_OUT"]]
 comm = PoolComm(dist, torch.device("cuda", 0), transport="host")
-dp = DistPool(comm, K, num_thr=T, collect_stats=True)
+dp = DistPool(comm, K, num_thr=T, collect_stats=True, phases=int(os.environ.get("P_PH", "1")))
 st = dp.run(lambda s: s.load_synth(n, L, n * L // 25, 3, 10000))
 s = dp.streams()
-np.savez(os.path.join(out, "rank%%d.npz" %% rank), **{k: s[k] for k in ("order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s")})
+np.savez(os.path.join(out, "rank%%d.npz" %% rank), **{k: s[k] for k in ("order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s", "tid_mid", "tid_mid_s")})
 print("RESULT " + json.dumps({"rank": rank, "rounds": int(st["rounds"]), "probes": int(st["probes"]), "hits": int(st["hits"])}), flush=True)
 dp.close()
 comm.close()
@@ -110,20 +110,21 @@ dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,L,K,T", [(200_000, 100, 64, 3), (300_000, 150, 500, 1)])
-def test_one_pool_two_processes_one_gpu(tmp_path, n, L, K, T):
+@pytest.mark.parametrize("n,L,K,T,PH", [(200_000, 100, 64, 3, 1), (300_000, 150, 500, 1, 1), (200_000, 100, 8192, 3, 2)])
+def test_one_pool_two_processes_one_gpu(tmp_path, n, L, K, T, PH):
     import spring_amd
     from oracle import pyoracle as po
     from spring_amd.pool import merge_rank_streams
     script = tmp_path / "pool_worker.py"
     script.write_text(POOL_WORKER)
-    outs = _spawn(script, 2, extra_env=dict(P_N=str(n), P_L=str(L), P_K=str(K), P_T=str(T), P_OUT=str(tmp_path)))
+    # (PH = 2: the chains in two groups -- every process owns a slice of each group, two exchanges per round through the host)
+    outs = _spawn(script, 2, extra_env=dict(P_N=str(n), P_L=str(L), P_K=str(K), P_T=str(T), P_PH=str(PH), P_OUT=str(tmp_path)))
     res = sorted((json.loads([x for x in o.splitlines() if x.startswith("RESULT ")][0][7:]) for o in outs),
                  key=lambda d: d["rank"])
     assert res[0]["rounds"] == res[1]["rounds"] > 0
     per_rank = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
     got = merge_rank_streams(per_rank, T)
-    with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=K, num_thr=T, collect_stats=True)) as s:
+    with spring_amd.ReorderStage(spring_amd.ReorderOpts(device=0, num_chains=K, num_thr=T, collect_stats=True, phases=PH)) as s:
         s.load_synth(n, L, n * L // 25, 3, 10000)
         want = s.run().streams()
         dna = s.download_dna()
@@ -132,7 +133,7 @@ def test_one_pool_two_processes_one_gpu(tmp_path, n, L, K, T):
     assert res[0]["probes"] + res[1]["probes"] == want["stats"]["probes"]
     assert res[0]["hits"] + res[1]["hits"] == want["stats"]["hits"]
     read, ln = po.load_dna(dna, n, L)
-    orc = po.reorder_rounds(read, ln, L, K, T)
+    orc = po.reorder_rounds(read, ln, L, K, T) if PH == 1 else po.reorder_rounds_ph(read, ln, L, K, T)
     for k in ("order", "rc", "flag", "pos", "rlen", "order_s"):
         assert np.array_equal(got[k], orc[k]), ("oracle", k)
 
@@ -146,10 +147,11 @@ import torch.distributed as dist
 import spring_amd
 from spring_amd.pool import DistPool, PoolComm
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-n, L, K, T = 300_000, 150, 777, 4
+n, L, T = 300_000, 150, 4
 comm = PoolComm(dist, torch.device("cuda", 0), transport="rccl")
 ok = True
-for rep in range(2):                      # the communicator is reused by several runs
+for rep in range(3):                      # the communicator is reused by several runs; the last one runs two chain groups
+    K = 777 if rep < 2 else 16384         # (the library's choice at that chain count: the exchanges go through their own stream)
     dp = DistPool(comm, K, num_thr=T)
     dp.run(lambda s: s.load_synth(n, L, n * L // 25, 5 + rep, 10000))
     got = dp.streams()
@@ -158,6 +160,7 @@ for rep in range(2):                      # the communicator is reused by severa
         s.load_synth(n, L, n * L // 25, 5 + rep, 10000)
         want = s.run().streams()
     ok = ok and all(np.array_equal(got[k], want[k]) for k in ("order", "rc", "flag", "pos", "rlen", "order_s", "tid_off", "tid_off_s"))
+    ok = ok and got["stats"]["phases"] == want["stats"]["phases"] == (2 if rep == 2 else 1)
 comm.close()
 print("RESULT " + json.dumps({"ok": bool(ok)}), flush=True)
 dist.destroy_process_group()
