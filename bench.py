@@ -324,7 +324,8 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
     # one more pass with HIP events around the three pieces of a round (outside the timed region): where a round goes
     stt = one_pass(time_search=True)
     rounds = max(stt["search_launches"], 1)
-    budget = {"rounds": stt["rounds"],
+    groups = max(int(stt.get("phases", 1)), 1)
+    budget = {"rounds": stt["rounds"], "chain_groups": groups,
               "round_kernel_us": round(stt["ms_search_kernel"] * 1e3 / rounds, 1),
               "exchange_us": round(stt["ms_exchange"] * 1e3 / rounds, 1),
               "resolve_and_mark_us": round(stt["ms_resolve_mark"] * 1e3 / rounds, 1),
@@ -334,6 +335,21 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
               "what": "rank 0, per round: k_round over the rank's own chains | all-gather of the proposal words | "
                       "k_mg_resolve + k_mg_mark over ALL chains (replicated work, grows with N); replicated_ms is work every "
                       "rank repeats for the whole pool"}
+    if groups == 2:
+        # two chain groups: a rank owns a slice of each; a group's all-gather (on the exchange stream), resolve and mark run
+        # beside the OTHER group's round kernel.  round_kernels_busy_ms = the time during which at least one round kernel of
+        # the rank ran (union of the launches' intervals); chains_ms beyond it is what the exchange + resolve + mark still
+        # cost the critical path.  resolve_and_mark_us includes the mark step's wait for the other group's mark step.
+        busy = stt.get("ms_search_busy") or 0.0
+        budget.update({
+            "per": "group-round (a round of one chain group: half of the rank's chains)",
+            "round_kernels_busy_ms": round(busy, 1),
+            "off_the_round_kernels_ms": round(max(stt["ms_chains"] - busy, 0.0), 1),
+            "off_the_round_kernels_frac": round(max(stt["ms_chains"] - busy, 0.0) / max(stt["ms_chains"], 1e-9), 4),
+            "what": "rank 0, per group-round: k_round over the rank's slice of the group | in-place all-gather of the group's proposal "
+                    "words on the exchange stream | k_mg_resolve + the group's mark step over the whole group (replicated), which "
+                    "also waits for the other group's mark step; these run beside the other group's round kernel: chains_ms - "
+                    "round_kernels_busy_ms is what they leave on the critical path (timed pass: a batch of rounds at a time)"})
     # the single-GPU rate on the SAME pool and chain count (rank 0 alone, the others wait): what `value` is to be divided by
     single = None
     if world > 1 and not a.no_single:
@@ -350,8 +366,8 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
                 single = {"value": round(n / t1 / 1e6, 3), "unit": "Mreads/s", "seconds": round(t1, 3), "rounds": s1s["rounds"],
                           "chain_groups": int(s1s.get("phases", 1)),
                           "what": "the same pool and chain count on rank 0's GPU alone (one pass incl. allocations), with the "
-                                  "library's choice of the schedule: one GPU alone runs the chains in two groups whose rounds "
-                                  "alternate (DESIGN.md section 2), the pool one group (section 7)"}
+                                  "library's choice of the schedule (two chain groups whose rounds alternate, in the pool as well: "
+                                  "the same output)"}
             except Exception as e:  # noqa: BLE001
                 single = {"error": repr(e)}
         lanes.barrier()
@@ -362,9 +378,9 @@ def _pool_run(a, lanes, torch, spring_amd, L_):
         "config": {
             "workload": "ONE shared pool of %d x %d bp single-end synthetic reads, the same for every N (uniform genome "
                         "%d bp, %dx coverage, %.1f%% substitutions, 50%% reverse-complemented), resident in HBM on every GPU "
-                        "as .dna records; %d chains sharded over %d GPUs, one RCCL all-gather of %d proposal bytes per round "
-                        "issued by the library on its stream"
-                        % (n, L, G, a.coverage, a.err_ppm / 1e4, Ktot, world, Ktot * 8),
+                        "as .dna records; %d chains sharded over %d GPUs (%d chain group%s: a rank owns a slice of each), RCCL all-gathers of "
+                        "%d proposal bytes per round issued by the library on its exchange stream"
+                        % (n, L, G, a.coverage, a.err_ppm / 1e4, Ktot, world, int(st.get("phases", 1)), "s" if int(st.get("phases", 1)) > 1 else "", Ktot * 8),
             "exchange": exchange, "pool_reads": n, "read_len": L, "chains": Ktot, "num_thr": a.num_thr,
             "parallelism": "1 process per GPU, single shared pool: reads + dictionaries replicated, chains sharded, "
                            "all-gather per round (DESIGN.md section 7)",

@@ -28,91 +28,71 @@ extern "C" {
 
 typedef struct spring_reorder_ctx spring_reorder_ctx;
 
+/* Options.  Zero-initialise with spring_reorder_default_opts().  Three fields change the bytes written for num_chains > 1
+ * -- num_chains, alternatives, phases (stats reports what ran) --; every other field moves work
+ * between batches, kernels and table sizes only and is covered by a parity test at a non-default value
+ * (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results).  How the library makes its own choices: DESIGN.md
+ * section 3 (one table of every threshold). */
 typedef struct {
-  int32_t device;       /* HIP device ordinal; -1 = current device                                */
-  uint32_t num_chains;  /* K concurrent greedy chains (= reference threads, reorder.h:351);
-                           1 reproduces `-t 1` byte for byte; 0 = auto: N/1024, or N/128 when the
-                           dictionary averages >= 1.3 reads per key (deep coverage); at most 65536, deep coverage 131072 */
-  int32_t num_thr;      /* number of per-tid output sets to emit (cp.num_thr, reorder.h:748)      */
-  int32_t collect_stats;/* 1: count reference-equivalent probes / key hits / Hamming evaluations  */
-  int32_t time_search;  /* 1: bracket every search-kernel launch with HIP events (bench roofline) */
-  int32_t force_literal_update; /* 1: consensus update always through the literal lane-0 path (tests) */
-  int32_t rounds_per_sync;      /* rounds enqueued between host termination checks; 0 = auto      */
-  int32_t long_budget;          /* deep-bin kernel variant: 64-lane compare passes a wavefront spends on one search before the
-                                   search is handed to a block of 16 wavefronts (k_long).  0 = default: 8, and only on pools of
-                                   very deep bins (a quarter of the dictionary's reads in bins of >= 256 entries) and only for
-                                   searches with >= 2048 bin entries still ahead; > 0: on whenever that variant runs (values
-                                   below 8 hand over unconditionally: tests); -1 = never.  Same results for every value. */
-  /* ---- tuning / experiments (0 = default).  The output does not depend on any of them; each non-default
-   * setting is covered by a parity test (tests/test_gpu_parity.py::test_tuning_opts_do_not_change_results). */
-  int32_t first_shifts;   /* a search probes shifts in ordered batches of k and 16, then all the rest at once: k = 1..16;
-                             0 = default (4 + 8 + 16 with four chains per wavefront, 8 + 16 with one, 2 + 6 + 8 + 16 on
-                             deep-coverage pools); -1: batches of 4, 4, 8, 8 (fewer wasted requests, more round trips: slower) */
-  int32_t seed_wide;      /* -1: off; else a chain whose seed is still unmatched probes in batches of 16, 16 */
-  int32_t tab_scale;      /* dictionary table size multiplier 1 / 2 / 4 (default 2: load <= 0.2)           */
-  int32_t search_wpb;     /* chains (wavefronts) per block of the search kernel: 1 / 2 / 4                 */
-  int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per search block  */
-  int32_t dbg_apply_lds;  /* same for the apply kernel                                                     */
-  int32_t fused;          /* -1: two chain kernels per round (search, apply); else one (apply + search) + mark.  0: the mapping
-                             is chosen from the run (four chains per wavefront, k_round_mc, on shallow dictionaries with at
-                             least 32 768 chains -- 49 152 when the chains run as one group --; else one chain per wavefront, k_round); 2: always one chain per wavefront;
-                             3: four chains per wavefront wherever that kernel applies, whatever the chain count (tests) */
-  int32_t deep_bins;      /* 0: auto (from the dictionary); 1 / -1: chain kernel variant that trims dead bin tails in its scans on / off */
-  /* ---- spring_reorder_run on several GPUs of one node (one read pool; spring_reorder_encode_run
-   * runs on `device` alone and rejects num_devices >= 2):
-   * num_devices >= 2 runs the stage on devices[0 .. num_devices) -- one host thread and one context per entry inside
-   * the library, the reads loaded on every device, the chains sharded, one RCCL all-gather per round -- and writes the
-   * merged per-tid file set.  The output equals the single-device output with the same num_chains and phases = 1 -- the
-   * pool runs the chains as one group, stats.phases says so -- (the default chain
-   * count is rounded up to a multiple of num_devices).  0 / 1: `device` alone.  An entry may repeat a device (tests on a
-   * one-GPU box): the exchange then goes through host memory, as it does with mg_host_transport = 1. */
+  int32_t device;       /* HIP device ordinal; -1 = current device */
+  uint32_t num_chains;  /* K concurrent greedy chains (= reference threads, reorder.h:351); 1 reproduces `-t 1` byte for
+                           byte; 0 = the library's choice (spring_reorder_auto_chains) */
+  int32_t num_thr;      /* number of per-tid output sets to emit (cp.num_thr, reorder.h:748) */
+  int32_t collect_stats;/* 1: count reference-equivalent probes / key hits / Hamming evaluations (slower kernels) */
+  int32_t time_search;  /* 1: HIP events around every round-kernel launch (bench roofline) */
+  int32_t force_literal_update; /* 1: consensus update through the literal lane-0 restatement of reorder.h:133-212 (tests) */
+  int32_t rounds_per_sync;      /* rounds enqueued between host looks at the running chains; 0 = auto */
+  int32_t long_budget;  /* deep-bin pools: compare passes a wavefront spends on one search before the search goes to the
+                           long-search kernels; 0 = the library's choice (8, on pools of very deep bins only), > 0: on
+                           whenever the deep-bin kernel runs, -1 = never */
+  /* ---- tuning / experiments: 0 = default, the output does not depend on any of them */
+  int32_t first_shifts;   /* ordered probe batches of k and 16 shifts, then the rest at once: k = 1..16; -1: 4, 4, 8, 8 */
+  int32_t seed_wide;      /* -1: a chain whose seed is still unmatched uses plan0 as well (default: plan1 = 16, 16) */
+  int32_t tab_scale;      /* dictionary table size multiplier 1 / 2 / 4 (default 2: load <= 0.2) */
+  int32_t search_wpb;     /* two-kernel round: chains (wavefronts) per block of the search kernel: 1 / 2 / 4 */
+  int32_t dbg_search_lds; /* occupancy experiment: dummy LDS bytes per round / search block */
+  int32_t dbg_apply_lds;  /* same for the apply kernel */
+  int32_t fused;          /* 0: fused round kernel, mapping chosen from the run; -1: two kernels per round (search, apply);
+                             2: one chain per wavefront always; 3: four chains per wavefront wherever that kernel applies */
+  int32_t deep_bins;      /* 0: from the dictionary; 1 / -1: the kernel variants with the deep-bin machinery on / off */
+  /* ---- spring_reorder_run on several GPUs of one node: one read pool over devices[0 .. num_devices),
+   * one host thread and context per entry inside the library, merged per-tid file set; the output equals the single-device
+   * output with the same num_chains / alternatives / phases -- and with the library's own choices when the default chain
+   * count is a multiple of num_devices (it is for 2, 4, 8 devices from 16 384 chains on).  0 / 1: `device` alone.  An entry
+   * may repeat a device (tests): the exchange then goes through host memory, as with mg_host_transport = 1.
+   * spring_reorder_encode_run runs on `device` alone and rejects num_devices >= 2. */
   int32_t num_devices;
   int32_t devices[8];
   int32_t mg_host_transport;
-  int32_t table_mode;     /* dictionary table addressing (same results): 0 / 1 = by the key's hash; 2 = by the key's minimizer
-                             where that applies (32-base windows, reads of 100..192 bases): consecutive windows of a
-                             consensus share cache lines -- 60 % fewer memory requests per round, the same run time
-                             (DESIGN.md section 6), a dictionary stage twice as long: an experiment, not the default */
-  /* ---- more experiment switches (all 0 = default, none changes the output; they used to be environment variables) */
-  int32_t plan0[6];       /* ordered probe batches of a search, in shifts: up to six widths of 1..16, sum <= 32, 0-terminated
-                             (e.g. {4, 8, 16}); the tail covers the remaining shifts.  plan1: the same for a chain whose seed
-                             has no match yet.  An empty plan = the library's choice (first_shifts, kernel, dictionary depth) */
+  int32_t table_mode;     /* 0 / 1: table addressed by the key's hash; 2: by its minimizer where that applies (32-base windows,
+                             reads of 100..192 bases, four-chain kernel without known-absent masks): an experiment */
+  int32_t plan0[6];       /* ordered probe batches of a search in shifts: up to six widths of 1..16, sum <= 32, 0-terminated;
+                             empty = the library's choice.  plan1: for a chain whose seed has no match yet */
   int32_t plan1[6];
-  int32_t long_min;       /* k_long: bin entries that must still be ahead of a search for it to be handed over (0 = default 2048) */
-  int32_t long_blocks;    /* long searches: the grids of k_long_list / k_long_scan are 1-3 x / 5 x this many blocks (0 = default 256, the CUs) */
+  int32_t long_min;       /* long searches: bin entries that must still be ahead of a search for it to be handed over (0 = 512) */
+  int32_t long_blocks;    /* long searches: grid unit of the long-search kernels (0 = 256, the CUs) */
   int32_t debug;          /* 1: stage / phase timings on stderr */
-  int32_t long_split;     /* long searches (k_long_list / k_long_scan / k_long_fin): a search whose bins hold more than this many
-                             chunks of 64 entries within reach of the first turn is cut into parts (ranges of its bins, up to 64)
-                             that are scanned by a block each; 0 = default (256), -1 = never cut.  Same results for every value */
-  int32_t entry_flags;    /* deep-bin pools: -1 = the bin entries do not carry their read's taken bit (the scans ask the bitmap, as
-                             before round 4); 0 = they do.  Same results either way */
-  int32_t out_writers;    /* spring_reorder_run: threads that write the output files (each file belongs to one of them);
-                             0 = a quarter of the host's hardware threads, at least 4, at most 24 */
-  int32_t alternatives;   /* candidates per match proposal (specification: orc_reorder_rounds_alt).  1: a chain that
-                             loses its proposed read to a lower chain id searches again next round.  2: the search also records the
-                             next passing read of the winning bin -- what the reference's thread tries next after losing the
-                             read_lock race (reorder.h:303-311) -- and a second resolution pass hands it to the loser: fewer lost
-                             proposals, fewer rounds on contended (deep-coverage) pools.  The OUTPUT DEPENDS on it for
-                             num_chains > 1 (both are legal `-t K` interleavings; num_chains = 1 is the `-t 1` order either way).
-                             0 (or negative) = the library's choice, reported in stats.alternatives: 2 on contended pools -- a
-                             quarter of the dictionary's reads in bins of >= 64 entries (coverage of tens of thousands x,
-                             PhiX-like pools: -10 ... -14 % of the chain stage) --, else 1 (a second candidate costs every
-                             successful search another look at its bin).  Needs fused rounds and fewer than 2^27 - 1 reads; 2
-                             on a shallower pool runs the deep-bin kernel variant */
-  int32_t phases;         /* the chain schedule.  1: all chains advance in lock-step rounds (specification:
-                             orc_reorder_rounds).  2: the chains run as two groups whose rounds alternate -- one group's round kernel
-                             runs beside the other group's, so the chip is never left draining between rounds (specification:
-                             orc_reorder_rounds_ph; -19 % of the chain stage on 100 M x 150 bp).  A group searches on the pool as it
-                             was after its own last round and loses a read the other group took in between; group 0 takes its
-                             contig seeds from the upper half of the read ids, group 1 from the lower half.  The OUTPUT DEPENDS on
-                             it for num_chains > 1 (both are legal `-t K` interleavings).  0 = the library's choice, reported in
-                             stats.phases: 2 from 16 384 chains on for shallow dictionaries, at 131 072 chains for deep-coverage pools (not on
-                             contended ones, and not where the long searches of a pool go to the long-search kernels), else 1.  2 needs the fused round, one GPU
-                             (a device list / a multi-GPU pool runs one group), at least 4 096 chains and 8 192 .. 2^31 - 1 reads, not fewer reads
-                             than chains */
-  int32_t known_absent;   /* four-chain round kernel, reads up to 192 bases: a chain remembers which windows of its consensus are
-                             known to be absent from the dictionaries (the table is immutable, so the answer holds while the
-                             bases under a window do) and later searches skip them.  0 = on, -1 = off.  Same results either way */
+  int32_t long_split;     /* long searches: chunks of 64 bin entries per part (0 = 192, -1 = never cut a search into parts) */
+  int32_t entry_flags;    /* deep-bin pools: -1 = bin entries do not carry their read's taken bit (the scans ask the bitmap) */
+  int32_t out_writers;    /* spring_reorder_run: threads that write the output files; 0 = hardware threads / 4, in [4, 24] */
+  int32_t alternatives;   /* candidates per match proposal (specification: orc_reorder_rounds_alt).  1: a chain that loses its
+                             proposed read searches again next round.  2: the search also records the next passing read of the
+                             winning bin -- what the reference's thread tries next after losing the read_lock race
+                             (reorder.h:303-311) -- and a second resolution pass hands it to the loser.  Both are legal `-t K`
+                             interleavings; THE OUTPUT DEPENDS ON IT for num_chains > 1.  <= 0: the library's choice (2 on
+                             contended pools), reported in stats.alternatives.  2 needs fused rounds and < 2^27 - 1 reads */
+  int32_t phases;         /* chain groups (specifications: orc_reorder_rounds, orc_reorder_rounds_ph).  1: all chains advance
+                             in lock-step rounds.  2: the chains run as two groups whose rounds alternate, one group's round
+                             kernel beside the other's; a group searches on the pool as it was after its own last round and
+                             loses a read the other group took in between; group 0 takes its contig seeds from the upper half
+                             of the read ids, group 1 from the lower half.  That seed rule is a deliberate deviation: a
+                             deterministic, decodable schedule, NOT something reference threads can do (they scan the whole
+                             pool from the top, reorder.h:576-599).  THE OUTPUT DEPENDS ON IT for num_chains > 1.  <= 0: the
+                             library's choice, reported in stats.phases, the same on one GPU and in a pool.  2 needs the fused
+                             round, >= 4096 chains, 8192 .. 2^31 - 1 reads, not fewer reads than chains; in a pool over G GPUs
+                             both groups' chain counts must be multiples of 256 G */
+  int32_t known_absent;   /* four-chain round kernel, reads up to 192 bases: chains remember which windows of their consensus
+                             are known absent from the dictionaries and skip them (the table is immutable).  0 = on, -1 = off */
 } spring_reorder_opts;
 
 typedef struct {

@@ -2196,7 +2196,7 @@ static int mg_run_phased(spring_reorder_ctx *ctx, spring_mg_comm *comm) {
   HIPCHK(hipStreamWaitEvent(sx, ev0, 0));
   bool have_b = false;
   uint64_t rounds = 0, timed_rounds = 0;
-  double ms_round = 0, ms_xchg = 0, ms_mark = 0;
+  double ms_round = 0, ms_xchg = 0, ms_mark = 0, ms_busy = 0;
   auto fail_sync = [&](int code) {  // (nothing of this run may still be queued when the caller tears the context down)
     (void)hipStreamSynchronize(sg[0]); (void)hipStreamSynchronize(sg[1]); (void)hipStreamSynchronize(sx);
     return code;
@@ -2267,13 +2267,26 @@ static int mg_run_phased(spring_reorder_ctx *ctx, spring_mg_comm *comm) {
       HIPCHK(hipStreamSynchronize(sg[0]));
       HIPCHK(hipStreamSynchronize(sg[1]));
       if (timed) {
+        // per group-round: round kernel | all-gather (from the end of the round kernel to the end of the collective on the exchange
+        // stream) | resolve + mark (incl. the wait for the other group's mark step); and the union of the round kernels'
+        // intervals: the time during which at least one round kernel ran -- the rank's critical path if everything else hides
+        std::vector<std::pair<float, float>> iv(2 * (size_t)R);
         for (int i = 0; i < 2 * R; i++) {
-          float a = 0, b = 0, c = 0;
+          float a = 0, b = 0, c = 0, s0 = 0;
           (void)hipEventElapsedTime(&a, tev[4 * i], tev[4 * i + 1]);
           (void)hipEventElapsedTime(&b, tev[4 * i + 1], tev[4 * i + 2]);
           (void)hipEventElapsedTime(&c, tev[4 * i + 2], tev[4 * i + 3]);
+          (void)hipEventElapsedTime(&s0, tev[0], tev[4 * i]);
           ms_round += a; ms_xchg += b; ms_mark += c;
+          iv[(size_t)i] = {s0, s0 + a};
         }
+        std::sort(iv.begin(), iv.end());
+        float cs = iv[0].first, ce = iv[0].second;
+        for (size_t i = 1; i < iv.size(); i++) {
+          if (iv[i].first > ce) { ms_busy += ce - cs; cs = iv[i].first; ce = iv[i].second; }
+          else ce = std::max(ce, iv[i].second);
+        }
+        ms_busy += ce - cs;
         timed_rounds += (uint64_t)R;
       }
       if (!alive_in(0)) break;
@@ -2298,7 +2311,7 @@ static int mg_run_phased(spring_reorder_ctx *ctx, spring_mg_comm *comm) {
   ctx->round_no = round_no[0];
   ctx->stats.rounds = rounds;
   if (timed) {  // (per group-round: the pieces of both groups are summed; two round kernels run side by side most of the time)
-    ctx->stats.ms_search_kernel = ms_round; ctx->stats.ms_search_busy = ms_round; ctx->stats.search_launches = 2 * timed_rounds;
+    ctx->stats.ms_search_kernel = ms_round; ctx->stats.ms_search_busy = ms_busy; ctx->stats.search_launches = 2 * timed_rounds;
     ctx->stats.ms_exchange = ms_xchg; ctx->stats.ms_resolve_mark = ms_mark;
   }
   return 0;

@@ -46,7 +46,7 @@ class ReorderOpts:
     long_min: int = 0
     long_blocks: int = 0
     entry_flags: int = 0      # -1: deep-bin scans ask the taken bitmap instead of reading the flag in the bin entry (A/B)
-    long_split: int = 0       # long searches: chunks of 64 bin entries per part (0 = default 256, -1 = never cut a search into parts)
+    long_split: int = 0       # long searches: chunks of 64 bin entries per part (0 = default 192, -1 = never cut a search into parts)
     debug: bool = False       # stage timings on stderr
     out_writers: int = 0      # call_reorder: threads writing the output files (0 = from the host's thread count)
     alternatives: int = 0     # candidates per match proposal: 1, 2 (a loser takes the next passing read of the bin), 0 = library's choice
