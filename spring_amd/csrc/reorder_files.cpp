@@ -199,7 +199,11 @@ class Ring {  // a bounded set of pinned slots, cut from the library's cached pi
       if (!free_.empty()) { *out = free_.back(); free_.pop_back(); return true; }
       if ((int)chunks_.size() < cap_) {
         void *c = sr::pinned_get();
-        if (!c) return false;
+        if (!c) {
+          if (chunks_.empty()) return false;   // not a single chunk can be pinned
+          cap_ = (int)chunks_.size();          // no more pinned memory: carry on with the slots there are
+          continue;
+        }
         chunks_.push_back(c);
         for (int i = SLOTS_PER_CHUNK - 1; i >= 0; i--) {
           Slot s;
@@ -513,7 +517,8 @@ int write_out_files(const std::vector<OutFile> &files, int nw, bool dbg) {
     mine[w].push_back(i);
     load[w] += files[i].total() + 4096;
   }
-  Ring ring(16);  // 16 x 32 MiB = 64 slots in flight at most
+  // as many slots as the writers may hold in flight (MAX_INFLIGHT each) plus one chunk for the copies on their way
+  Ring ring((nw * 3 + SLOTS_PER_CHUNK - 1) / SLOTS_PER_CHUNK + 1);
   // one flag per copy, one waiting thread per stream the copies are issued on (a multi-GPU call: one per rank)
   size_t ncopies = 0;
   std::vector<hipStream_t> streams;
@@ -548,7 +553,7 @@ int write_out_files(const std::vector<OutFile> &files, int nw, bool dbg) {
   SubmitClock clk;
   double t_pace = 0;
   const auto t_begin = std::chrono::steady_clock::now();
-  constexpr int MAX_INFLIGHT = 3;
+  constexpr int MAX_INFLIGHT = 3;  // (the ring above is sized for nw x 3)
   for (;;) {
     int w = -1;
     bool any = false;

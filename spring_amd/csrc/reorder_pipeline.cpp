@@ -1428,23 +1428,10 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   const uint64_t nublk = std::max<uint64_t>(((uint64_t)n + (1u << UBLK_SHIFT) - 1) >> UBLK_SHIFT, 1);
   const uint64_t nwords = nublk << (UBLK_SHIFT - 6);
   const size_t nn = std::max<uint32_t>(n, 1);
-  DMALLOC(P.taken, nwords * 8);
-  DMALLOC(P.ublk, nublk * 4);
-  DMALLOC(P.resv, nn * 4);
-  const size_t needy_bytes = (((size_t)Ktot + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
-  DMALLOC(P.needy, needy_bytes);
-  DMALLOC(P.glob, sizeof(Globals));
-  P.cursor = &P.glob->cursor;
-  DMALLOC(P.chains, (size_t)K * sizeof(Chain));
-  DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
-  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t) + 64);  // (k_round_mc reads whole quads: up to 12 bytes past a column)
-  // append buffers: n records + one partly filled CHUNK per chain
-  const size_t cap = (size_t)n + (size_t)K * CHUNK;
-  if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
-  ctx->cap = cap;
-  const size_t nchunk = cap / CHUNK + 2;
-  DMALLOC(P.e_rec, cap * sizeof(uint4)); DMALLOC(P.e_chunk, nchunk * sizeof(uint2));
-  DMALLOC(P.s_rec, cap * 4); DMALLOC(P.s_chunk, nchunk * sizeof(uint2));
+  // options whose values are refused: before anything is allocated
+  if (ctx->o.alternatives > 2) return fail(SPRING_REORDER_E_ARG, "alternatives: <= 0 (library's choice), 1 or 2");
+  if (ctx->o.phases > 2) return fail(SPRING_REORDER_E_ARG, "phases: <= 0 (library's choice), 1 or 2");
+  // (every refusal of an option combination happens here, before the allocations)
   P.K = K; P.c0 = c0; P.Ktot = Ktot;
   P.fused = fused ? 1 : 0;
   // candidates per match proposal (opts.alternatives): the second one travels in the proposal word beside the first
@@ -1513,6 +1500,23 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
     }
     ctx->stats.phases = (uint64_t)P.phases;
   }
+  DMALLOC(P.taken, nwords * 8);
+  DMALLOC(P.ublk, nublk * 4);
+  DMALLOC(P.resv, nn * 4);
+  const size_t needy_bytes = (((size_t)Ktot + 31) / 32 + 255) / 256 * 256 * 4;  // find_seed reads whole 256-word groups
+  DMALLOC(P.needy, needy_bytes);
+  DMALLOC(P.glob, sizeof(Globals));
+  P.cursor = &P.glob->cursor;
+  DMALLOC(P.chains, (size_t)K * sizeof(Chain));
+  DMALLOC(P.cnt, (size_t)K * 2 * ctx->Lpad * sizeof(int4));
+  DMALLOC(P.cnt8, (size_t)K * 2 * ctx->Lpad * sizeof(uint32_t) + 64);  // (k_round_mc reads whole quads: up to 12 bytes past a column)
+  // append buffers: n records + one partly filled CHUNK per chain
+  const size_t cap = (size_t)n + (size_t)K * CHUNK;
+  if (cap > 0xfffffff0ull) return fail(SPRING_REORDER_E_ARG, "n + K*%u exceeds the 32-bit slot space", CHUNK);
+  ctx->cap = cap;
+  const size_t nchunk = cap / CHUNK + 2;
+  DMALLOC(P.e_rec, cap * sizeof(uint4)); DMALLOC(P.e_chunk, nchunk * sizeof(uint2));
+  DMALLOC(P.s_rec, cap * 4); DMALLOC(P.s_chunk, nchunk * sizeof(uint2));
   P.mc = ctx->o.fused == 2 ? 0 : 1;  // opts.fused = 2: one chain per wavefront everywhere (A/B, tests)
   // Four chains per wavefront pay when a launch holds several wavefronts per slot (5 120 slots of four chains): with
   // fewer chains the GPU is not full and every wavefront waits for the slowest of its four.  25x, chains stage, four
@@ -1719,6 +1723,12 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
   uint32_t *h_aw = nullptr;
   HIPCHK(hipHostMalloc((void **)&h_aw, 2 * nw * sizeof(uint32_t), hipHostMallocDefault));
   struct HostFree { void *p; ~HostFree() { if (p) (void)hipHostFree(p); } } h_aw_guard{h_aw};
+  // an error half way leaves work queued on all three streams: nothing of the run may be in flight when the events and the
+  // pinned buffer above go (this guard is destroyed before them)
+  struct SyncOnError {
+    spring_reorder_ctx *c; bool ok;
+    ~SyncOnError() { if (!ok) { (void)hipStreamSynchronize(c->st2); (void)hipStreamSynchronize(c->st3); (void)hipStreamSynchronize(c->st); } }
+  } sync_guard{ctx, false};
   // group 1 starts behind the set-up (on the context's stream) and half a round late
   HIPCHK(hipEventRecord(ev0, sg[0]));
   HIPCHK(hipStreamWaitEvent(sg[1], ev0, 0));
@@ -1819,6 +1829,7 @@ static int run_chains_phased(spring_reorder_ctx *ctx, int R, bool timed) {
   ctx->stats.ms_search_kernel = ms_search;
   ctx->stats.ms_search_busy = ms_busy;
   ctx->stats.search_launches = launches;
+  sync_guard.ok = true;
   return 0;
 }
 
