@@ -1523,18 +1523,27 @@ static int setup_chains(spring_reorder_ctx *ctx, uint32_t K, uint32_t c0, uint32
   // chains / one chain per wavefront: 4 882 chains (5 M reads) 74 / 47 ms, 19 531 (20 M) 106 / 100, 39 062 (40 M)
   // 184 / 179, 65 536 (70 M) 282 / 293, 65 536 (100 M) 405 / 418 (tools/variant_probe2.py; at 60-100x the one-chain
   // kernel's lead below 40 000 chains is 5-16 %)
-  if (K < (P.phases == 2 ? 32768u : 49152u) && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
-  if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
   // known-absent window masks (reorder_round_mc.h: search_ka): reads up to 192 bases -- four limbs per strand in the spare
   // half of Chain::revref, the forward strand's from the limb of its first window (offsets dstart[0] .. L - wl)
-  P.ka = 0; P.ka_lo = 0;
-  if (P.mc && P.Lpad <= 192 && ctx->o.known_absent >= 0 && !ctx->minz) {
+  bool ka_ok = false;
+  int ka_lo = 0;
+  if (P.Lpad <= 192 && ctx->o.known_absent >= 0 && !ctx->minz) {
     const int wlen = ctx->dict[0].end - ctx->dict[0].start + 1, lo = ctx->dict[0].start >> 5;
     if (wlen <= 32 && ctx->dict[1].start == ctx->dict[0].end + 1 && ctx->dict[1].end - ctx->dict[1].start + 1 == wlen &&
         2 * (ctx->L - wlen) + 2 <= 64 * (lo + 4) && 2 * ctx->dict[1].start + 2 <= 256 && lo + 4 <= 6) {
-      P.ka = 1; P.ka_lo = lo;
+      ka_ok = true; ka_lo = lo;
     }
   }
+  // Round 6, with the masks (chains stage, 25x pools, one chain / four chains per wavefront, two groups): 14 648 chains 82 / 79 ms,
+  // 18 432 99 / 101, 22 528 114 / 110, 28 672 130 / 112; at 100x (1.09 reads per key: most probes find their key, the masks
+  // save little) 108 / 129, 123 / 141, 131 / 139 -- so on very shallow dictionaries (< 1.05 reads per key) the four-chain
+  // kernel takes over at 20 480 chains instead of 32 768 (profiles/r06_mc_threshold.txt)
+  const uint64_t nd_ = (uint64_t)ctx->dict[0].numreads + ctx->dict[1].numreads, nk_ = (uint64_t)ctx->dict[0].numkeys + ctx->dict[1].numkeys;
+  const uint32_t mc_min = P.phases == 2 ? ((ka_ok && nd_ * 100 < nk_ * 105) ? 20480u : 32768u) : 49152u;
+  if (K < mc_min && ctx->o.fused != 3) P.mc = 0;   // (opts.fused = 3: four chains per wavefront whatever the count -- tests)
+  if (64 - ctx->bshift > 32) P.mc = 0;            // (k_round_mc keeps bucket indices in 32 bits)
+  P.ka = (P.mc && ka_ok) ? 1 : 0;
+  P.ka_lo = P.ka ? ka_lo : 0;
   if (ctx->minz && !(fused && P.mc && !ctx->o.collect_stats && !P.deep_bins))
     return fail(SPRING_REORDER_E_ARG, "table_mode = 2 (minimizer-addressed table) is an experiment of the four-chain round kernel: "
                 "shallow dictionary, at least 49152 chains or fused = 3, no work counters");
