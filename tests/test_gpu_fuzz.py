@@ -155,6 +155,35 @@ def test_fuzz_single_pool_virtual_ranks(block):
             assert np.array_equal(got[k], want[k]), ("seed", seed, "G", G, "K", K, k)
 
 
+@pytest.mark.parametrize("block", range(2))
+def test_fuzz_two_groups_over_virtual_ranks(block):
+    """Two chain groups in the pool path (a rank owns a slice of each group): random read sets of 8 192 .. 30 000 reads, 4 096 ..
+    12 288 chains cut into groups of unequal size, 2 or 4 virtual ranks, a random kernel variant (four chains / one chain per
+    wavefront, deep-bin machinery, one or two candidates per proposal) == the two-group oracle == whatever the rank count."""
+    from spring_amd.pool import VirtualPool
+    for seed in range(7600 + 5 * block, 7600 + 5 * (block + 1)):
+        dna, n, L, K, T = _random_case(seed, 8192, 30000, (4096, 6144, 8192, 12288))
+        if n < max(8192, K):
+            continue
+        rng = np.random.default_rng(seed + 9)
+        G = int(rng.choice([2, 4]))
+        A = int(rng.choice([1, 1, 2]))
+        deep = 1 if A == 2 else int(rng.choice([1, -1, -1]))
+        kw = dict(deep_bins=deep, alternatives=A, phases=2)
+        if deep != 1:
+            kw.update(fused=int(rng.choice([3, 3, 0, 2])))
+        read, ln = po.load_dna(dna, n, L)
+        want = po.reorder_rounds_ph(read, ln, L, K, T, alternatives=A)
+        vp = VirtualPool(G, K, T, **kw)
+        try:
+            got = vp.run(lambda s: s.load_dna(dna, n, L))
+        finally:
+            vp.close()
+        for k in KEYS:
+            assert np.array_equal(got[k], want[k]), ("seed", seed, "G", G, "K", K, kw, k)
+        assert np.array_equal(got["tid_off"], want["tid_off"]) and np.array_equal(got["tid_off_s"], want["tid_off_s"]), ("seed", seed, G)
+
+
 @pytest.mark.parametrize("block", range(max(_BLOCKS // 2, 1)))
 def test_fuzz_encoder_equals_oracle(block):
     """Row f2: reorder on the GPU, then the encoder stage on the GPU vs the encoder oracle on the same streams,
